@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path (diffnorm_amd/).
+
+Leaf-file loader for the upstream reference's hot-path modules, used ONLY in the
+build container (where /root/reference is mounted) to
+
+  * validate the CPU restatement in ``oracle/diffnorm_oracle.py`` and
+  * generate the golden vectors committed under ``tests/golden/`` (see
+    ``oracle/gen_golden.py``).
+
+``import fairseq`` as a whole fails here (omegaconf/hydra are absent), so the hot-path
+files are loaded one by one under their real dotted names with empty package stubs
+around them (recipe: SURVEY.md section 10).  Nothing is copied out of the reference;
+the modules are executed where they lie.  The reference never travels to the GPU box,
+so nothing under tests/ marked ``gpu``, ``bench.py`` or ``__graft_entry__.smoke`` may
+call this module.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+REF = os.environ.get("DIFFNORM_REFERENCE", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(REF, "fairseq/models/text_to_speech/latent_module.py"))
+
+
+def _pkg(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+_CACHE = {}
+
+
+def load_reference():
+    """Returns (latent_module, gaussian_diffusion_pkg) of the reference."""
+    if "lm" in _CACHE:
+        return _CACHE["lm"], _CACHE["gd"]
+    if not available():
+        raise RuntimeError("reference checkout not present at %s" % REF)
+    sys.dont_write_bytecode = True  # the reference mount is read-only
+    import torch
+
+    for n in ("torchaudio", "torchaudio.transforms", "torchaudio.functional", "sacrebleu"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)  # imported, never used on the path
+    fs = _pkg("fairseq")
+    fs.utils = _load("fairseq.utils", "fairseq/utils.py")
+    mods = _pkg("fairseq.modules")
+    _load("fairseq.modules.learned_positional_embedding", "fairseq/modules/learned_positional_embedding.py")
+    _load("fairseq.modules.sinusoidal_positional_embedding", "fairseq/modules/sinusoidal_positional_embedding.py")
+    mods.PositionalEmbedding = _load(
+        "fairseq.modules.positional_embedding", "fairseq/modules/positional_embedding.py"
+    ).PositionalEmbedding
+    _pkg("fairseq.models").FairseqEncoder = _load(
+        "fairseq.models.fairseq_encoder", "fairseq/models/fairseq_encoder.py"
+    ).FairseqEncoder
+    _pkg("fairseq.criterions")
+    ls = types.ModuleType("fairseq.criterions.label_smoothed_cross_entropy")
+
+    # the real file drags omegaconf; this is the build's own restatement of the
+    # label-smoothed NLL (reference: fairseq/criterions/label_smoothed_cross_entropy.py:34-51)
+    def label_smoothed_nll_loss(lprobs, target, epsilon, ignore_index=None, reduce=True):
+        tgt = target.unsqueeze(-1) if target.dim() == lprobs.dim() - 1 else target
+        nll = -lprobs.gather(-1, tgt)
+        smooth = -lprobs.sum(-1, keepdim=True)
+        if ignore_index is not None:
+            pad = tgt.eq(ignore_index)
+            nll = nll.masked_fill(pad, 0.0)
+            smooth = smooth.masked_fill(pad, 0.0)
+        else:
+            nll, smooth = nll.squeeze(-1), smooth.squeeze(-1)
+        if reduce:
+            nll, smooth = nll.sum(), smooth.sum()
+        eps_i = epsilon / (lprobs.size(-1) - 1)
+        return (1.0 - epsilon - eps_i) * nll + eps_i * smooth, nll
+
+    ls.label_smoothed_nll_loss = label_smoothed_nll_loss
+    sys.modules[ls.__name__] = ls
+    _pkg("fairseq.models.text_to_speech")
+    _load("fairseq.models.text_to_speech.distributions", "fairseq/models/text_to_speech/distributions.py")
+    lm = _load("fairseq.models.text_to_speech.latent_module", "fairseq/models/text_to_speech/latent_module.py")
+    p = os.path.join(REF, "fairseq/models/text_to_speech/diffusion")
+    spec = importlib.util.spec_from_file_location(
+        "refdiffusion", os.path.join(p, "__init__.py"), submodule_search_locations=[p]
+    )
+    gd = importlib.util.module_from_spec(spec)
+    sys.modules["refdiffusion"] = gd
+    spec.loader.exec_module(gd)
+    _CACHE["lm"], _CACHE["gd"] = lm, gd
+    return lm, gd
