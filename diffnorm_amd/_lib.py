@@ -1,0 +1,121 @@
+"""ctypes binding of libdiffnorm_hip.so (C ABI: include/diffnorm_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this module
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C diffnorm_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffnorm_hip.so")
+
+DN_F32, DN_BF16 = 0, 1
+EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB = range(6)
+DN_MAX_TERMS = 8
+
+
+class DiffNormHipError(RuntimeError):
+    pass
+
+
+class GemmTerm(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("lda", C.c_int32), ("shift", C.c_int32),
+                ("a_gstride", C.c_int64), ("w_gstride", C.c_int64), ("shift_by_group", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("terms", GemmTerm * DN_MAX_TERMS), ("n_terms", C.c_int32), ("dtype", C.c_int32),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
+                ("groups", C.c_int32), ("epilogue", C.c_int32), ("bias", C.c_void_p),
+                ("bias_gstride", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int32),
+                ("out_dtype", C.c_int32), ("out_gstride", C.c_int64), ("res", C.c_void_p),
+                ("ldr", C.c_int32), ("res_dtype", C.c_int32), ("res_gstride", C.c_int64),
+                ("gamma_beta", C.c_void_p), ("gb_ld", C.c_int32), ("gb_half", C.c_int32),
+                ("gb_gstride", C.c_int64), ("pos_table", C.c_void_p), ("pos_ld", C.c_int32),
+                ("pad_", C.c_int32), ("lengths", C.c_void_p)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+                ("B", C.c_int32), ("T", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32),
+                ("dtype", C.c_int32), ("pad_", C.c_int32), ("lengths", C.c_void_p),
+                ("scale", C.c_float), ("pad2_", C.c_int32)]
+
+
+class EpsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "latent", "depth", "heads", "dim_head", "wn_layers",
+                                         "wn_stacks", "cond_mult", "dtype", "max_pos")]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "z", "depth", "heads", "dim_head", "stacks", "layers",
+                                         "vocab", "n_mults")] + [("mults", C.c_int32 * 4), ("dtype", C.c_int32)]
+
+
+# every symbol include/diffnorm_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+SYMBOLS = {
+    "dn_conv_gemm": (C.c_int, [C.POINTER(GemmParams), _vp]),
+    "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),
+    "dn_rmsnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "dn_time_cond": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "dn_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dn_posterior_sample": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_argmax_units": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_randn": (C.c_int, [_vp, _i64, _u64, _u64, _vp]),
+    "dn_convert_rows": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dn_eps_create": (C.c_int, [C.POINTER(EpsConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
+    "dn_eps_destroy": (None, [_vp]),
+    "dn_eps_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "dn_eps_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_vae_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
+    "dn_vae_destroy": (None, [_vp]),
+    "dn_vae_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "dn_vae_encode_params": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_vae_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dn_ddim_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "dn_last_error": (C.c_char_p, []),
+    "dn_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and binds every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DiffNormHipError(
+            f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
+            "Build it with `make -C diffnorm_amd/csrc` or `__graft_entry__.build()`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().dn_last_error()
+        raise DiffNormHipError(f"{what or 'libdiffnorm_hip'} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or 0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

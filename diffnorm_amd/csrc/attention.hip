@@ -1,0 +1,253 @@
+// dn_attention: fused key-masked multi-head self-attention (flash-style, online softmax) for gfx950.
+//
+// Workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries (two 16-query
+// tiles) and walks the keys in tiles of 64 staged in LDS.  Both products run "transposed" so that the
+// query index lives on the MFMA column (= lane & 15):
+//     S^T = K . Q^T      A operand = K rows from LDS (ds_read_b128), B operand = Q fragments in registers
+//     O^T = V^T . P^T    A operand = V^T, B operand = P^T straight from the S^T accumulators
+// With that orientation the softmax statistics of a query are lane-local up to two xor-shuffles
+// (lanes l, l^16, l^32, l^48 hold the same query), the O rescale is a per-lane scalar, and P needs no
+// LDS round trip: the S^T accumulator registers of two 16-key tiles, converted to bf16, ARE the B
+// fragment of a 32-key k-step once the V^T fragment is gathered with the same key permutation --
+// which is exactly what ds_read_b64_tr_b16 delivers from a row-major V tile (4 keys x 16 dims per
+// 16-lane group).  In f32 mode each v_mfma_f32_16x16x4_f32 takes one P register and one scalar LDS
+// read of V.  LDS rows are 256 B (bf16) / 512 B (f32) with an XOR swizzle that makes the K row reads,
+// the V transposed reads and the f32 scalar reads bank-conflict-free (see lds_off).
+#include "common.h"
+
+namespace dn {
+
+template <typename E> struct AttnGeom;
+template <> struct AttnGeom<BF16> { static constexpr int ROWB = 256; };
+template <> struct AttnGeom<F32> { static constexpr int ROWB = 512; };
+
+// byte offset of byte `byte` (16-B aligned pieces stay contiguous) of row `row` in a K/V tile
+template <typename E>
+__device__ __forceinline__ int lds_off(int row, int byte);
+template <>
+__device__ __forceinline__ int lds_off<BF16>(int row, int byte) {
+  return row * 256 + ((((byte >> 5) ^ (row & 7))) << 5) + (byte & 31);
+}
+template <>
+__device__ __forceinline__ int lds_off<F32>(int row, int byte) {
+  return row * 512 + (((byte >> 4) ^ (row & 15)) << 4) + (byte & 15);
+}
+
+constexpr int KV_TILE = 64;
+constexpr float NEG_BIG = -3.0e38f;
+
+template <typename E, int DHP>
+__global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int ROWB = AttnGeom<E>::ROWB;
+  constexpr int KS_D = DHP * ES / 64;    // 64-byte k-steps along the head dim (QK^T)
+  constexpr int NCH = DHP * ES / 16;     // 16-byte chunks per K/V row
+  constexpr int DT = DHP / 16;           // 16-wide output tiles along the head dim
+  char* k_lds = smem;
+  char* v_lds = smem + KV_TILE * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = p.T, dh = p.dim_head;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int dhb = dh * ES;  // valid bytes per head row
+
+  const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
+  const char* kp = reinterpret_cast<const char*>(p.k) + ((int64_t)b * T * p.ldk + h * dh) * ES;
+  const char* vp = reinterpret_cast<const char*>(p.v) + ((int64_t)b * T * p.ldv + h * dh) * ES;
+
+  // Q fragments (B operand): row = query, chunk = ks*4 + fg
+  uint4 qf[2][KS_D];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int q = q0 + qt * 16 + fr;
+    q = q < T ? q : T - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS_D; ++ks) {
+      const int byte = ks * 64 + fg * 16;
+      qf[qt][ks] = byte < dhb ? *reinterpret_cast<const uint4*>(qp + (int64_t)q * p.ldq * ES + byte) : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  f32x4 acc_o[DT][2];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i][0] = acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+
+  int len = p.lengths ? p.lengths[b] : T;
+  len = len < T ? len : T;
+  if (len <= 0) len = T;  // every key masked: masked_fill gives a uniform softmax over all T keys
+  const float sc = p.scale * 1.44269504088896340736f;  // work in log2 domain
+
+  for (int kv0 = 0; kv0 < len; kv0 += KV_TILE) {
+    __syncthreads();  // previous tile fully consumed
+    for (int idx = tid; idx < KV_TILE * NCH; idx += 256) {
+      const int row = idx / NCH, ch = idx - row * NCH;
+      const int key = kv0 + row;
+      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
+      if (key < T && ch * 16 < dhb) {
+        kv4 = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
+        vv4 = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
+      }
+      const int off = lds_off<E>(row, ch * 16);
+      *reinterpret_cast<uint4*>(k_lds + off) = kv4;
+      *reinterpret_cast<uint4*>(v_lds + off) = vv4;
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T : acc_s[kt][qt][r] = S[query qt*16+fr][key kt*16 + 4*fg + r]
+    f32x4 acc_s[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc_s[kt][0] = acc_s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS_D; ++ks) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(k_lds + lds_off<E>(kt * 16 + fr, ks * 64 + fg * 16));
+        mma_kstep<E>(acc_s[kt][0], kf, qf[0][ks]);
+        mma_kstep<E>(acc_s[kt][1], kf, qf[1][ks]);
+      }
+    }
+
+    // ---- online softmax (log2 domain), per query tile
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kt * 16 + fg * 4 + r;
+          const float s = key < len ? acc_s[kt][qt][r] * sc : NEG_BIG;
+          acc_s[kt][qt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = exp2f(m_run[qt] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = exp2f(acc_s[kt][qt][r] - m_new);
+          acc_s[kt][qt][r] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[qt] = l_run[qt] * alpha + rs;
+      m_run[qt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
+    }
+
+    // ---- O^T += V^T . P^T
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {  // 32-key k-steps = accumulator tiles (2kk, 2kk+1)
+        uint4 pf[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          pf[qt].x = pack_bf16x2(acc_s[2 * kk][qt][0], acc_s[2 * kk][qt][1]);
+          pf[qt].y = pack_bf16x2(acc_s[2 * kk][qt][2], acc_s[2 * kk][qt][3]);
+          pf[qt].z = pack_bf16x2(acc_s[2 * kk + 1][qt][0], acc_s[2 * kk + 1][qt][1]);
+          pf[qt].w = pack_bf16x2(acc_s[2 * kk + 1][qt][2], acc_s[2 * kk + 1][qt][3]);
+        }
+        // transposed read: lane i of a 16-lane group supplies row (i>>2) cols 4*(i&3).., receives column i
+        const int krow0 = (2 * kk) * 16 + fg * 4 + (fr >> 2);
+        const int krow1 = krow0 + 16;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int byte = dt * 32 + (fr & 3) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(v_lds + lds_off<E>(krow0, byte)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(v_lds + lds_off<E>(krow1, byte)));
+          uint4 vf;
+          const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+          vf.x = lo2.x; vf.y = lo2.y; vf.z = hi2.x; vf.w = hi2.y;
+          mma_kstep<E>(acc_o[dt][0], vf, pf[0]);
+          mma_kstep<E>(acc_o[dt][1], vf, pf[1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + fg * 4 + r;  // k-slot fg of MFMA (kt, r)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const float vv = *reinterpret_cast<const float*>(v_lds + lds_off<E>(key, (dt * 16 + fr) * 4));
+            acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][0][r], acc_o[dt][0], 0, 0, 0);
+            acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][1][r], acc_o[dt][1], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- O = acc / l ; lane holds dims dt*16 + 4*fg + 0..3 of query qt*16 + fr
+  char* op = reinterpret_cast<char*>(p.out);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + fr;
+    if (q >= T) continue;
+    const float inv = 1.0f / l_run[qt];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + fg * 4;
+      if (d >= dh) continue;
+      const f32x4 o = acc_o[dt][qt];
+      store4(op, ((int64_t)b * T + q) * p.ldo + h * dh + d, p.dtype, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    }
+  }
+}
+
+template <typename E, int DHP>
+static int launch_attn(const DnAttnParams& p, hipStream_t s) {
+  constexpr int lds = 2 * KV_TILE * AttnGeom<E>::ROWB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  dim3 grid((p.T + 127) / 128, p.heads, p.B);
+  hipLaunchKernelGGL((attn_kernel<E, DHP>), grid, dim3(256), lds, s, p);
+  DN_CHECK_LAUNCH("dn_attention");
+  return DN_OK;
+}
+
+}  // namespace dn
+
+extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
+  DN_CHECK_ARG(pp != nullptr, "dn_attention: null params");
+  const DnAttnParams& p = *pp;
+  DN_CHECK_ARG(p.q && p.k && p.v && p.out, "dn_attention: null tensor");
+  DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0, "dn_attention: bad shape");
+  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_attention: bad dtype");
+  const int es = p.dtype == DN_BF16 ? 2 : 4;
+  DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);
+  DN_CHECK_ARG((p.ldq * es) % 16 == 0 && (p.ldk * es) % 16 == 0 && (p.ldv * es) % 16 == 0 && p.ldo % 4 == 0,
+               "dn_attention: row strides must keep 16-byte alignment");
+  DN_CHECK_ARG(((uintptr_t)p.q & 15) == 0 && ((uintptr_t)p.k & 15) == 0 && ((uintptr_t)p.v & 15) == 0 && ((uintptr_t)p.out & 15) == 0,
+               "dn_attention: tensors must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int dh = p.dim_head;
+  if (p.dtype == DN_BF16) {
+    if (dh <= 32) return dn::launch_attn<dn::BF16, 32>(p, s);
+    if (dh <= 64) return dn::launch_attn<dn::BF16, 64>(p, s);
+    if (dh <= 96) return dn::launch_attn<dn::BF16, 96>(p, s);
+    if (dh <= 128) return dn::launch_attn<dn::BF16, 128>(p, s);
+  } else {
+    if (dh <= 16) return dn::launch_attn<dn::F32, 16>(p, s);
+    if (dh <= 32) return dn::launch_attn<dn::F32, 32>(p, s);
+    if (dh <= 64) return dn::launch_attn<dn::F32, 64>(p, s);
+    if (dh <= 96) return dn::launch_attn<dn::F32, 96>(p, s);
+  }
+  dn_set_error("dn_attention: dim_head %d not supported", dh);
+  return DN_EINVAL;
+}

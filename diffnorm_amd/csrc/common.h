@@ -1,0 +1,93 @@
+// Device-side helpers shared by the gfx950 kernels of libdiffnorm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diffnorm_hip.h"
+
+namespace dn {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct BF16 {};  // tag types selecting the contraction arithmetic
+struct F32 {};
+
+template <typename E> struct Elem;
+template <> struct Elem<BF16> { static constexpr int bytes = 2; static constexpr int kDtype = DN_BF16; };
+template <> struct Elem<F32> { static constexpr int bytes = 4; static constexpr int kDtype = DN_F32; };
+
+// One "k-step" = 64 bytes of K per row; a fragment is the 16 bytes a lane holds of it:
+// lane l -> row (l & 15), 16-byte chunk (l >> 4) of the 64-byte k-step.
+//   bf16: 8 consecutive k per lane, one v_mfma_f32_16x16x32_bf16 per k-step (32 k).
+//   f32 : 4 consecutive k per lane, four v_mfma_f32_16x16x4_f32 per k-step (16 k); MFMA j consumes
+//         element j of every lane, i.e. k-slot q of MFMA j is k = 4q + j.  A and B fragments use the
+//         same lane->k map, so the sum over the k-step is exact.
+// acc: C[row = 4*(l>>4) + r][col = l & 15] for the A-operand rows / B-operand rows (cols).
+template <typename E>
+__device__ __forceinline__ void mma_kstep(f32x4& acc, const uint4& a, const uint4& b);
+
+template <>
+__device__ __forceinline__ void mma_kstep<BF16>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ void mma_kstep<F32>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserved
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// store 4 consecutive fp32 values as out_dtype at element pointer (row base + col)
+__device__ __forceinline__ void store4(void* base, int64_t elem_off, int out_dtype, float a, float b, float c, float d) {
+  if (out_dtype == DN_BF16) {
+    uint2 v = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem_off) = v;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem_off) = make_float4(a, b, c, d);
+  }
+}
+
+__device__ __forceinline__ float4 load4(const void* base, int64_t elem_off, int dtype) {
+  if (dtype == DN_BF16) {
+    uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_sigmoid_gate(float h) { return tanhf(h) * (1.0f / (1.0f + expf(-h))); }
+
+}  // namespace dn
+
+// host-side error plumbing (defined in capi.hip)
+void dn_set_error(const char* fmt, ...);
+#define DN_CHECK_ARG(cond, ...)  \
+  do {                           \
+    if (!(cond)) {               \
+      dn_set_error(__VA_ARGS__); \
+      return DN_EINVAL;          \
+    }                            \
+  } while (0)
+#define DN_CHECK_LAUNCH(what)                                             \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      dn_set_error("%s: %s", what, hipGetErrorString(e__));               \
+      return DN_ELAUNCH;                                                  \
+    }                                                                     \
+  } while (0)

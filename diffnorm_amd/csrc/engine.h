@@ -1,0 +1,82 @@
+// Host-side orchestration of the DiffNorm hot path on top of the op-level C ABI: sub-model
+// descriptors (WaveNet, conditionable transformer), the workspace bump allocator, and the packed
+// weight order shared with diffnorm_amd/packing.py.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/diffnorm_hip.h"
+
+namespace dn {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int padk(int c) { return round_up(c, 64); }    // channel width as a K dimension / row stride
+inline int padn(int c) { return round_up(c, 128); }   // packed weight rows
+
+struct Arena {  // bump allocator over the caller's workspace; base == nullptr only measures
+  char* base;
+  size_t off, cap;
+  void* take(size_t bytes) {
+    size_t a = (off + 255) & ~size_t(255);
+    off = a + bytes;
+    if (!base) return reinterpret_cast<void*>(a + 256);  // non-null dummy while measuring
+    return off <= cap ? base + a : nullptr;
+  }
+};
+
+// WaveNet / WavenetEncoder (latent_module.py:585-617, 1003-1032).  Packed tensors (packing.py):
+//   init_W [3][padn(cout)][padk(cin)]   init_b [padk(cout)]
+//   conv_W [S][L][3][padn(cout)][padk(cout)]   conv_b [S][L][padk(cout)]
+//   res_W  [S][L][padn(cout)][padk(cout)]      res_b  [S][L][padk(cout)]
+//   skip_W [L][padn(cout)][padk(cout)]         skip_b [padk(cout)]  (sum over the L blocks)
+//   final_W [padn(cout)][padk(cout)]           final_b [padk(cout)]
+struct WavenetW {
+  int cin, cout, stacks, layers;
+  const void *init_W, *conv_W, *res_W, *skip_W, *final_W;
+  const float *init_b, *conv_b, *res_b, *skip_b, *final_b;
+};
+constexpr int kWavenetTensors = 10;
+
+// ConditionableTransformer (latent_module.py:642-706).  Packed tensors:
+//   qkv_W [depth][padn(3*hd)][padk(D)]  (rows: to_q ; to_kv)       out_W [depth][padn(D)][padk(hd)]
+//   ffin_W [depth][2*padk(inner)][padk(D)] GEGLU-interleaved        ffin_b [depth][2*padk(inner)]
+//   ffconv_W [depth][3][padn(inner)][padk(inner)]                   ffconv_b [depth][padk(inner)]
+//   ffout_W [depth][padn(D)][padk(inner)]                           ffout_b [depth][padk(D)]
+//   g1, g2 [depth][D] learned RMSNorm gammas (NULL when time-conditioned)
+//   pred_gamma [D]   pred_W [padn(D)][padk(D)]
+struct TransformerW {
+  int dim, depth, heads, dim_head, inner;
+  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W;
+  const float *ffin_b, *ffconv_b, *ffout_b, *g1, *g2, *pred_gamma;
+};
+constexpr int kTransformerTensors = 12;
+
+}  // namespace dn
+
+struct DnEps {
+  DnEpsConfig cfg;
+  // packed tensors in table order: w_freq, tc_W, tc_b, cond_W, cond_b, init_W, init_b,
+  // <wavenet x10>, <transformer x12>, final_W, final_b, pos_table
+  const float *w_freq, *tc_W, *tc_b, *cond_b, *init_b, *final_b, *pos_table;
+  const void *cond_W, *init_W, *final_W;
+  dn::WavenetW wn;
+  dn::TransformerW tf;
+  int n_cond;  // columns of the conditioning table: 2*padk(dim) per conditioned module
+  // hipGraph cache for dn_ddim_loop
+  void* graph_exec;
+  int graph_B, graph_T;
+  void* graph_ws;
+  float* graph_x;
+  const int32_t* graph_len;
+  const float* graph_coef;
+};
+constexpr int kEpsTensors = 7 + dn::kWavenetTensors + dn::kTransformerTensors + 3;
+
+struct DnVae {
+  DnVaeConfig cfg;
+  int n_wave;
+  dn::WavenetW enc[4], dec[4];
+  dn::TransformerW tf;
+  const void* lm_W;
+  const float* lm_b;
+};

@@ -1,0 +1,578 @@
+// Whole-path engine: the eps-predictor `Model`, the speech VAE and the DDIM device loop, expressed as
+// sequences of dn_conv_gemm / dn_attention / pointwise launches on one stream.  Nothing here
+// allocates or synchronises; every intermediate lives in the caller's workspace (bump-allocated by
+// the plan_* functions, which also serve the *_workspace_bytes queries).
+#include <new>
+#include <string.h>
+
+#include "common.h"
+#include "engine.h"
+
+using namespace dn;
+
+namespace {
+
+inline const void* eoff(const void* p, size_t elems, int es) { return static_cast<const char*>(p) + elems * es; }
+inline void* eoff(void* p, size_t elems, int es) { return static_cast<char*>(p) + elems * es; }
+inline int esize(int dtype) { return dtype == DN_BF16 ? 2 : 4; }
+
+#define DN_TRY(expr)          \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != DN_OK) return rc__; \
+  } while (0)
+
+DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
+  DnGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.dtype = dtype;
+  p.M = M; p.N = N; p.K = K; p.T = T;
+  p.groups = 1;
+  p.n_terms = 1;
+  p.epilogue = DN_EPI_BIAS;
+  p.out_dtype = dtype;
+  p.res_dtype = dtype;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------ WaveNet
+struct WaveBufs { void *hw, *resb, *blk0, *blk1, *sk; };
+
+WaveBufs plan_wave(const WavenetW& w, int M, int es, Arena& ar) {
+  const size_t one = (size_t)M * padk(w.cout) * es;
+  WaveBufs b;
+  b.hw = ar.take(one);
+  b.resb = ar.take(one * w.layers);
+  b.blk0 = ar.take(one * w.layers);
+  b.blk1 = ar.take(one * w.layers);
+  b.sk = ar.take(one);
+  return b;
+}
+
+// `fin` carries the destination of the final 1x1 conv (out, ldo, out_dtype, N, epilogue and its extras).
+int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, const float* gb, int gb_ld, const WaveBufs& wb,
+                DnGemmParams fin, hipStream_t s) {
+  const int es = esize(dtype);
+  const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.layers, S = w.stacks;
+  const size_t mat = (size_t)cn * cp;
+  const int64_t plane = (int64_t)M * cp;
+  {  // init conv, k=3, dilation 1 (latent_module.py:596,614 / 1014,1029)
+    DnGemmParams p = gemm_base(dtype, M, cp, cinp, T);
+    p.n_terms = 3;
+    for (int j = 0; j < 3; ++j) {
+      p.terms[j].A = in; p.terms[j].lda = cinp; p.terms[j].shift = 2 - j;
+      p.terms[j].W = eoff(w.init_W, (size_t)j * cn * cinp, es);
+    }
+    p.bias = w.init_b; p.out = wb.hw; p.ldo = cp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  for (int st = 0; st < S; ++st) {
+    const void* in_s = st == 0 ? wb.hw : ((st - 1) & 1 ? wb.blk1 : wb.blk0);
+    const int64_t a_gs = st == 0 ? 0 : plane;  // stack 0 feeds one tensor to all blocks (:570-571)
+    void* out_s = (st & 1) ? wb.blk1 : wb.blk0;
+    {  // res_conv 1x1 of the L blocks (:510,521)
+      DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+      p.groups = L;
+      p.terms[0].A = in_s; p.terms[0].lda = cp; p.terms[0].a_gstride = a_gs;
+      p.terms[0].W = eoff(w.res_W, (size_t)st * L * mat, es); p.terms[0].w_gstride = (int64_t)mat;
+      p.bias = w.res_b + (size_t)st * L * cp; p.bias_gstride = cp;
+      p.out = wb.resb; p.ldo = cp; p.out_gstride = plane;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {  // dilated conv k=3 (dilation 2^block) + FiLM + tanh*sigmoid + residual (:509,523-530)
+      DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+      p.groups = L;
+      p.n_terms = 3;
+      for (int j = 0; j < 3; ++j) {
+        p.terms[j].A = in_s; p.terms[j].lda = cp; p.terms[j].a_gstride = a_gs;
+        p.terms[j].shift = 2 - j; p.terms[j].shift_by_group = 1;
+        p.terms[j].W = eoff(w.conv_W, ((size_t)st * L * 3 + j) * mat, es); p.terms[j].w_gstride = (int64_t)(3 * mat);
+      }
+      p.bias = w.conv_b + (size_t)st * L * cp; p.bias_gstride = cp;
+      p.epilogue = DN_EPI_FILM_GATE;
+      p.res = wb.resb; p.ldr = cp; p.res_gstride = plane;
+      if (gb) {
+        p.gamma_beta = gb + (size_t)st * L * 2 * cp; p.gb_ld = gb_ld; p.gb_half = cp; p.gb_gstride = 2 * cp;
+      }
+      p.out = out_s; p.ldo = cp; p.out_gstride = plane;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+  }
+  const void* last = ((S - 1) & 1) ? wb.blk1 : wb.blk0;
+  {  // sum over blocks of skip_conv(out_i): one contraction with L terms (:511,534,617)
+    DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+    p.n_terms = L;
+    for (int i = 0; i < L; ++i) {
+      p.terms[i].A = eoff(last, (size_t)i * plane, es); p.terms[i].lda = cp;
+      p.terms[i].W = eoff(w.skip_W, (size_t)i * mat, es);
+    }
+    p.bias = w.skip_b; p.out = wb.sk; p.ldo = cp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  fin.dtype = dtype; fin.M = M; fin.K = cp; fin.T = T; fin.groups = 1; fin.n_terms = 1;
+  fin.terms[0].A = wb.sk; fin.terms[0].lda = cp; fin.terms[0].W = w.final_W;
+  fin.bias = w.final_b;
+  return dn_conv_gemm(&fin, s);
+}
+
+// ------------------------------------------------------------------------------------------ transformer
+struct TfBufs { void *xn, *qkv, *ao, *gg, *fc; };
+
+TfBufs plan_tf(const TransformerW& w, int M, int es, Arena& ar) {
+  const int hd = w.heads * w.dim_head;
+  TfBufs b;
+  b.xn = ar.take((size_t)M * padk(w.dim) * es);
+  b.qkv = ar.take((size_t)M * 3 * hd * es);
+  b.ao = ar.take((size_t)M * hd * es);
+  b.gg = ar.take((size_t)M * padk(w.inner) * es);
+  b.fc = ar.take((size_t)M * padk(w.inner) * es);
+  return b;
+}
+
+// xres fp32 [M, padk(dim)] is updated in place; `pred` receives to_pred's output.
+int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T, const int32_t* lengths, const float* gb, int gb_ld,
+                    const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, hipStream_t s) {
+  const int es = esize(dtype), M = B * T;
+  const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
+  for (int l = 0; l < w.depth; ++l) {
+    const float* gb1 = gb ? gb + (size_t)(2 * l) * 2 * Dp : nullptr;
+    const float* gb2 = gb ? gb + (size_t)(2 * l + 1) * 2 * Dp : nullptr;
+    DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.g1 ? w.g1 + (size_t)l * D : nullptr, gb1, gb_ld, Dp, s));
+    {  // to_q ; to_kv in one contraction (:930-931,945)
+      DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
+      p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
+      p.out = tb.qkv; p.ldo = 3 * hd;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      DnAttnParams a;
+      memset(&a, 0, sizeof(a));
+      a.q = tb.qkv; a.k = eoff(tb.qkv, hd, es); a.v = eoff(tb.qkv, 2 * hd, es); a.out = tb.ao;
+      a.ldq = a.ldk = a.ldv = 3 * hd; a.ldo = hd;
+      a.B = B; a.T = T; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = lengths;
+      a.scale = 1.0f / sqrtf((float)w.dim_head);
+      DN_TRY(dn_attention(&a, s));
+    }
+    {  // to_out + residual (:932,692)
+      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
+      p.terms[0].A = tb.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
+      p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.g2 ? w.g2 + (size_t)l * D : nullptr, gb2, gb_ld, Dp, s));
+    {  // Linear(D -> 2*inner) + GEGLU (:899,881-884)
+      DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
+      p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
+      p.bias = w.ffin_b + (size_t)l * 2 * ip;
+      p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {  // CausalConv1d(inner, inner, 3) (:894)
+      DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
+      p.n_terms = 3;
+      for (int j = 0; j < 3; ++j) {
+        p.terms[j].A = tb.gg; p.terms[j].lda = ip; p.terms[j].shift = 2 - j;
+        p.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
+      }
+      p.bias = w.ffconv_b + (size_t)l * ip; p.out = tb.fc; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {  // Linear(inner -> D) + residual (:902,704)
+      DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
+      p.terms[0].A = tb.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
+      p.bias = w.ffout_b + (size_t)l * Dp;
+      p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+  }
+  // to_pred = RMSNorm(gamma) + Linear(D, D, no bias) (:676-679)
+  DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.pred_gamma, nullptr, 0, 0, s));
+  DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
+  p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = w.pred_W;
+  p.out = pred; p.ldo = pred_ld; p.out_dtype = pred_dtype;
+  if (pred_ld < Dp) p.N = pred_ld;  // dense fp32 destination narrower than the padded width
+  return dn_conv_gemm(&p, s);
+}
+
+const void* const* take_wavenet(WavenetW& w, const void* const* t) {
+  w.init_W = t[0]; w.init_b = (const float*)t[1]; w.conv_W = t[2]; w.conv_b = (const float*)t[3];
+  w.res_W = t[4]; w.res_b = (const float*)t[5]; w.skip_W = t[6]; w.skip_b = (const float*)t[7];
+  w.final_W = t[8]; w.final_b = (const float*)t[9];
+  return t + kWavenetTensors;
+}
+
+const void* const* take_transformer(TransformerW& w, const void* const* t) {
+  w.qkv_W = t[0]; w.out_W = t[1]; w.ffin_W = t[2]; w.ffin_b = (const float*)t[3]; w.ffconv_W = t[4];
+  w.ffconv_b = (const float*)t[5]; w.ffout_W = t[6]; w.ffout_b = (const float*)t[7];
+  w.g1 = (const float*)t[8]; w.g2 = (const float*)t[9]; w.pred_gamma = (const float*)t[10]; w.pred_W = t[11];
+  return t + kTransformerTensors;
+}
+
+int check_dims(const char* who, int dtype, int dim, int heads, int dim_head, int layers) {
+  DN_CHECK_ARG(dtype == DN_F32 || dtype == DN_BF16, "%s: bad dtype %d", who, dtype);
+  DN_CHECK_ARG(dim > 0 && dim % 4 == 0, "%s: dim=%d must be a positive multiple of 4", who, dim);
+  DN_CHECK_ARG((heads * dim_head) % 64 == 0, "%s: heads*dim_head=%d must be a multiple of 64", who, heads * dim_head);
+  DN_CHECK_ARG(layers >= 1 && layers <= DN_MAX_TERMS, "%s: wavenet layers=%d must be in 1..%d", who, layers, DN_MAX_TERMS);
+  return DN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ eps plan
+struct EpsBufs {
+  float *cond, *gb, *xres;
+  void *cond_act, *xin, *h0, *tp;
+  WaveBufs wv;
+  TfBufs tf;
+};
+
+EpsBufs plan_eps(const DnEps* m, int B, int T, int Bt, Arena& ar) {
+  const int es = esize(m->cfg.dtype), M = B * T;
+  const int C = m->cfg.dim * m->cfg.cond_mult, Dp = padk(m->cfg.dim), zp = padk(m->cfg.latent);
+  EpsBufs b;
+  b.cond = (float*)ar.take((size_t)Bt * C * 4);
+  b.cond_act = ar.take((size_t)Bt * C * es);
+  b.gb = (float*)ar.take((size_t)Bt * m->n_cond * 4);
+  b.xin = ar.take((size_t)M * zp * es);
+  b.h0 = ar.take((size_t)M * Dp * es);
+  b.wv = plan_wave(m->wn, M, es, ar);
+  b.xres = (float*)ar.take((size_t)M * Dp * 4);
+  b.tf = plan_tf(m->tf, M, es, ar);
+  b.tp = ar.take((size_t)M * Dp * es);
+  return b;
+}
+
+__global__ void fill_t_kernel(int32_t* t, int n, const int32_t* counter) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) t[i] = *counter;
+}
+__global__ void set_counter_kernel(int32_t* counter, int v) { *counter = v; }
+__global__ void dec_counter_kernel(int32_t* counter) { *counter -= 1; }
+
+}  // namespace
+
+// =========================================================================================== eps
+extern "C" int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights, int32_t n_weights, DnEps** out) {
+  DN_CHECK_ARG(cfg && weights && out, "dn_eps_create: null argument");
+  DN_CHECK_ARG(n_weights == kEpsTensors, "dn_eps_create: expected %d packed tensors, got %d", kEpsTensors, n_weights);
+  DN_TRY(check_dims("dn_eps_create", cfg->dtype, cfg->dim, cfg->heads, cfg->dim_head, cfg->wn_layers));
+  DN_CHECK_ARG(cfg->dim % 2 == 0 && (cfg->dim * cfg->cond_mult) % 64 == 0, "dn_eps_create: dim*cond_mult must be a multiple of 64");
+  DN_CHECK_ARG(cfg->latent % 4 == 0 && cfg->latent > 0, "dn_eps_create: latent=%d must be a multiple of 4", cfg->latent);
+  for (int i = 0; i < n_weights; ++i) DN_CHECK_ARG(weights[i] != nullptr, "dn_eps_create: packed tensor %d is null", i);
+  DnEps* m = new (std::nothrow) DnEps();
+  DN_CHECK_ARG(m != nullptr, "dn_eps_create: out of host memory");
+  memset(m, 0, sizeof(*m));
+  m->cfg = *cfg;
+  const void* const* t = weights;
+  m->w_freq = (const float*)t[0]; m->tc_W = (const float*)t[1]; m->tc_b = (const float*)t[2];
+  m->cond_W = t[3]; m->cond_b = (const float*)t[4]; m->init_W = t[5]; m->init_b = (const float*)t[6];
+  t += 7;
+  m->wn.cin = m->wn.cout = cfg->dim; m->wn.stacks = cfg->wn_stacks; m->wn.layers = cfg->wn_layers;
+  t = take_wavenet(m->wn, t);
+  m->tf.dim = cfg->dim; m->tf.depth = cfg->depth; m->tf.heads = cfg->heads; m->tf.dim_head = cfg->dim_head;
+  m->tf.inner = (int)((double)cfg->dim * 4 * 2 / 3);  // int(dim*mult*2/3), latent_module.py:888
+  t = take_transformer(m->tf, t);
+  m->tf.g1 = m->tf.g2 = nullptr;  // time-conditioned norms carry no learned gamma (:662-663)
+  m->final_W = t[0]; m->final_b = (const float*)t[1]; m->pos_table = (const float*)t[2];
+  m->n_cond = (cfg->wn_stacks * cfg->wn_layers + 2 * cfg->depth) * 2 * padk(cfg->dim);
+  *out = m;
+  return DN_OK;
+}
+
+extern "C" void dn_eps_destroy(DnEps* m) {
+  if (!m) return;
+  if (m->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)m->graph_exec);
+  delete m;
+}
+
+static size_t eps_ws_core(const DnEps* m, int B, int T) {
+  Arena ar{nullptr, 0, 0};
+  (void)plan_eps(m, B, T, B, ar);
+  return ar.off + 256;
+}
+
+extern "C" size_t dn_eps_workspace_bytes(const DnEps* m, int32_t B, int32_t T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  // + the DDIM loop's own state (eps buffer, t vector, counter) so one query serves both entry points
+  return eps_ws_core(m, B, T) + (size_t)B * T * m->cfg.latent * 4 + (size_t)B * 4 + 1024;
+}
+
+extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
+                              int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && x && t && lengths && eps_out && workspace, "dn_eps_forward: null argument");
+  DN_CHECK_ARG(B > 0 && T > 0, "dn_eps_forward: B=%d T=%d", B, T);
+  DN_CHECK_ARG(T <= m->cfg.max_pos, "dn_eps_forward: T=%d exceeds the positional table (%d)", T, m->cfg.max_pos);
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const DnEpsConfig& c = m->cfg;
+  const int dtype = c.dtype, es = esize(dtype), M = B * T, Bt = shared_t ? 1 : B;
+  const int D = c.dim, Dp = padk(D), Dn = padn(D), z = c.latent, zp = padk(z), C = D * c.cond_mult;
+  Arena ar{(char*)workspace, 0, workspace_bytes};
+  EpsBufs b = plan_eps(m, B, T, Bt, ar);
+  if (ar.off > workspace_bytes) {
+    dn_set_error("dn_eps_forward: workspace %zu < required %zu", workspace_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  // a1: timestep embedding -> [Bt, C]
+  DN_TRY(dn_time_cond(t, Bt, m->w_freq, D / 2, m->tc_W, m->tc_b, C, b.cond, b.cond_act, dtype, C, s));
+  {  // all 56 FiLM / adaptive-norm projections in one contraction (:507,517 and :624,637)
+    DnGemmParams p = gemm_base(dtype, Bt, m->n_cond, C, 1);
+    p.terms[0].A = b.cond_act; p.terms[0].lda = C; p.terms[0].W = m->cond_W;
+    p.bias = m->cond_b; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  const int gb_ld = shared_t ? 0 : m->n_cond;
+  DN_TRY(dn_convert_rows(x, DN_F32, z, b.xin, dtype, zp, M, z, s));
+  {  // init_conv 1x1: latent -> dim (:734,864)
+    DnGemmParams p = gemm_base(dtype, M, Dp, zp, T);
+    p.terms[0].A = b.xin; p.terms[0].lda = zp; p.terms[0].W = m->init_W;
+    p.bias = m->init_b; p.out = b.h0; p.ldo = Dp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  {  // WaveNet; its final 1x1 conv also adds the positional embedding and opens the fp32 residual stream
+    DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
+    fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
+    fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, b.gb, gb_ld, b.wv, fin, s));
+  }
+  const float* gb_tf = b.gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, s));
+  // final_proj: dim -> latent (:807,875), dense fp32 out
+  DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
+  p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
+  p.bias = m->final_b; p.out = eps_out; p.ldo = z; p.out_dtype = DN_F32;
+  (void)Dn; (void)es;
+  return dn_conv_gemm(&p, s);
+}
+
+extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, const float* coef,
+                            int32_t timesteps, int32_t use_graph, void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && x && lengths && coef && workspace, "dn_ddim_loop: null argument");
+  DN_CHECK_ARG(start_step >= 1 && start_step <= timesteps - 1, "dn_ddim_loop: start_step=%d must be in [1, %d]", start_step, timesteps - 1);
+  hipStream_t s = (hipStream_t)stream;
+  const int z = m->cfg.latent, M = B * T;
+  const size_t core = eps_ws_core(m, B, T);
+  const size_t need = core + (size_t)M * z * 4 + (size_t)B * 4 + 1024;
+  if (need > workspace_bytes) {
+    dn_set_error("dn_ddim_loop: workspace %zu < required %zu", workspace_bytes, need);
+    return DN_EWORKSPACE;
+  }
+  char* base = (char*)workspace;
+  float* eps = (float*)(base + core);
+  int32_t* tvec = (int32_t*)(base + core + (((size_t)M * z * 4 + 255) & ~size_t(255)));
+  int32_t* counter = tvec + ((B + 63) / 64) * 64;
+  const int last = start_step == 1 ? 0 : 1;  // the loop breaks after the t == 1 update (:1444-1445)
+  const int n_eval = start_step - last;       // t = start_step-1 ... last
+  auto one_step = [&]() -> int {
+    hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
+    DN_TRY(dn_eps_forward(m, x, tvec, lengths, B, T, 1, eps, workspace, core, s));
+    DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, M, z, z, T, coef, tvec, s));
+    hipLaunchKernelGGL(dec_counter_kernel, dim3(1), dim3(1), 0, s, counter);
+    DN_CHECK_LAUNCH("dn_ddim_loop step");
+    return DN_OK;
+  };
+  hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, s, counter, start_step - 1);
+  int done = 0;
+  if (!s) use_graph = 0;  // the null stream cannot be captured
+  if (use_graph && n_eval > 2) {
+    const bool cached = m->graph_exec && m->graph_B == B && m->graph_T == T && m->graph_ws == workspace && m->graph_x == x &&
+                        m->graph_len == lengths && m->graph_coef == coef;
+    if (!cached) {
+      DN_TRY(one_step());  // eager first step: also settles the per-kernel attributes outside capture
+      done = 1;
+      if (m->graph_exec) {
+        (void)hipGraphExecDestroy((hipGraphExec_t)m->graph_exec);
+        m->graph_exec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        dn_set_error("dn_ddim_loop: hipStreamBeginCapture failed");
+        return DN_ELAUNCH;
+      }
+      int rc = one_step();
+      hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc != DN_OK) return rc;
+      if (e != hipSuccess || !graph) {
+        dn_set_error("dn_ddim_loop: hipStreamEndCapture: %s", hipGetErrorString(e));
+        return DN_ELAUNCH;
+      }
+      hipGraphExec_t exec = nullptr;
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) {
+        dn_set_error("dn_ddim_loop: hipGraphInstantiate: %s", hipGetErrorString(e));
+        return DN_ELAUNCH;
+      }
+      m->graph_exec = exec; m->graph_B = B; m->graph_T = T; m->graph_ws = workspace; m->graph_x = x;
+      m->graph_len = lengths; m->graph_coef = coef;
+    }
+    for (; done < n_eval; ++done) {
+      hipError_t e = hipGraphLaunch((hipGraphExec_t)m->graph_exec, s);
+      if (e != hipSuccess) {
+        dn_set_error("dn_ddim_loop: hipGraphLaunch: %s", hipGetErrorString(e));
+        return DN_ELAUNCH;
+      }
+    }
+  } else {
+    for (; done < n_eval; ++done) DN_TRY(one_step());
+  }
+  return n_eval;
+}
+
+// =========================================================================================== VAE
+extern "C" int dn_vae_create(const DnVaeConfig* cfg, const void* const* weights, int32_t n_weights, DnVae** out) {
+  DN_CHECK_ARG(cfg && weights && out, "dn_vae_create: null argument");
+  DN_CHECK_ARG(cfg->n_mults >= 1 && cfg->n_mults <= 4, "dn_vae_create: n_mults=%d", cfg->n_mults);
+  const int expect = 2 * cfg->n_mults * kWavenetTensors + kTransformerTensors + 2;
+  DN_CHECK_ARG(n_weights == expect, "dn_vae_create: expected %d packed tensors, got %d", expect, n_weights);
+  DN_TRY(check_dims("dn_vae_create", cfg->dtype, cfg->dim, cfg->heads, cfg->dim_head, cfg->layers));
+  DN_CHECK_ARG(cfg->vocab % 4 == 0 && cfg->z % 4 == 0, "dn_vae_create: vocab and z must be multiples of 4");
+  for (int i = 0; i < n_weights; ++i) DN_CHECK_ARG(weights[i] != nullptr, "dn_vae_create: packed tensor %d is null", i);
+  DnVae* m = new (std::nothrow) DnVae();
+  DN_CHECK_ARG(m != nullptr, "dn_vae_create: out of host memory");
+  memset(m, 0, sizeof(*m));
+  m->cfg = *cfg;
+  m->n_wave = cfg->n_mults;
+  const void* const* t = weights;
+  int cur = cfg->dim;
+  for (int n = 0; n < m->n_wave; ++n) {  // latent_module.py:1053-1065
+    WavenetW& w = m->enc[n];
+    w.cin = cur; w.cout = cur / cfg->mults[n]; w.stacks = cfg->stacks; w.layers = cfg->layers;
+    cur = w.cout;
+    t = take_wavenet(w, t);
+  }
+  DN_CHECK_ARG(cur == 2 * cfg->z, "dn_vae_create: encoder width %d != 2*z (%d)", cur, 2 * cfg->z);
+  for (int n = 0; n < m->n_wave; ++n) {  // :1067-1081 (first decoder input halved by the posterior sample)
+    WavenetW& w = m->dec[n];
+    const int mult = cfg->mults[m->n_wave - 1 - n];
+    w.cout = cur * mult; w.cin = n == 0 ? cur / 2 : cur; w.stacks = cfg->stacks; w.layers = cfg->layers;
+    cur = w.cout;
+    t = take_wavenet(w, t);
+  }
+  DN_CHECK_ARG(cur == cfg->dim, "dn_vae_create: decoder width %d != dim %d", cur, cfg->dim);
+  m->tf.dim = cfg->dim; m->tf.depth = cfg->depth; m->tf.heads = cfg->heads; m->tf.dim_head = cfg->dim_head;
+  m->tf.inner = (int)((double)cfg->dim * 4 * 2 / 3);
+  t = take_transformer(m->tf, t);
+  m->lm_W = t[0]; m->lm_b = (const float*)t[1];
+  *out = m;
+  return DN_OK;
+}
+
+extern "C" void dn_vae_destroy(DnVae* m) { delete m; }
+
+namespace {
+struct VaeBufs {
+  void *in_act, *mid[2];
+  WaveBufs wv[4];
+  float *xres, *recon, *logits;
+  void* pred_act;
+  TfBufs tf;
+};
+
+VaeBufs plan_vae_enc(const DnVae* m, int M, Arena& ar) {
+  const int es = esize(m->cfg.dtype);
+  VaeBufs b;
+  memset(&b, 0, sizeof(b));
+  b.in_act = ar.take((size_t)M * padk(m->cfg.dim) * es);
+  int widest = 0;
+  for (int n = 0; n < m->n_wave; ++n) widest = widest > m->enc[n].cout ? widest : m->enc[n].cout;
+  b.mid[0] = ar.take((size_t)M * padk(widest) * es);
+  b.mid[1] = ar.take((size_t)M * padk(widest) * es);
+  for (int n = 0; n < m->n_wave; ++n) b.wv[n] = plan_wave(m->enc[n], M, es, ar);
+  return b;
+}
+
+VaeBufs plan_vae_dec(const DnVae* m, int M, bool need_recon, bool need_logits, Arena& ar) {
+  const int es = esize(m->cfg.dtype), Dp = padk(m->cfg.dim);
+  VaeBufs b;
+  memset(&b, 0, sizeof(b));
+  b.in_act = ar.take((size_t)M * padk(m->cfg.z) * es);
+  b.mid[0] = ar.take((size_t)M * Dp * es);
+  b.mid[1] = ar.take((size_t)M * Dp * es);
+  for (int n = 0; n < m->n_wave; ++n) b.wv[n] = plan_wave(m->dec[n], M, es, ar);
+  b.xres = (float*)ar.take((size_t)M * Dp * 4);
+  b.tf = plan_tf(m->tf, M, es, ar);
+  b.recon = need_recon ? (float*)ar.take((size_t)M * Dp * 4) : nullptr;
+  b.pred_act = ar.take((size_t)M * Dp * es);
+  b.logits = need_logits ? (float*)ar.take((size_t)M * m->cfg.vocab * 4) : nullptr;
+  return b;
+}
+}  // namespace
+
+extern "C" size_t dn_vae_workspace_bytes(const DnVae* m, int32_t B, int32_t T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  Arena a{nullptr, 0, 0}, d{nullptr, 0, 0};
+  (void)plan_vae_enc(m, B * T, a);
+  (void)plan_vae_dec(m, B * T, true, true, d);
+  return (a.off > d.off ? a.off : d.off) + 256;
+}
+
+extern "C" int dn_vae_encode_params(DnVae* m, const float* feat, int32_t B, int32_t T, float* params, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && feat && params && workspace && B > 0 && T > 0, "dn_vae_encode_params: bad argument");
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_vae_encode_params: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int dtype = m->cfg.dtype, M = B * T;
+  Arena ar{(char*)workspace, 0, workspace_bytes};
+  VaeBufs b = plan_vae_enc(m, M, ar);
+  if (ar.off > workspace_bytes) {
+    dn_set_error("dn_vae_encode_params: workspace %zu < required %zu", workspace_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  DN_TRY(dn_convert_rows(feat, DN_F32, m->cfg.dim, b.in_act, dtype, padk(m->cfg.dim), M, m->cfg.dim, s));
+  const void* cur = b.in_act;
+  for (int n = 0; n < m->n_wave; ++n) {
+    const WavenetW& w = m->enc[n];
+    const bool lastw = n == m->n_wave - 1;
+    DnGemmParams fin = gemm_base(dtype, M, lastw ? w.cout : padk(w.cout), padk(w.cout), T);
+    if (lastw) {  // posterior parameters [mean ; logvar], dense fp32
+      fin.out = params; fin.ldo = w.cout; fin.out_dtype = DN_F32;
+    } else {
+      fin.out = b.mid[n & 1]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
+    }
+    DN_TRY(run_wavenet(w, dtype, cur, M, T, nullptr, 0, b.wv[n], fin, s));
+    cur = b.mid[n & 1];
+  }
+  return DN_OK;
+}
+
+extern "C" int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengths, int32_t B, int32_t T, float* recon, float* logits,
+                             int32_t* units, void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && latent && lengths && workspace && B > 0 && T > 0, "dn_vae_decode: bad argument");
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_vae_decode: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int dtype = m->cfg.dtype, M = B * T, D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, V = m->cfg.vocab;
+  const bool want_lm = logits != nullptr || units != nullptr;
+  const bool dense_recon = recon != nullptr && Dp == D;  // to_pred can write the caller's buffer directly
+  Arena ar{(char*)workspace, 0, workspace_bytes};
+  VaeBufs b = plan_vae_dec(m, M, !dense_recon, want_lm && !logits, ar);
+  if (ar.off > workspace_bytes) {
+    dn_set_error("dn_vae_decode: workspace %zu < required %zu", workspace_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  DN_TRY(dn_convert_rows(latent, DN_F32, z, b.in_act, dtype, padk(z), M, z, s));
+  const void* cur = b.in_act;
+  for (int n = 0; n < m->n_wave; ++n) {
+    const WavenetW& w = m->dec[n];
+    const bool lastw = n == m->n_wave - 1;
+    DnGemmParams fin = gemm_base(dtype, M, padk(w.cout), padk(w.cout), T);
+    if (lastw) {  // opens the transformer's fp32 residual stream (no positional embedding, :1109-1114)
+      fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    } else {
+      fin.out = b.mid[n & 1]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
+    }
+    DN_TRY(run_wavenet(w, dtype, cur, M, T, nullptr, 0, b.wv[n], fin, s));
+    cur = b.mid[n & 1];
+  }
+  float* rec = dense_recon ? recon : b.recon;
+  const int rec_ld = dense_recon ? D : Dp;
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, b.tf, rec, rec_ld, DN_F32, s));
+  if (recon && !dense_recon) DN_TRY(dn_convert_rows(rec, DN_F32, Dp, recon, DN_F32, D, M, D, s));
+  if (!want_lm) return DN_OK;
+  DN_TRY(dn_convert_rows(rec, DN_F32, rec_ld, b.pred_act, dtype, Dp, M, D, s));
+  float* lg = logits ? logits : b.logits;
+  DnGemmParams p = gemm_base(dtype, M, V, Dp, T);  // decoder_lm (:1096,1115)
+  p.terms[0].A = b.pred_act; p.terms[0].lda = Dp; p.terms[0].W = m->lm_W;
+  p.bias = m->lm_b; p.out = lg; p.ldo = V; p.out_dtype = DN_F32;
+  DN_TRY(dn_conv_gemm(&p, s));
+  if (units) DN_TRY(dn_argmax_units(lg, V, M, V, 4, units, s));
+  return DN_OK;
+}

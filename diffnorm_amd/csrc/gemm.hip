@@ -1,0 +1,244 @@
+// dn_conv_gemm: causal-conv / linear contraction on MFMA with fused epilogues (gfx950).
+//
+//   out[g][m, n] = epi( sum_{term} sum_k A_term[g][m - shift_term, k] * W_term[g][n, k] )
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a 128(m) x 128(n) output tile; the K loop walks
+// (term, 128-byte K-tile) pairs.  Both operand tiles are staged HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction) into two 32 KiB stages; the LDS image is
+// linear in lane order and the bank-conflict swizzle (16-byte chunk ^= row & 7) is applied on the
+// per-lane SOURCE address and again on the ds_read_b128 address.  Frames before the start of a
+// sequence (t < shift) are sourced from a 128-byte zero page, so activations stay dense [M, ld]
+// with no per-sequence padding.  Weights are the MFMA A operand and activations the B operand, so
+// each lane ends up with 4 consecutive output columns of one row: bias/FiLM vectors load as
+// float4 and stores are 8/16 bytes per lane.
+#include "common.h"
+
+namespace dn {
+
+__device__ uint4 g_zero_page[8];  // 128 bytes of zeros (static storage is zero-initialised)
+
+constexpr int BM = 128, BN = 128, ROWB = 128;       // tile rows; bytes of K per row per K-tile
+constexpr int TILE_BYTES = BM * ROWB;               // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // W tile then A tile
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;           // 64 KiB -> 2 workgroups per CU
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename E, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int KT = ROWB / ES;  // K elements per K-tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.y;
+
+  // XCD-aware tile order: blocks sharing blockIdx % 8 share an L2, give each XCD a contiguous run of
+  // logical tiles with n fastest so the tiles that re-read one A row-panel sit behind one L2.
+  const int n_tiles_n = (p.N * (EPI == DN_EPI_GEGLU ? 2 : 1) + BN - 1) / BN;
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (logical / n_tiles_n) * BM;
+  const int n0 = (logical % n_tiles_n) * BN;  // packed weight row of the tile
+
+  // ---- staging geometry: wave w stages rows [32w, 32w+32) of each tile, 8 rows per instruction ----
+  const int srow = lane >> 3;                 // row within the 8-row piece
+  const int schunk = (lane & 7) ^ srow;       // swizzled 16-byte chunk this lane fetches
+  int64_t a_off[4];                           // element offset of row m (clamped) in A
+  int a_t[4];                                 // frame index of that row within its sequence
+  int64_t w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + wave * 32 + i * 8 + srow;
+    m = m < p.M ? m : p.M - 1;
+    a_off[i] = (int64_t)m;
+    a_t[i] = m % p.T;
+    w_off[i] = (int64_t)(n0 + wave * 32 + i * 8 + srow) * p.K;
+  }
+  const int ktiles_per_term = p.K / KT;
+  const int nkt = p.n_terms * ktiles_per_term;
+  const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+
+  auto stage = [&](int kt, int buf) {
+    const int term = kt / ktiles_per_term;
+    const int kk = kt - term * ktiles_per_term;
+    const DnGemmTerm& tm = p.terms[term];
+    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES;
+    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES;
+    const int kbyte = kk * ROWB + schunk * 16;
+    char* wbase = smem + buf * STAGE_BYTES + wave * 4096;
+    char* abase = wbase + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(W + w_off[i] * ES + kbyte, wbase + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = A + ((a_off[i] - shift) * tm.lda) * ES + kbyte;
+      src = a_t[i] >= shift ? src : zero_src;
+      glds16(src, abase + i * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses: row (l & 15) of a 16-row sub-tile, chunk ks*4 + (l >> 4), swizzled by row & 7
+  const int frow = lane & 15, fq = lane >> 4;
+  const int w_rd = (wn * 64 + frow) * ROWB;
+  const int a_rd = TILE_BYTES + (wm * 64 + frow) * ROWB;
+  const int sw = frow & 7;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // (vmcnt(0) + barrier): tile kt landed for everyone, tile kt-1 fully consumed
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + fq) ^ sw) << 4;
+      uint4 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB + coff);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[nt], af[mt]);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
+  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (p.out_dtype == DN_BF16 ? 2 : 4);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + frow;
+    if (m >= p.M) continue;
+    const int b = m / p.T;
+    const int t = m - b * p.T;
+    (void)t;
+    if constexpr (EPI == DN_EPI_GEGLU) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int np = n0 + wn * 64 + nt * 16 + fq * 4;       // packed row of the value
+        const int n = (n0 >> 1) + wn * 32 + nt * 16 + fq * 4;  // output column
+        if (n >= p.N) continue;
+        float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
+        float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
+        const f32x4 v = acc[nt][mt], gt = acc[nt + 2][mt];
+        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, gelu_erf(gt[0] + bg.x) * (v[0] + bv.x),
+               gelu_erf(gt[1] + bg.y) * (v[1] + bv.y), gelu_erf(gt[2] + bg.z) * (v[2] + bv.z),
+               gelu_erf(gt[3] + bg.w) * (v[3] + bv.w));
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+        float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
+              v3 = acc[nt][mt][3] + bv.w;
+        if constexpr (EPI == DN_EPI_SILU) {
+          v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+        } else if constexpr (EPI == DN_EPI_FILM_GATE) {
+          if (p.gamma_beta) {
+            const float* gb = p.gamma_beta + p.gb_gstride * g + (int64_t)b * p.gb_ld + n;
+            const float4 ga = *reinterpret_cast<const float4*>(gb);
+            const float4 be = *reinterpret_cast<const float4*>(gb + p.gb_half);
+            v0 = v0 * ga.x + be.x; v1 = v1 * ga.y + be.y; v2 = v2 * ga.z + be.z; v3 = v3 * ga.w + be.w;
+          }
+          const char* res = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (p.res_dtype == DN_BF16 ? 2 : 4);
+          const float4 rv = load4(res, (int64_t)m * p.ldr + n, p.res_dtype);
+          v0 = tanh_sigmoid_gate(v0) + rv.x; v1 = tanh_sigmoid_gate(v1) + rv.y;
+          v2 = tanh_sigmoid_gate(v2) + rv.z; v3 = tanh_sigmoid_gate(v3) + rv.w;
+        } else if constexpr (EPI == DN_EPI_RESADD) {
+          const float* res = reinterpret_cast<const float*>(p.res) + p.res_gstride * g;
+          const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
+          v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+        } else if constexpr (EPI == DN_EPI_POSEMB) {
+          const int pos = t < p.lengths[b] ? t + 1 : 0;
+          const float4 pe = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
+          v0 += pe.x; v1 += pe.y; v2 += pe.z; v3 += pe.w;
+        }
+        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+template <typename E, int EPI>
+static int launch(const DnGemmParams& p, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<E, EPI>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    attr_done = true;
+  }
+  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  dim3 grid(((p.M + BM - 1) / BM) * ((np + BN - 1) / BN), p.groups);
+  hipLaunchKernelGGL((conv_gemm_kernel<E, EPI>), grid, dim3(256), GEMM_LDS, s, p);
+  DN_CHECK_LAUNCH("dn_conv_gemm");
+  return DN_OK;
+}
+
+template <typename E>
+static int dispatch_epi(const DnGemmParams& p, hipStream_t s) {
+  switch (p.epilogue) {
+    case DN_EPI_BIAS: return launch<E, DN_EPI_BIAS>(p, s);
+    case DN_EPI_SILU: return launch<E, DN_EPI_SILU>(p, s);
+    case DN_EPI_GEGLU: return launch<E, DN_EPI_GEGLU>(p, s);
+    case DN_EPI_FILM_GATE: return launch<E, DN_EPI_FILM_GATE>(p, s);
+    case DN_EPI_RESADD: return launch<E, DN_EPI_RESADD>(p, s);
+    case DN_EPI_POSEMB: return launch<E, DN_EPI_POSEMB>(p, s);
+  }
+  dn_set_error("dn_conv_gemm: unknown epilogue %d", p.epilogue);
+  return DN_EINVAL;
+}
+
+}  // namespace dn
+
+extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
+  DN_CHECK_ARG(pp != nullptr, "dn_conv_gemm: null params");
+  const DnGemmParams& p = *pp;
+  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_conv_gemm: bad dtype %d", p.dtype);
+  const int kt = p.dtype == DN_BF16 ? 64 : 32;
+  DN_CHECK_ARG(p.n_terms >= 1 && p.n_terms <= DN_MAX_TERMS, "dn_conv_gemm: n_terms %d", p.n_terms);
+  DN_CHECK_ARG(p.M > 0 && p.N > 0 && p.T > 0 && p.groups >= 1, "dn_conv_gemm: M=%d N=%d T=%d groups=%d", p.M, p.N, p.T, p.groups);
+  DN_CHECK_ARG(p.M % p.T == 0, "dn_conv_gemm: M=%d is not a multiple of T=%d", p.M, p.T);
+  DN_CHECK_ARG(p.K > 0 && p.K % kt == 0, "dn_conv_gemm: K=%d must be a multiple of %d", p.K, kt);
+  DN_CHECK_ARG(p.N % 4 == 0 && p.ldo % 4 == 0 && p.ldo >= p.N, "dn_conv_gemm: N=%d ldo=%d must be multiples of 4, ldo>=N", p.N, p.ldo);
+  DN_CHECK_ARG(p.out != nullptr, "dn_conv_gemm: null out");
+  for (int i = 0; i < p.n_terms; ++i) {
+    DN_CHECK_ARG(p.terms[i].A && p.terms[i].W, "dn_conv_gemm: term %d null operand", i);
+    DN_CHECK_ARG(p.terms[i].lda >= p.K && p.terms[i].lda % (16 / (p.dtype == DN_BF16 ? 2 : 4)) == 0,
+                 "dn_conv_gemm: term %d lda=%d (K=%d)", i, p.terms[i].lda, p.K);
+    DN_CHECK_ARG(p.terms[i].shift >= 0, "dn_conv_gemm: term %d negative shift", i);
+    DN_CHECK_ARG((reinterpret_cast<uintptr_t>(p.terms[i].A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.terms[i].W) & 15) == 0,
+                 "dn_conv_gemm: term %d operands must be 16-byte aligned", i);
+  }
+  if (p.epilogue == DN_EPI_FILM_GATE || p.epilogue == DN_EPI_RESADD)
+    DN_CHECK_ARG(p.res != nullptr && p.ldr % 4 == 0, "dn_conv_gemm: epilogue needs res (ldr multiple of 4)");
+  if (p.epilogue == DN_EPI_RESADD) DN_CHECK_ARG(p.out_dtype == DN_F32, "dn_conv_gemm: RESADD writes fp32");
+  if (p.epilogue == DN_EPI_POSEMB) DN_CHECK_ARG(p.pos_table && p.lengths && p.pos_ld % 4 == 0, "dn_conv_gemm: POSEMB needs pos_table and lengths");
+  if (p.epilogue == DN_EPI_FILM_GATE && p.gamma_beta) DN_CHECK_ARG(p.gb_half % 4 == 0 && p.gb_ld % 4 == 0, "dn_conv_gemm: gamma_beta strides must be multiples of 4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return p.dtype == DN_BF16 ? dn::dispatch_epi<dn::BF16>(p, s) : dn::dispatch_epi<dn::F32>(p, s);
+}

@@ -1,0 +1,342 @@
+// HBM-bound kernels of the path: norms, timestep conditioning, scheduler updates, posterior sampling,
+// argmax, Philox normal fill, row conversion.  All are one pass over their operands with 16-byte
+// accesses where the layout allows; reductions are wave-level (64 lanes) with DPP-free shuffles.
+#include "common.h"
+
+namespace dn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ RMSNorm
+// one wave per row; D <= 1024 keeps the row in registers (4 float4 per lane), larger D re-reads.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, void* __restrict__ y, int ldy,
+                                                      int out_dtype, int M, int D, int T, const float* __restrict__ gamma,
+                                                      const float* __restrict__ gb, int gb_ld, int gb_half) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float4 v[4];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+    ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+  }
+  for (int c = (256 + lane) * 4; c < D; c += 256) {
+    const float4 u = *reinterpret_cast<const float4*>(xr + c);
+    ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+  const float scale = sqrtf((float)D);
+  const float* gbr = gb ? gb + (int64_t)(row / T) * gb_ld : nullptr;
+  auto emit = [&](int c, float4 u) {
+    float o[4] = {u.x / denom * scale, u.y / denom * scale, u.z / denom * scale, u.w / denom * scale};
+    if (gamma) {
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+      o[0] *= ga.x; o[1] *= ga.y; o[2] *= ga.z; o[3] *= ga.w;
+    }
+    if (gbr) {
+      const float4 ga = *reinterpret_cast<const float4*>(gbr + c);
+      const float4 be = *reinterpret_cast<const float4*>(gbr + gb_half + c);
+      o[0] = o[0] * ga.x + be.x; o[1] = o[1] * ga.y + be.y; o[2] = o[2] * ga.z + be.z; o[3] = o[3] * ga.w + be.w;
+    }
+    store4(y, (int64_t)row * ldy + c, out_dtype, o[0], o[1], o[2], o[3]);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) emit(c, v[i]);
+  }
+  for (int c = (256 + lane) * 4; c < D; c += 256) emit(c, *reinterpret_cast<const float4*>(xr + c));
+  // zero the pad columns [D, ldy) so the row can feed a K-padded contraction
+  for (int c = D + lane * 4; c < ldy; c += 256) store4(y, (int64_t)row * ldy + c, out_dtype, 0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------ time cond
+// block = (16 outputs, one sample): the 2*half+1 Fourier features go to LDS once, then each wave does
+// 4 dot products of length 2*half+1.  The angle is formed exactly as the reference forms it in fp32:
+// fl(fl(fl(t*w)*2)*pi_f32) -- t up to 999 and w ~ N(0,1) give arguments of 1e3..1e4 rad, so sinf/cosf
+// (full range reduction) are used, never the fast intrinsics.
+__global__ __launch_bounds__(256) void time_cond_kernel(const int32_t* __restrict__ times, const float* __restrict__ wf, int half,
+                                                        const float* __restrict__ W, const float* __restrict__ bias, int C,
+                                                        float* __restrict__ out, void* __restrict__ out_act, int act_dtype, int ldo) {
+  extern __shared__ float feat[];
+  const int b = blockIdx.y;
+  const int nfeat = 2 * half + 1;
+  const float tf = (float)times[b];
+  for (int k = threadIdx.x; k < nfeat; k += 256) {
+    float f;
+    if (k == 0) {
+      f = tf;
+    } else {
+      const int j = k <= half ? k - 1 : k - 1 - half;
+      float ang = __fmul_rn(__fmul_rn(__fmul_rn(tf, wf[j]), 2.0f), 3.14159265358979323846f);
+      f = k <= half ? sinf(ang) : cosf(ang);
+    }
+    feat[k] = f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = blockIdx.x * 16 + wave * 4 + i;
+    if (c >= C) break;
+    const float* wr = W + (int64_t)c * nfeat;
+    float s = 0.f;
+    for (int k = lane; k < nfeat; k += 64) s += feat[k] * wr[k];
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float v = silu(s + bias[c]);
+      out[(int64_t)b * ldo + c] = v;
+      if (out_act) {
+        if (act_dtype == DN_BF16)
+          reinterpret_cast<uint16_t*>(out_act)[(int64_t)b * ldo + c] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+        else
+          reinterpret_cast<float*>(out_act)[(int64_t)b * ldo + c] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ scheduler
+__device__ __forceinline__ void store_act1(void* p, int64_t off, int dtype, float v) {
+  if (dtype == DN_BF16)
+    reinterpret_cast<uint16_t*>(p)[off] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+  else
+    reinterpret_cast<float*>(p)[off] = v;
+}
+
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* x, const float* __restrict__ eps, float* xo,
+                                                        void* __restrict__ xact, int act_dtype, int ld_act, int M, int C, int ld,
+                                                        int T, const float* __restrict__ coef, const int32_t* __restrict__ t) {
+  const int64_t n = (int64_t)M * C;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
+    const float* cf = coef + 4 * t[m / T];
+    const float sa = cf[0], s1 = cf[1];
+    const int64_t o = (int64_t)m * ld + c;
+    const float xv = x[o], ev = eps[o];
+    // x1_hat = safe_div(x - s1*eps, sa); pred_noise = safe_div(x - sa*x1_hat, s1); mean = x1_hat*sqrt(abp) + sqrt(1-abp)*pn
+    const float x1 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(s1, ev)), fmaxf(sa, 1e-10f));
+    const float pn = __fdiv_rn(__fsub_rn(xv, __fmul_rn(sa, x1)), fmaxf(s1, 1e-10f));
+    const float r = __fadd_rn(__fmul_rn(x1, cf[2]), __fmul_rn(cf[3], pn));
+    xo[o] = r;
+    if (xact) store_act1(xact, (int64_t)m * ld_act + c, act_dtype, r);
+  }
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                                       void* __restrict__ oact, int act_dtype, int ld_act, int M, int C, int ld, int T,
+                                                       const float* __restrict__ ca, const float* __restrict__ cb,
+                                                       const int32_t* __restrict__ t) {
+  const int64_t n = (int64_t)M * C;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
+    const int tb = t[m / T];
+    const int64_t o = (int64_t)m * ld + c;
+    const float r = __fadd_rn(__fmul_rn(ca[tb], x[o]), __fmul_rn(cb[tb], noise[o]));
+    out[o] = r;
+    if (oact) store_act1(oact, (int64_t)m * ld_act + c, act_dtype, r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ posterior
+__global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ params, int ldp, const float* __restrict__ noise, int ldn,
+                                                        float* __restrict__ z, void* __restrict__ zact, int act_dtype, int ldz, int M,
+                                                        int Z, int T, const int32_t* __restrict__ lengths, float* __restrict__ kl_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* pr = params + (int64_t)row * ldp;
+  float kl = 0.f;
+  for (int c = lane; c < Z; c += 64) {
+    const float mean = pr[c];
+    const float lv = fminf(fmaxf(pr[Z + c], -30.0f), 20.0f);
+    const float sd = expf(0.5f * lv);
+    const float v = __fadd_rn(mean, __fmul_rn(sd, noise[(int64_t)row * ldn + c]));
+    z[(int64_t)row * ldz + c] = v;
+    if (zact) store_act1(zact, (int64_t)row * ldz + c, act_dtype, v);
+    kl += mean * mean + expf(lv) - 1.0f - lv;
+  }
+  for (int c = Z + lane; c < ldz; c += 64) {
+    z[(int64_t)row * ldz + c] = 0.f;
+    if (zact) store_act1(zact, (int64_t)row * ldz + c, act_dtype, 0.f);
+  }
+  if (kl_rows) {
+    kl = wave_sum(kl);
+    const int b = row / T, t = row - b * T;
+    const bool valid = lengths ? t < lengths[b] : true;
+    if (lane == 0) kl_rows[row] = valid ? 0.5f * kl : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ argmax
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int M, int V, int offset,
+                                                     int32_t* __restrict__ units) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* lr = logits + (int64_t)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    const float v = lr[c];
+    if (v > best || (v == best && c < bi)) {  // first maximum wins, like torch.argmax
+      best = v;
+      bi = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) units[row] = bi - offset;
+}
+
+// ------------------------------------------------------------------------------------------ Philox randn
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1;
+  c[3] = (uint32_t)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t nquad = (n + 3) >> 2;
+  for (int64_t q = blockIdx.x * 256 + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * 256) {
+    const uint64_t ctr = offset + (uint64_t)q;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float r[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+      const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.28318530717958647692f * u2, &sn, &cs);
+      r[2 * h] = rad * cs;
+      r[2 * h + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) out[q * 4 + j] = r[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ convert rows
+__global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int sdt, int lds, void* __restrict__ dst, int ddt,
+                                                           int ldd, int M, int C) {
+  const int64_t n = (int64_t)M * ldd;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / ldd), c = (int)(i - (int64_t)m * ldd);
+    float v = 0.f;
+    if (c < C) {
+      const int64_t so = (int64_t)m * lds + c;
+      v = sdt == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[so]) : reinterpret_cast<const float*>(src)[so];
+    }
+    store_act1(dst, i, ddt, v);
+  }
+}
+
+static inline int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" int dn_rmsnorm(const float* x, int32_t ldx, void* y, int32_t ldy, int32_t out_dtype, int32_t M, int32_t D, int32_t T,
+                          const float* gamma, const float* gamma_beta, int32_t gb_ld, int32_t gb_half, void* stream) {
+  DN_CHECK_ARG(x && y && M > 0 && D > 0 && T > 0, "dn_rmsnorm: bad args");
+  DN_CHECK_ARG(D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= D && ldx >= D, "dn_rmsnorm: D=%d ldx=%d ldy=%d must be multiples of 4", D, ldx, ldy);
+  DN_CHECK_ARG(!gamma_beta || (gb_ld % 4 == 0 && gb_half % 4 == 0), "dn_rmsnorm: gamma_beta strides must be multiples of 4");
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, out_dtype, M, D, T, gamma,
+                     gamma_beta, gb_ld, gb_half);
+  DN_CHECK_LAUNCH("dn_rmsnorm");
+  return DN_OK;
+}
+
+extern "C" int dn_time_cond(const int32_t* times, int32_t B, const float* w_freq, int32_t half, const float* W, const float* bias,
+                            int32_t C, float* out, void* out_act, int32_t act_dtype, int32_t ldo, void* stream) {
+  DN_CHECK_ARG(times && w_freq && W && bias && out && B > 0 && half > 0 && C > 0 && ldo >= C, "dn_time_cond: bad args");
+  hipLaunchKernelGGL(time_cond_kernel, dim3((C + 15) / 16, B), dim3(256), (2 * half + 1) * sizeof(float), (hipStream_t)stream, times,
+                     w_freq, half, W, bias, C, out, out_act, act_dtype, ldo);
+  DN_CHECK_LAUNCH("dn_time_cond");
+  return DN_OK;
+}
+
+extern "C" int dn_ddim_step(const float* x, const float* eps, float* x_out, void* x_act, int32_t act_dtype, int32_t ld_act, int32_t M,
+                            int32_t C, int32_t ld, int32_t T, const float* coef, const int32_t* t, void* stream) {
+  DN_CHECK_ARG(x && eps && x_out && coef && t && M > 0 && C > 0 && ld >= C && T > 0, "dn_ddim_step: bad args");
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_grid((int64_t)M * C)), dim3(256), 0, (hipStream_t)stream, x, eps, x_out, x_act, act_dtype,
+                     ld_act, M, C, ld, T, coef, t);
+  DN_CHECK_LAUNCH("dn_ddim_step");
+  return DN_OK;
+}
+
+extern "C" int dn_q_sample(const float* x, const float* noise, float* out, void* out_act, int32_t act_dtype, int32_t ld_act, int32_t M,
+                           int32_t C, int32_t ld, int32_t T, const float* coef_a, const float* coef_b, const int32_t* t, void* stream) {
+  DN_CHECK_ARG(x && noise && out && coef_a && coef_b && t && M > 0 && C > 0 && ld >= C && T > 0, "dn_q_sample: bad args");
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid((int64_t)M * C)), dim3(256), 0, (hipStream_t)stream, x, noise, out, out_act, act_dtype,
+                     ld_act, M, C, ld, T, coef_a, coef_b, t);
+  DN_CHECK_LAUNCH("dn_q_sample");
+  return DN_OK;
+}
+
+extern "C" int dn_posterior_sample(const float* params, int32_t ldp, const float* noise, int32_t ldn, float* z, void* z_act,
+                                   int32_t act_dtype, int32_t ldz, int32_t M, int32_t Z, int32_t T, const int32_t* lengths,
+                                   float* kl_rows, void* stream) {
+  DN_CHECK_ARG(params && noise && z && M > 0 && Z > 0 && ldp >= 2 * Z && ldn >= Z && ldz >= Z && T > 0, "dn_posterior_sample: bad args");
+  hipLaunchKernelGGL(posterior_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, ldp, noise, ldn, z, z_act, act_dtype,
+                     ldz, M, Z, T, lengths, kl_rows);
+  DN_CHECK_LAUNCH("dn_posterior_sample");
+  return DN_OK;
+}
+
+extern "C" int dn_argmax_units(const float* logits, int32_t ld, int32_t M, int32_t V, int32_t offset, int32_t* units, void* stream) {
+  DN_CHECK_ARG(logits && units && M > 0 && V > 0 && ld >= V, "dn_argmax_units: bad args");
+  hipLaunchKernelGGL(argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, M, V, offset, units);
+  DN_CHECK_LAUNCH("dn_argmax_units");
+  return DN_OK;
+}
+
+extern "C" int dn_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  DN_CHECK_ARG(out && n > 0, "dn_randn: bad args");
+  hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+  DN_CHECK_LAUNCH("dn_randn");
+  return DN_OK;
+}
+
+extern "C" int dn_convert_rows(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype, int32_t ldd, int32_t M,
+                               int32_t C, void* stream) {
+  DN_CHECK_ARG(src && dst && M > 0 && C > 0 && lds >= C && ldd >= C, "dn_convert_rows: bad args");
+  hipLaunchKernelGGL(convert_rows_kernel, dim3(ew_grid((int64_t)M * ldd)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, lds, dst,
+                     dst_dtype, ldd, M, C);
+  DN_CHECK_LAUNCH("dn_convert_rows");
+  return DN_OK;
+}

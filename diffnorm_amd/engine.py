@@ -1,0 +1,190 @@
+"""Thin Python handles over the C-ABI engine objects (DnEps / DnVae) of libdiffnorm_hip.so.
+
+PyTorch is used only for device memory (packed weights, workspaces, I/O tensors) and the current
+stream; all arithmetic runs in the HIP library.  There is no CPU path: constructing an engine
+without a GPU or without the library raises.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, packing
+
+
+def _dtype_code(dtype) -> int:
+    if dtype in (_lib.DN_BF16, "bf16", torch.bfloat16):
+        return _lib.DN_BF16
+    if dtype in (_lib.DN_F32, "f32", "fp32", torch.float32):
+        return _lib.DN_F32
+    raise ValueError(f"unsupported arithmetic dtype {dtype!r} (use 'bf16' or 'f32')")
+
+
+def _require_cuda(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.DiffNormHipError("diffnorm_amd engines need a HIP device (cuda:N); there is no CPU fallback")
+    return device
+
+
+def _i32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _Engine:
+    def __init__(self, device, tensors: List[torch.Tensor]):
+        self.device = _require_cuda(device)
+        self.lib = _lib.load()
+        self.tensors = [t.to(self.device).contiguous() for t in tensors]  # keeps packed weights alive
+        self._table = (C.c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
+        self._ws: Optional[torch.Tensor] = None
+        self.handle = C.c_void_p()
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _aligned(ws: torch.Tensor):
+        p = ws.data_ptr()
+        a = (p + 255) & ~255
+        return a, ws.numel() - (a - p)
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.tensors)
+
+
+class EpsEngine(_Engine):
+    """eps-predictor `Model` (reference latent_module.py:709-876) on the GPU."""
+
+    def __init__(self, state_dict, cfg, dtype="bf16", device="cuda:0", max_pos: int = 2048):
+        self.cfg = cfg
+        self.dtype = _dtype_code(dtype)
+        super().__init__(device, packing.pack_eps(state_dict, cfg, self.dtype, max_pos))
+        c = _lib.EpsConfig(cfg.dim, cfg.latent_dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.wavenet_layers,
+                           cfg.wavenet_stacks, cfg.dim_cond_mult, self.dtype, max_pos)
+        _lib.check(self.lib.dn_eps_create(C.byref(c), self._table, len(self.tensors), C.byref(self.handle)),
+                   "dn_eps_create")
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.dn_eps_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def workspace_bytes(self, B: int, T: int) -> int:
+        return int(self.lib.dn_eps_workspace_bytes(self.handle, B, T))
+
+    def forward(self, x: torch.Tensor, times: torch.Tensor, lengths: torch.Tensor, shared_t: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,T,z] fp32, times [B] int, lengths [B] int -> eps_hat [B,T,z] fp32 (Model.forward :828-876)."""
+        B, T, z = x.shape
+        assert z == self.cfg.latent_dim
+        x = _f32(x, self.device)
+        t32, l32 = _i32(times, self.device), _i32(lengths, self.device)
+        out = torch.empty_like(x) if out is None else out
+        ws = self._workspace(self.workspace_bytes(B, T))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_eps_forward(self.handle, x.data_ptr(), t32.data_ptr(), l32.data_ptr(), B, T,
+                                               int(shared_t), out.data_ptr(), wp, wn, _lib.current_stream()),
+                       "dn_eps_forward")
+        return out
+
+    def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
+                  use_graph: bool = True) -> int:
+        """In-place DDIM eta=0 chain on x [B,T,z] fp32 (reference latent_module.py:1411-1445).
+        coef: fp32 [timesteps,4] from `scheduler.ddim_coef_table`.  Returns the number of model evaluations."""
+        B, T, z = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.device == self.device
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.device == self.device
+        l32 = lengths if (lengths.dtype == torch.int32 and lengths.device == self.device) else _i32(lengths, self.device)
+        self._keep = (l32, coef)
+        ws = self._workspace(self.workspace_bytes(B, T))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            return _lib.check(self.lib.dn_ddim_loop(self.handle, x.data_ptr(), l32.data_ptr(), B, T, start_step,
+                                                    coef.data_ptr(), coef.shape[0], int(use_graph), wp, wn,
+                                                    _lib.current_stream()), "dn_ddim_loop")
+
+
+class VaeEngine(_Engine):
+    """SpeechVAEEncoderDecoder (reference latent_module.py:1035-1142) on the GPU."""
+
+    def __init__(self, state_dict, dim: int = 768, latent_dim: int = 128, dtype="bf16", device="cuda:0",
+                 depth: int = 6, heads: int = 8, dim_head: int = 96, stacks: int = 2, layers: int = 3,
+                 vocab: int = 1004):
+        self.dim, self.vocab = dim, vocab
+        self.mults = packing.vae_mults(latent_dim)
+        z = dim
+        for m in self.mults:
+            z //= m
+        self.z = z // 2
+        self.dtype = _dtype_code(dtype)
+        super().__init__(device, packing.pack_vae(state_dict, dim, self.mults, depth, heads, dim_head, stacks, layers,
+                                                  vocab, self.dtype))
+        mults = (C.c_int32 * 4)(*(self.mults + [0] * (4 - len(self.mults))))
+        c = _lib.VaeConfig(dim, self.z, depth, heads, dim_head, stacks, layers, vocab, len(self.mults), mults, self.dtype)
+        _lib.check(self.lib.dn_vae_create(C.byref(c), self._table, len(self.tensors), C.byref(self.handle)),
+                   "dn_vae_create")
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.dn_vae_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def workspace_bytes(self, B: int, T: int) -> int:
+        return int(self.lib.dn_vae_workspace_bytes(self.handle, B, T))
+
+    def encode_params(self, feat: torch.Tensor) -> torch.Tensor:
+        """feat [B,T,dim] fp32 -> posterior parameters [B,T,2z] fp32 ([mean ; logvar])."""
+        B, T, _ = feat.shape
+        feat = _f32(feat, self.device)
+        out = torch.empty(B, T, 2 * self.z, dtype=torch.float32, device=self.device)
+        ws = self._workspace(self.workspace_bytes(B, T))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_vae_encode_params(self.handle, feat.data_ptr(), B, T, out.data_ptr(), wp, wn,
+                                                     _lib.current_stream()), "dn_vae_encode_params")
+        return out
+
+    def sample_posterior(self, params: torch.Tensor, noise: torch.Tensor, lengths: Optional[torch.Tensor] = None,
+                         want_kl: bool = False):
+        """DiagonalGaussianDistribution.sample / kl_3d (reference distributions.py:24-41, 62-74)."""
+        B, T, _ = params.shape
+        noise = _f32(noise, self.device)
+        z = torch.empty(B, T, self.z, dtype=torch.float32, device=self.device)
+        kl_rows = torch.empty(B, T, dtype=torch.float32, device=self.device) if want_kl else None
+        l32 = _i32(lengths, self.device) if lengths is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_posterior_sample(params.data_ptr(), 2 * self.z, noise.data_ptr(), self.z, z.data_ptr(),
+                                                    None, _lib.DN_F32, self.z, B * T, self.z, T, _lib.ptr(l32),
+                                                    _lib.ptr(kl_rows), _lib.current_stream()), "dn_posterior_sample")
+        if want_kl:
+            return z, kl_rows.sum(dim=1) / (T * self.z)  # mean over (z,T) with pads counted, per sample
+        return z
+
+    def encode(self, feat: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """encode_feature (reference latent_module.py:1099-1107) with caller-supplied posterior noise."""
+        return self.sample_posterior(self.encode_params(feat), noise)
+
+    def decode(self, latent: torch.Tensor, lengths: torch.Tensor, want_recon=True, want_logits=True, want_units=True):
+        """decode_feature (:1109-1116) -> (recon [B,T,dim], logits [B,T,vocab], units [B,T] = argmax-4)."""
+        B, T, _ = latent.shape
+        latent = _f32(latent, self.device)
+        l32 = _i32(lengths, self.device)
+        recon = torch.empty(B, T, self.dim, dtype=torch.float32, device=self.device) if want_recon else None
+        logits = torch.empty(B, T, self.vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        units = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_units else None
+        ws = self._workspace(self.workspace_bytes(B, T))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_vae_decode(self.handle, latent.data_ptr(), l32.data_ptr(), B, T, _lib.ptr(recon),
+                                              _lib.ptr(logits), _lib.ptr(units), wp, wn, _lib.current_stream()),
+                       "dn_vae_decode")
+        return recon, logits, units

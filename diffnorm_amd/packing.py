@@ -1,0 +1,202 @@
+"""State-dict -> packed device tensors for libdiffnorm_hip.so.
+
+Input: tensors in the reference's state-dict layout (conv weights [Cout,Cin,k], linear
+weights [out,in]).  Output: the ordered tensor tables `dn_eps_create` / `dn_vae_create` expect
+(diffnorm_amd/csrc/engine.h documents each entry).  Packing rules:
+
+* every weight becomes [rows padded to 128][K padded to 64] with K contiguous, in the arithmetic
+  dtype (bf16 or fp32); pads are zeros, so padded channels stay exactly zero through the network;
+* a k-tap causal conv becomes k matrices, tap j multiplying the frame t-(k-1-j)*dilation;
+* Linear(D, 2*inner) of the GEGLU is interleaved in blocks of 64 rows = [32 value rows ; 32 gate rows]
+  so one wave holds value and gate of the same column (epilogue DN_EPI_GEGLU);
+* the 2*S*L FiLM and 2*depth adaptive-RMSNorm projections are stacked into one [n_cond, C] matrix,
+  each as [gamma(Dp) ; beta(Dp)];
+* biases, norm gammas, the Fourier frequencies and the sinusoidal table stay fp32.
+"""
+import math
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+
+SD = Dict[str, torch.Tensor]
+
+
+def padk(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+def padn(c: int) -> int:
+    return (c + 127) // 128 * 128
+
+
+def _act_dtype(dtype: int):
+    return torch.bfloat16 if dtype == _lib.DN_BF16 else torch.float32
+
+
+def _mat(w: torch.Tensor, dtype: int, rows: int = None, cols: int = None) -> torch.Tensor:
+    """[N,K] -> zero-padded [rows or padn(N), cols or padk(K)] in the arithmetic dtype."""
+    n, k = w.shape
+    out = torch.zeros(rows or padn(n), cols or padk(k), dtype=torch.float32)
+    out[:n, :k] = w.float()
+    return out.to(_act_dtype(dtype))
+
+
+def _vec(b: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, dtype=torch.float32)
+    out[: b.numel()] = b.float().flatten()
+    return out
+
+
+def _conv(w: torch.Tensor, dtype: int) -> torch.Tensor:
+    """[Cout,Cin,k] -> [k, padn(Cout), padk(Cin)], tap j = w[:, :, j]."""
+    return torch.stack([_mat(w[:, :, j], dtype) for j in range(w.shape[2])])
+
+
+def sinusoidal_table(num: int, dim: int, ld: int) -> torch.Tensor:
+    """fairseq SinusoidalPositionalEmbedding table with padding_idx 0
+    (reference fairseq/modules/sinusoidal_positional_embedding.py:36-58): rows
+    [sin(p f_j) | cos(p f_j)], f_j = exp(-j ln(1e4)/(dim/2-1)), row 0 = 0; built in fp32 like upstream."""
+    half = dim // 2
+    f = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(num, dtype=torch.float).unsqueeze(1) * f.unsqueeze(0)
+    tab = torch.zeros(num, ld, dtype=torch.float32)
+    tab[:, :half] = torch.sin(ang)
+    tab[:, half:2 * half] = torch.cos(ang)
+    tab[0] = 0
+    return tab
+
+
+def pack_wavenet(sd: SD, prefix: str, cin: int, cout: int, stacks: int, layers: int, dtype: int) -> List[torch.Tensor]:
+    cp = padk(cout)
+    g = lambda k: sd[prefix + k]
+    conv_W, conv_b, res_W, res_b = [], [], [], []
+    for s in range(stacks):
+        for i in range(layers):
+            p = f"stacks.{s}.blocks.{i}."
+            conv_W.append(_conv(g(p + "conv.weight"), dtype))
+            conv_b.append(_vec(g(p + "conv.bias"), cp))
+            res_W.append(_mat(g(p + "res_conv.weight")[:, :, 0], dtype))
+            res_b.append(_vec(g(p + "res_conv.bias"), cp))
+    last = f"stacks.{stacks - 1}.blocks."
+    skip_W = torch.stack([_mat(g(f"{last}{i}.skip_conv.weight")[:, :, 0], dtype) for i in range(layers)])
+    skip_b = _vec(sum(g(f"{last}{i}.skip_conv.bias").float() for i in range(layers)), cp)
+    return [
+        _conv(g("init_conv.weight"), dtype), _vec(g("init_conv.bias"), cp),
+        torch.stack(conv_W), torch.stack(conv_b), torch.stack(res_W), torch.stack(res_b),
+        skip_W, skip_b,
+        _mat(g("final_conv.weight")[:, :, 0], dtype), _vec(g("final_conv.bias"), cp),
+    ]
+
+
+def _geglu_rows(inner: int) -> torch.Tensor:
+    """Source row in Linear(D,2*inner).weight for every packed row (or -1 for a zero row)."""
+    ip = padk(inner)
+    p = torch.arange(2 * ip)
+    col = (p // 64) * 32 + (p % 32)
+    is_gate = (p % 64) >= 32
+    src = torch.where(is_gate, col + inner, col)
+    return torch.where(col < inner, src, torch.full_like(src, -1))
+
+
+def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_head: int, dtype: int,
+                     conditioned: bool) -> List[torch.Tensor]:
+    inner = int(dim * 4 * 2 / 3)
+    ip, Dp, hd = padk(inner), padk(dim), heads * dim_head
+    rows = _geglu_rows(inner)
+    keep = rows >= 0
+    g = lambda k: sd[prefix + k]
+    qkv, out, ffin, ffin_b, ffc, ffc_b, ffo, ffo_b, g1, g2 = ([] for _ in range(10))
+    for l in range(depth):
+        p = f"layers.{l}."
+        qkv.append(_mat(torch.cat([g(p + "1.to_q.weight"), g(p + "1.to_kv.weight")], dim=0), dtype))
+        out.append(_mat(g(p + "1.to_out.weight"), dtype))
+        w, b = g(p + "5.0.weight").float(), g(p + "5.0.bias").float()
+        wp = torch.zeros(2 * ip, Dp)
+        bp = torch.zeros(2 * ip)
+        wp[keep, :dim] = w[rows[keep]]
+        bp[keep] = b[rows[keep]]
+        ffin.append(wp.to(_act_dtype(dtype)))
+        ffin_b.append(bp)
+        ffc.append(_conv(g(p + "5.2.1.weight"), dtype))
+        ffc_b.append(_vec(g(p + "5.2.1.bias"), ip))
+        ffo.append(_mat(g(p + "5.3.weight"), dtype))
+        ffo_b.append(_vec(g(p + "5.3.bias"), Dp))
+        if not conditioned:
+            g1.append(g(p + "0.gamma").float())
+            g2.append(g(p + "4.gamma").float())
+    dummy = torch.zeros(4, dtype=torch.float32)
+    return [
+        torch.stack(qkv), torch.stack(out), torch.stack(ffin), torch.stack(ffin_b), torch.stack(ffc),
+        torch.stack(ffc_b), torch.stack(ffo), torch.stack(ffo_b),
+        torch.stack(g1) if g1 else dummy, torch.stack(g2) if g2 else dummy.clone(),
+        g("to_pred.0.gamma").float().clone(), _mat(g("to_pred.1.weight"), dtype),
+    ]
+
+
+def pack_eps(sd: SD, cfg, dtype: int, max_pos: int = 2048) -> List[torch.Tensor]:
+    """cfg: object with dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult."""
+    D, Dp = cfg.dim, padk(cfg.dim)
+    C = D * cfg.dim_cond_mult
+    cond_rows, cond_b = [], []
+
+    def add_cond(wname, bname):
+        w, b = sd[wname].float(), sd[bname].float()  # [2D, C]: [gamma ; beta]
+        blk = torch.zeros(2 * Dp, C)
+        bb = torch.zeros(2 * Dp)
+        blk[:D], blk[Dp:Dp + D] = w[:D], w[D:]
+        bb[:D], bb[Dp:Dp + D] = b[:D], b[D:]
+        cond_rows.append(blk)
+        cond_b.append(bb)
+
+    for s in range(cfg.wavenet_stacks):
+        for i in range(cfg.wavenet_layers):
+            p = f"wavenet.stacks.{s}.blocks.{i}.to_time_cond."
+            add_cond(p + "weight", p + "bias")
+    for l in range(cfg.depth):
+        for j in (0, 4):
+            p = f"transformer.layers.{l}.{j}.to_gamma_beta."
+            add_cond(p + "weight", p + "bias")
+    cond_W = _mat(torch.cat(cond_rows, dim=0), dtype)
+    tensors = [
+        sd["to_time_cond.0.weights"].float().clone(),
+        sd["to_time_cond.1.weight"].float().contiguous().clone(),
+        sd["to_time_cond.1.bias"].float().clone(),
+        cond_W, torch.cat(cond_b),
+        _mat(sd["init_conv.weight"][:, :, 0], dtype), _vec(sd["init_conv.bias"], Dp),
+    ]
+    wsd = {k[len("wavenet."):]: v for k, v in sd.items() if k.startswith("wavenet.")}
+    tensors += pack_wavenet(wsd, "", D, D, cfg.wavenet_stacks, cfg.wavenet_layers, dtype)
+    tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+    tensors += pack_transformer(tsd, "", D, cfg.depth, cfg.heads, cfg.dim_head, dtype, conditioned=True)
+    tensors += [
+        _mat(sd["final_proj.weight"], dtype), _vec(sd["final_proj.bias"], padk(cfg.latent_dim)),
+        sinusoidal_table(max_pos + 1, D, Dp),
+    ]
+    return tensors
+
+
+def vae_mults(latent_flag: int) -> List[int]:
+    """chan_mults of SpeechVAEEncoderDecoder (reference latent_module.py:1044-1051)."""
+    return {16: [4, 3, 2], 32: [4, 3], 128: [3]}[latent_flag]
+
+
+def pack_vae(sd: SD, dim: int, mults: List[int], depth: int, heads: int, dim_head: int, stacks: int, layers: int,
+             vocab: int, dtype: int) -> List[torch.Tensor]:
+    tensors: List[torch.Tensor] = []
+    cur = dim
+    for n, m in enumerate(mults):
+        tensors += pack_wavenet(sd, f"encoder_wave.{n}.", cur, cur // m, stacks, layers, dtype)
+        cur //= m
+    first = True
+    for n, m in enumerate(reversed(mults)):
+        tgt = cur * m
+        cin = cur // 2 if first else cur
+        first = False
+        tensors += pack_wavenet(sd, f"decoder_wave.{n}.", cin, tgt, stacks, layers, dtype)
+        cur = tgt
+    tsd = {k[len("decoder_tf."):]: v for k, v in sd.items() if k.startswith("decoder_tf.")}
+    tensors += pack_transformer(tsd, "", dim, depth, heads, dim_head, dtype, conditioned=False)
+    tensors += [_mat(sd["decoder_lm.weight"], dtype), _vec(sd["decoder_lm.bias"], padn(vocab))]
+    return tensors

@@ -1,0 +1,215 @@
+/*
+ * diffnorm_hip.h -- C ABI of libdiffnorm_hip.so: the MI355X (gfx950) implementation of DiffNorm's
+ * latent-diffusion denoising hot path.
+ *
+ * The reference (steventan0110/DiffNorm) has no FFI on this path: its boundary is the fairseq Python
+ * plugin API and everything below it is stock ATen.  The entry points here are what a binding for the
+ * path would attach to; each cites the reference function it replaces (paths relative to
+ * fairseq/models/text_to_speech/ in the reference).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, enums; no torch types.
+ *   - every function returns 0 on success or a negative DN_E* code; dn_last_error() gives the text.
+ *   - functions taking a `stream` only enqueue work on it (hipStream_t passed as void*); they never
+ *     allocate device memory and never synchronise, so they are capturable into a hipGraph.
+ *   - activations are channels-last row-major: row m = b*T + t, `ld` elements between rows.
+ *   - `dtype` selects the arithmetic of the contractions: DN_BF16 = bf16 MFMA operands with fp32
+ *     accumulation (activations that feed a contraction are stored bf16, the transformer residual
+ *     stream stays fp32); DN_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.
+ */
+#ifndef DIFFNORM_HIP_H
+#define DIFFNORM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DN_F32 = 0, DN_BF16 = 1 };
+
+enum {
+  DN_OK = 0,
+  DN_EINVAL = -1,   /* bad argument (shape/alignment/enum) */
+  DN_ELAUNCH = -2,  /* HIP launch or runtime error */
+  DN_EWORKSPACE = -3 /* workspace too small */
+};
+
+/* epilogues of dn_conv_gemm */
+enum {
+  DN_EPI_BIAS = 0,      /* out = acc + bias                                               (nn.Linear / CausalConv1d) */
+  DN_EPI_SILU = 1,      /* out = silu(acc + bias)                                          latent_module.py:741-745 */
+  DN_EPI_GEGLU = 2,     /* out[:, j] = gelu_erf(gate_j) * value_j, GEGLU-interleaved packing latent_module.py:881-884 */
+  DN_EPI_FILM_GATE = 3, /* h=(acc+bias)[*gamma+beta]; out = tanh(h)*sigmoid(h) + res      latent_module.py:525-530 */
+  DN_EPI_RESADD = 4,    /* out = res + acc + bias  (fp32 residual stream)                  latent_module.py:692,704 */
+  DN_EPI_POSEMB = 5     /* out = acc + bias + pe[pos(b,t)]                                 latent_module.py:867-868 */
+};
+
+#define DN_MAX_TERMS 8
+
+/* One additive term of a causal-conv contraction: rows of A shifted back by `shift` frames inside
+ * each sequence (rows with t < shift read zeros), times the packed weight W[Np][K].              */
+typedef struct {
+  const void* A;      /* [M, lda] activations, element type = dtype                                */
+  const void* W;      /* [Np, K] packed weights (K contiguous), Np = N rounded up to 128           */
+  int32_t lda;        /* elements between rows of A                                                 */
+  int32_t shift;      /* causal shift in frames (tap j of a k-tap conv: (k-1-j)*dilation)           */
+  int64_t a_gstride;  /* elements added to A per group (0 = all groups share A)                     */
+  int64_t w_gstride;  /* elements added to W per group                                              */
+  int32_t shift_by_group; /* 1: effective shift = shift << group (WaveNet dilation 2^i)             */
+  int32_t pad_;
+} DnGemmTerm;
+
+/* out[g] = epilogue( sum_terms shift(A_term[g]) @ W_term[g]^T ), g = 0..groups-1.
+ * Replaces nn.Linear / CausalConv1d(k=1,3) and the ops the reference runs after them
+ * (latent_module.py:476-488, 513-536, 613-617, 887-903, 930-950).                               */
+typedef struct {
+  DnGemmTerm terms[DN_MAX_TERMS];
+  int32_t n_terms;
+  int32_t dtype;       /* DN_F32 | DN_BF16: element type of A and W                                 */
+  int32_t M, N, K;     /* rows (B*T), stored output columns (multiple of 4), K per term (multiple of
+                          64 for bf16 / 32 for f32)                                                 */
+  int32_t T;           /* frames per sequence: row m -> (b = m / T, t = m % T)                      */
+  int32_t groups;      /* independent problems in one launch (>= 1)                                 */
+  int32_t epilogue;    /* DN_EPI_*                                                                  */
+  const float* bias;   /* [N] fp32 or NULL                                                          */
+  int64_t bias_gstride;
+  void* out;           /* [M, ldo]                                                                  */
+  int32_t ldo;
+  int32_t out_dtype;   /* DN_F32 | DN_BF16                                                          */
+  int64_t out_gstride;
+  const void* res;     /* FILM_GATE: [M, ldr] in res_dtype; RESADD: fp32 [M, ldr] (may alias out)   */
+  int32_t ldr;
+  int32_t res_dtype;
+  int64_t res_gstride;
+  const float* gamma_beta; /* FILM_GATE: fp32 [Bc, gb_ld]: gamma at col 0.., beta at col gb_half..; NULL = no FiLM */
+  int32_t gb_ld;       /* elements between batch rows (0 = one row shared by the whole batch)       */
+  int32_t gb_half;     /* column offset of beta                                                     */
+  int64_t gb_gstride;
+  const float* pos_table; /* POSEMB: fp32 [T+1, pos_ld] sinusoidal table, row 0 = zeros             */
+  int32_t pos_ld;
+  int32_t pad_;
+  const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
+} DnGemmParams;
+
+int dn_conv_gemm(const DnGemmParams* p, void* stream);
+
+/* Fused key-masked multi-head self-attention, flash-style (no [B,H,T,T] tensor).
+ * Replaces Attend.forward (non-flash branch) latent_module.py:299-343 between the to_q/to_kv and
+ * to_out projections (:945-949).  q,k,v,out: row m = b*T+t, head h at columns [h*dh, (h+1)*dh).
+ * Keys j >= lengths[b] are masked (lengths[b] == 0 -> uniform over all T keys, as masked_fill gives). */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t B, T, heads, dim_head;
+  int32_t dtype;      /* element type of q,k,v,out                                                 */
+  int32_t pad_;
+  const int32_t* lengths; /* [B] or NULL (no mask)                                                  */
+  float scale;        /* dim_head ** -0.5                                                           */
+  int32_t pad2_;
+} DnAttnParams;
+
+int dn_attention(const DnAttnParams* p, void* stream);
+
+/* RMSNorm (latent_module.py:620-639): y = x / max(|x|_2, 1e-12) * sqrt(D) [* gamma] [* g_c[b] + b_c[b]].
+ * x fp32 [M, ldx]; y [M, ldy] in out_dtype; gamma fp32 [D] or NULL; gamma_beta fp32 [Bc, gb_ld] or NULL. */
+int dn_rmsnorm(const float* x, int32_t ldx, void* y, int32_t ldy, int32_t out_dtype, int32_t M, int32_t D,
+               int32_t T, const float* gamma, const float* gamma_beta, int32_t gb_ld, int32_t gb_half,
+               void* stream);
+
+/* LearnedSinusoidalPosEmb + Linear + SiLU (latent_module.py:104-116, 741-745).
+ * times int32 [B]; w_freq fp32 [half]; W fp32 [C, 2*half+1]; bias fp32 [C]; out fp32 [B, ldo] and,
+ * when out_act != NULL, a copy in act_dtype [B, ldo] for the conditioning contractions.            */
+int dn_time_cond(const int32_t* times, int32_t B, const float* w_freq, int32_t half, const float* W,
+                 const float* bias, int32_t C, float* out, void* out_act, int32_t act_dtype, int32_t ldo,
+                 void* stream);
+
+/* DDIM eta=0 update (latent_module.py:1419-1442, safe_div :958-959), elementwise over [B, T*z... rows].
+ * coef fp32 [n_steps, 4] = {sqrt_abar, sqrt_1m_abar, sqrt(abar_prev), sqrt(1-abar_prev)} (fp32 casts
+ * formed as the reference does); t int32 [B].  x, eps, x_out fp32 [M, ld]; x_act (optional, [M, ld_act])
+ * receives x_out in act_dtype for the next step's first contraction.                                        */
+int dn_ddim_step(const float* x, const float* eps, float* x_out, void* x_act, int32_t act_dtype,
+                 int32_t ld_act, int32_t M, int32_t C, int32_t ld, int32_t T, const float* coef,
+                 const int32_t* t, void* stream);
+
+/* out = a[t_b]*x + b[t_b]*noise: q_sample / noise injection
+ * (latent_module.py:1405-1409, 1538-1543; diffusion/gaussian_diffusion.py:215-230).               */
+int dn_q_sample(const float* x, const float* noise, float* out, void* out_act, int32_t act_dtype,
+                int32_t ld_act, int32_t M, int32_t C, int32_t ld, int32_t T, const float* coef_a,
+                const float* coef_b, const int32_t* t, void* stream);
+
+/* DiagonalGaussianDistribution (distributions.py:24-41, 62-74): params fp32 [M, ldp] = [mean ; logvar];
+ * z = mean + exp(0.5*clamp(logvar,-30,20))*noise; kl_rows (optional, fp32 [M]) = 0.5*sum_c(mean^2+var-1-logvar)
+ * for valid frames, 0 for pads.                                                                    */
+int dn_posterior_sample(const float* params, int32_t ldp, const float* noise, int32_t ldn, float* z,
+                        void* z_act, int32_t act_dtype, int32_t ldz, int32_t M, int32_t Z, int32_t T,
+                        const int32_t* lengths, float* kl_rows, void* stream);
+
+/* argmax over the first V logits of each row minus `offset` (latent_module.py:1450-1451). */
+int dn_argmax_units(const float* logits, int32_t ld, int32_t M, int32_t V, int32_t offset, int32_t* units,
+                    void* stream);
+
+/* Philox4x32-10 standard normal fill (Box-Muller), the build's own generator for throughput runs
+ * (the reference draws with torch.randn, latent_module.py:1409, distributions.py:38).             */
+int dn_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* dtype conversion / zero-padded row copy: dst[m, 0:C] = src[m, 0:C], dst[m, C:ldd] = 0. */
+int dn_convert_rows(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype,
+                    int32_t ldd, int32_t M, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------ whole-path engine ---------- */
+
+typedef struct {
+  int32_t dim, latent, depth, heads, dim_head, wn_layers, wn_stacks, cond_mult;
+  int32_t dtype;  /* DN_F32 | DN_BF16 */
+  int32_t max_pos; /* rows in the positional table minus 1 */
+} DnEpsConfig;
+
+typedef struct {
+  int32_t dim, z, depth, heads, dim_head, stacks, layers, vocab;
+  int32_t n_mults; int32_t mults[4];
+  int32_t dtype;
+} DnVaeConfig;
+
+typedef struct DnEps DnEps;   /* eps-predictor `Model`        latent_module.py:709-876  */
+typedef struct DnVae DnVae;   /* SpeechVAEEncoderDecoder      latent_module.py:1035-1142 */
+
+/* Packed-weight tables: device pointers in the order produced by diffnorm_amd/packing.py
+ * (documented in DESIGN.md "packed layout"); the library keeps the pointers, not copies.           */
+int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights, int32_t n_weights, DnEps** out);
+void dn_eps_destroy(DnEps* m);
+size_t dn_eps_workspace_bytes(const DnEps* m, int32_t B, int32_t T);
+/* Model.forward (latent_module.py:828-876): x fp32 [B,T,latent] dense, t int32 [B], lengths int32 [B]
+ * -> eps fp32 [B,T,latent].  shared_t != 0 promises all t[b] equal (sampling) so the 56 conditioning
+ * projections run for one row.                                                                     */
+int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
+                   int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream);
+
+int dn_vae_create(const DnVaeConfig* cfg, const void* const* weights, int32_t n_weights, DnVae** out);
+void dn_vae_destroy(DnVae* m);
+size_t dn_vae_workspace_bytes(const DnVae* m, int32_t B, int32_t T);
+/* encoder WaveNets of encode_feature (latent_module.py:1099-1106): feat fp32 [B,T,dim] -> params fp32 [B,T,2z] */
+int dn_vae_encode_params(DnVae* m, const float* feat, int32_t B, int32_t T, float* params, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* decode_feature (latent_module.py:1109-1116): latent fp32 [B,T,z] -> recon fp32 [B,T,dim], logits fp32
+ * [B,T,vocab] (either may be NULL), units int32 [B,T] = argmax-4 (may be NULL)                     */
+int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengths, int32_t B, int32_t T, float* recon,
+                  float* logits, int32_t* units, void* workspace, size_t workspace_bytes, void* stream);
+
+/* LatentDiscreteModel.ddim_sample's device loop (latent_module.py:1405-1445): starting from x (already
+ * noised at start_step), evaluates the eps-predictor for t = start_step-1 .. 1 (t = 0 only when
+ * start_step == 1) with the eta=0 update after each.  coef: fp32 [timesteps,4] as dn_ddim_step.
+ * x fp32 [B,T,latent] is updated in place.  use_graph != 0 captures one step into a hipGraph and
+ * replays it.  Returns the number of model evaluations (>= 0) or a negative error.                 */
+int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step,
+                 const float* coef, int32_t timesteps, int32_t use_graph, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+const char* dn_last_error(void);
+int dn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFNORM_HIP_H */

@@ -1,0 +1,102 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports every symbol include/diffnorm_hip.h
+declares, the ctypes structs match the header's layout, and bad arguments are rejected on the host
+(no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "diffnorm_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from diffnorm_amd import _lib
+
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from diffnorm_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.SYMBOLS, f"{n} declared in the header but not bound in _lib.SYMBOLS"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_struct_layout_matches_header(lib, tmp_path):
+    """Compiles the header with gcc and compares sizeof/offsetof with the ctypes mirrors."""
+    import subprocess
+
+    from diffnorm_amd import _lib
+
+    probes = {
+        "DnGemmTerm": (_lib.GemmTerm, ["A", "W", "lda", "shift", "a_gstride", "w_gstride", "shift_by_group"]),
+        "DnGemmParams": (_lib.GemmParams, ["terms", "n_terms", "dtype", "M", "N", "K", "T", "groups", "epilogue", "bias",
+                                           "bias_gstride", "out", "ldo", "out_dtype", "out_gstride", "res", "ldr", "res_dtype",
+                                           "res_gstride", "gamma_beta", "gb_ld", "gb_half", "gb_gstride", "pos_table", "pos_ld",
+                                           "lengths"]),
+        "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
+                                           "dtype", "lengths", "scale"]),
+        "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
+                                         "dtype", "max_pos"]),
+        "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",
+                                         "mults", "dtype"]),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, (_, fields) in probes.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, (ct, fields) in probes.items():
+        assert C.sizeof(ct) == int(out[cname]), cname
+        for f in fields:
+            assert getattr(ct, f).offset == int(out[f"{cname}.{f}"]), f"{cname}.{f}"
+
+
+def test_version_and_host_side_argument_checks(lib):
+    from diffnorm_amd import _lib
+
+    assert lib.dn_version() >= 100
+    p = _lib.GemmParams()  # all zeros: must be refused before any launch
+    assert lib.dn_conv_gemm(C.byref(p), None) == -1
+    assert b"dn_conv_gemm" in lib.dn_last_error()
+    a = _lib.AttnParams()
+    assert lib.dn_attention(C.byref(a), None) == -1
+    assert lib.dn_eps_workspace_bytes(None, 1, 1) == 0
+    with pytest.raises(_lib.DiffNormHipError):
+        _lib.check(-1, "probe")
+
+
+def test_engines_refuse_to_run_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffnorm_amd import _lib, engine
+
+    with pytest.raises(_lib.DiffNormHipError):
+        engine._require_cuda("cuda:0")
+    with pytest.raises(_lib.DiffNormHipError):
+        engine._require_cuda("cpu")

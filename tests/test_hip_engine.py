@@ -1,0 +1,151 @@
+"""GPU parity of the whole path (C-ABI engine) against the CPU oracle and the committed golden vectors.
+
+Budgets (north_star): 1e-3 in f32 mode, 1e-2 in bf16 mode, on O(1) activations; the golden vectors
+are outputs of the real reference (tests/golden, oracle/gen_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import diffnorm_oracle as O
+from gen_golden_configs import CHAIN_EPS, CHAIN_VAE, FULL_EPS, FULL_VAE, TINY_EPS, ragged_lengths, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from diffnorm_amd import engine, scheduler
+
+    return engine, scheduler
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
+    engine, _ = eng
+    g = golden("eps_tiny")
+    sd = O.make_eps_state_dict(TINY_EPS, "tiny")
+    e = engine.EpsEngine(sd, TINY_EPS, dtype=dtype, device=DEV)
+    x, t, lens = T_(g["x"]), T_(g["t"]), T_(g["lens"])
+    got = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
+    mask = O.lengths_to_mask(lens, x.shape[1])
+    ref = T_(g["eps"])
+    assert maxerr(got[mask], ref[mask]) < tol
+    # padded frames are computed like upstream too (dense), so the whole tensor matches
+    assert maxerr(got, ref) < tol * 3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_eps_properties(eng, dtype):
+    """Reference properties: valid frames are invariant to the content of right-padded frames,
+    samples are independent across the batch, shared_t equals per-sample t."""
+    engine, _ = eng
+    sd = O.make_eps_state_dict(TINY_EPS, "tiny")
+    e = engine.EpsEngine(sd, TINY_EPS, dtype=dtype, device=DEV)
+    B, T = 4, 70
+    x = seeded((B, T, 16), 3)
+    lens = torch.tensor([70, 33, 1, 50])
+    t = torch.full((B,), 123)
+    mask = O.lengths_to_mask(lens, T)
+    a = e.forward(x.to(DEV), t, lens).cpu()
+    x2 = x.clone()
+    x2[~mask] = 1e3  # garbage in the padding
+    b = e.forward(x2.to(DEV), t, lens).cpu()
+    assert torch.equal(a[mask], b[mask])
+    c = e.forward(x.to(DEV), t, lens, shared_t=True).cpu()
+    assert torch.equal(a, c)
+    single = e.forward(x[1:2].to(DEV), t[1:2], lens[1:2]).cpu()
+    assert maxerr(single[0][mask[1]], a[1][mask[1]]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+def test_eps_full_cfg2_vs_reference_golden(eng, golden, dtype, tol):
+    """BASELINE config 2: [8,256,128] latents, t=500, full-size eps-predictor, eps-MSE and max-abs vs the reference."""
+    engine, _ = eng
+    g = golden("eps_full_cfg2")
+    sd = O.make_eps_state_dict(FULL_EPS, "full")
+    e = engine.EpsEngine(sd, FULL_EPS, dtype=dtype, device=DEV)
+    del sd
+    x = seeded((8, 256, 128), 0)
+    lens = T_(g["lens"])
+    got = e.forward(x.to(DEV), T_(g["t"]), lens, shared_t=True).cpu()
+    mask = O.lengths_to_mask(lens, 256)
+    ref = T_(g["eps"])
+    err = maxerr(got[mask], ref[mask])
+    mse = ((got - ref)[mask] ** 2).mean().item()
+    print(f"cfg2 {dtype}: max abs {err:.3e}  mse {mse:.3e}  ref rms {ref[mask].pow(2).mean().sqrt().item():.3f}")
+    assert err < tol and mse < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
+    """VAE encode/decode + DDIM chains (start_step 1, 5, 50; T=200) with the reference's recorded noise."""
+    engine, scheduler = eng
+    g = golden("chain_small")
+    esd = O.make_eps_state_dict(CHAIN_EPS, "chain")
+    vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
+    ee = engine.EpsEngine(esd, CHAIN_EPS, dtype=dtype, device=DEV)
+    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype=dtype, device=DEV)
+    assert ve.z == CHAIN_VAE.z
+    B, Tn = 3, 48
+    feat = seeded((B, Tn, CHAIN_VAE.dim), 31)
+    lens, units = T_(g["lens"]), T_(g["units"])
+    mask = O.lengths_to_mask(lens, Tn)
+    sched = scheduler.DDPMScheduler(200)
+    coef = sched.ddim_coef_table(DEV)
+    params = ve.encode_params(feat.to(DEV))
+    assert maxerr(params.cpu(), O.vae_encode_params(vsd, CHAIN_VAE, feat)) < tol
+    from diffnorm_amd import ops
+
+    for start in (1, 5, 50):
+        z = ve.sample_posterior(params, T_(g[f"s{start}_post_noise"]))
+        ts = torch.full((B,), start, dtype=torch.int32, device=DEV)
+        x = ops.q_sample(z, T_(g[f"s{start}_start_noise"]).to(DEV), sched.f32("sqrt_alphas_cumprod", DEV),
+                         sched.f32("sqrt_one_minus_alphas_cumprod", DEV), ts, Tn)
+        for use_graph in (False, True):
+            xs = x.clone()
+            n = ee.ddim_loop(xs, lens.to(DEV).int(), start, coef, use_graph=use_graph)
+            assert n == max(1, start - 1)
+            recon, logits, u = ve.decode(xs, lens)
+            err = maxerr(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask])
+            print(f"chain start={start} {dtype} graph={use_graph}: recon max abs err {err:.3e}")
+            assert err < tol * 5  # (start-1) sequential evaluations accumulate
+            got_units = torch.cat([u[i, : int(lens[i])] for i in range(B)]).cpu().numpy()
+            agree = (got_units == g[f"s{start}_units"]).mean()
+            assert agree >= (0.99 if dtype == "f32" else 0.9), agree
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+def test_vae_full_cfg1_vs_reference_golden(eng, golden, dtype, tol):
+    """BASELINE config 1: 64 x [128,768] encode -> posterior sample -> decode -> 1004-way logits."""
+    engine, _ = eng
+    g = golden("vae_full_cfg1")
+    sd = O.make_vae_state_dict(FULL_VAE, "full")
+    ve = engine.VaeEngine(sd, dtype=dtype, device=DEV)
+    del sd
+    feat = seeded((64, 128, 768), 0)
+    lens = T_(g["lens"])
+    mask = O.lengths_to_mask(lens, 128)
+    noise = seeded((64, 128, 128), 3)
+    params = ve.encode_params(feat.to(DEV))
+    assert maxerr(params.cpu()[:2], T_(g["params_head"])) < tol
+    assert maxerr(params.cpu().sum(dim=(1, 2)), T_(g["params_sum"])) < tol * 200
+    z = ve.sample_posterior(params, noise)
+    recon, logits, units = ve.decode(z, lens)
+    rc, lg = recon.cpu(), logits.cpu()
+    m2 = mask[:2]
+    assert maxerr(rc[:2, :, :96][m2], T_(g["recon_head"])[m2]) < tol
+    assert maxerr(lg[:2, :16], T_(g["logits_head"])) < tol
+    margin = T_(g["margin"])
+    safe = mask & (margin > (1e-3 if dtype == "f32" else 5e-2))
+    assert (units.cpu()[safe] == T_(g["units"]).int()[safe]).all()
+    assert (units.cpu() == (lg.argmax(-1) - 4).int()).all()
