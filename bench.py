@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the DiffNorm denoising hot path on MI355X (driver contract: one JSON line on rank 0).
+
+A "step" = one denoising step: eps-predictor forward (`Model.forward`, reference latent_module.py:828-876)
++ DDIM eta=0 scheduler update (:1419-1442) on a batch of B x T latent frames.  Workload at N=1 =
+BASELINE.json configs[2]: [B=32, T=512] latents (z=128, hidden 512) on the 1000-step cosine schedule,
+bf16 MFMA arithmetic, synthetic N(0,1) latents and random-init weights of the recipe architecture.
+With N > 1 every rank runs its own [32,512] batch (utterances are independent: weak scaling, no
+data-path collective); value = N*K steps / max-over-ranks time.
+
+Extra objects: "roofline" (dominant kernel = the FFN causal-conv contraction, timed live with HIP
+events) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
+    """FFN CausalConv1d(1365,1365,3) as one dn_conv_gemm launch: M = B*T rows, K = 3 x 1408 (padded), N = 1408.
+    Returns (avg seconds per launch, algorithmic FLOPs per launch)."""
+    import torch
+
+    inner, ip = 1365, packing.padk(1365)
+    M = B * T
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    a = torch.randn(M, ip, device=dev).to(tdt)
+    a[:, inner:] = 0
+    w = (torch.randn(3, packing.padn(inner), ip, device=dev) * 0.02).to(tdt)
+    bias = torch.zeros(ip, device=dev)
+    out = torch.empty(M, ip, device=dev, dtype=tdt)
+    terms = [(a, w[j], 2 - j) for j in range(3)]
+    for _ in range(3):
+        ops.conv_gemm(terms, out, T, ip, bias=bias)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv_gemm(terms, out, T, ip, bias=bias)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters, 2.0 * M * (3 * inner) * inner
+
+
+def cpu_baseline(sd, cfg, B, T, timesteps, sample_b):
+    """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/golden) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+
+    import diffnorm_oracle as O
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    ocfg = O.EpsConfig(dim=cfg.dim, latent_dim=cfg.latent_dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head,
+                       wavenet_layers=cfg.wavenet_layers, wavenet_stacks=cfg.wavenet_stacks, dim_cond_mult=cfg.dim_cond_mult)
+    tab = O.ddpm_tables(timesteps)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample_b, T, cfg.latent_dim, generator=g)
+    mask = torch.ones(sample_b, T, dtype=torch.bool)
+
+    def step(xx, tval):
+        t = torch.full((xx.shape[0],), tval, dtype=torch.long)
+        return O.ddim_update(tab, xx, O.eps_forward(sd, ocfg, xx, t, mask[: xx.shape[0]]), t)
+
+    with torch.no_grad():
+        step(x[:1, :64], 500)  # warm-up (thread pool, allocator)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            x = step(x, timesteps - 2 - n)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 or n >= 3:
+                break
+    steps_per_s = n / dt * (sample_b / B)  # sequences are independent: a B-sequence step costs B/sample_b as much
+    return {"value": steps_per_s, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} step(s) of [{sample_b},{T},{cfg.latent_dim}] (a {sample_b}/{B} slice of the batch; "
+                      f"rate scaled by {sample_b}/{B}) in {dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from diffnorm_amd import _lib, engine, ops, packing, scheduler, synthetic
+
+    cfg = synthetic.eps_config()
+    sd = synthetic.random_eps_state_dict(cfg, seed=0)
+    eng = engine.EpsEngine(sd, cfg, dtype=args.dtype, device=dev)
+    B, T, K, W = args.batch, args.frames, args.steps, args.warmup
+    sched = scheduler.DDPMScheduler(args.timesteps)
+    coef = sched.ddim_coef_table(dev)
+    start = args.timesteps - 1  # "full 1000-step" chain: t = 998 ... 1 (last bullet)
+    assert W + K <= start - 1, "steps + warmup exceed the chain length"
+    x = ops.randn((B, T, cfg.latent_dim), seed=1234 + rank, device=dev)  # x_T ~ N(0, I): the build's Philox
+    lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
+
+    stream = torch.cuda.Stream(device=dev)  # graphs cannot be captured on the null stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        if W > 0:
+            n = eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=W)
+            assert n == W
+        barrier()
+        t0 = time.perf_counter()
+        n = eng.ddim_loop(x, lengths, start - W, coef, use_graph=not args.no_graph, max_evals=K)
+        barrier()
+        dt = time.perf_counter() - t0
+        assert n == K
+        assert torch.isfinite(x).all().item(), "state diverged"
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    result = None
+    if rank == 0:
+        step_flops = synthetic.eps_step_flops(B, T)
+        with torch.cuda.stream(stream):
+            ksec, kflops = time_dominant_kernel(ops, _lib, packing, dev, B, T, args.dtype)
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        achieved = kflops / ksec / 1e12
+        result = {
+            "metric": "denoising-steps/sec (BxT latents)", "value": world * K / dt, "unit": "denoising-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[2]: DDIM/DDPM-schedule reverse chain, eps-predictor Model(512, z=128) on "
+                                   f"[B={B},T={T}] latents per GPU, {args.timesteps}-step cosine schedule, random-init weights",
+                       "batch_per_gpu": B, "frames": T, "latent_dim": cfg.latent_dim, "timesteps": args.timesteps,
+                       "hip_graph": not args.no_graph, "parallelism": f"batch-sharded x{world} (no collective)"},
+            "frame_steps_per_s": world * K * B * T / dt,
+            "step_tflops": step_flops * K / dt / 1e12,
+            "step_mfma_frac": step_flops * K / dt / 1e12 / peak,
+            "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel<{args.dtype}, BIAS> FFN causal conv k=3 "
+                                                    f"[{B * T} x 4095] x [4095 x 1365]",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B))
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

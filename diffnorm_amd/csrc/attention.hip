@@ -78,8 +78,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 
   int len = p.lengths ? p.lengths[b] : T;
   len = len < T ? len : T;
-  if (len <= 0) len = T;  // every key masked: masked_fill gives a uniform softmax over all T keys
-  const float sc = p.scale * 1.44269504088896340736f;  // work in log2 domain
+  float sc = p.scale * 1.44269504088896340736f;  // work in log2 domain
+  if (len <= 0) {  // every key masked: masked_fill makes all scores equal -> uniform softmax over all T keys
+    len = T;
+    sc = 0.f;
+  }
 
   for (int kv0 = 0; kv0 < len; kv0 += KV_TILE) {
     __syncthreads();  // previous tile fully consumed

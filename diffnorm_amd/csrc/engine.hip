@@ -219,7 +219,7 @@ int check_dims(const char* who, int dtype, int dim, int heads, int dim_head, int
 // ------------------------------------------------------------------------------------------ eps plan
 struct EpsBufs {
   float *cond, *gb, *xres;
-  void *cond_act, *xin, *h0, *tp;
+  void *xin, *h0, *tp;
   WaveBufs wv;
   TfBufs tf;
 };
@@ -229,7 +229,6 @@ EpsBufs plan_eps(const DnEps* m, int B, int T, int Bt, Arena& ar) {
   const int C = m->cfg.dim * m->cfg.cond_mult, Dp = padk(m->cfg.dim), zp = padk(m->cfg.latent);
   EpsBufs b;
   b.cond = (float*)ar.take((size_t)Bt * C * 4);
-  b.cond_act = ar.take((size_t)Bt * C * es);
   b.gb = (float*)ar.take((size_t)Bt * m->n_cond * 4);
   b.xin = ar.take((size_t)M * zp * es);
   b.h0 = ar.take((size_t)M * Dp * es);
@@ -291,35 +290,29 @@ static size_t eps_ws_core(const DnEps* m, int B, int T) {
 
 extern "C" size_t dn_eps_workspace_bytes(const DnEps* m, int32_t B, int32_t T) {
   if (!m || B <= 0 || T <= 0) return 0;
-  // + the DDIM loop's own state (eps buffer, t vector, counter) so one query serves both entry points
-  return eps_ws_core(m, B, T) + (size_t)B * T * m->cfg.latent * 4 + (size_t)B * 4 + 1024;
+  return eps_ws_core(m, B, T);
 }
 
-extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
-                              int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
-  DN_CHECK_ARG(m && x && t && lengths && eps_out && workspace, "dn_eps_forward: null argument");
-  DN_CHECK_ARG(B > 0 && T > 0, "dn_eps_forward: B=%d T=%d", B, T);
-  DN_CHECK_ARG(T <= m->cfg.max_pos, "dn_eps_forward: T=%d exceeds the positional table (%d)", T, m->cfg.max_pos);
-  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward: workspace must be 256-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
+namespace {
+
+// Conditioning table: rows of [gamma ; beta] for the S*L FiLM blocks and the 2*depth adaptive norms,
+// one row per entry of `times`.  Always fp32 (exact-f32 MFMA, fp32 weights): the raw integer timestep
+// drives activations of O(100), so this tiny contraction is kept out of the bf16 budget.
+int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, float* gb, hipStream_t s) {
+  const int D = m->cfg.dim, C = D * m->cfg.cond_mult;
+  DN_TRY(dn_time_cond(times, n, m->w_freq, D / 2, m->tc_W, m->tc_b, C, cond, nullptr, DN_F32, C, s));
+  DnGemmParams p = gemm_base(DN_F32, n, m->n_cond, C, 1);  // (:507,517) and (:624,637), all at once
+  p.terms[0].A = cond; p.terms[0].lda = C; p.terms[0].W = m->cond_W;
+  p.bias = m->cond_b; p.out = gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+  return dn_conv_gemm(&p, s);
+}
+
+// Model.forward after the conditioning (latent_module.py:861-876); gb_ld == 0 -> one row for the batch.
+int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const int32_t* lengths, int B, int T, float* eps_out,
+             const EpsBufs& b, hipStream_t s) {
   const DnEpsConfig& c = m->cfg;
-  const int dtype = c.dtype, es = esize(dtype), M = B * T, Bt = shared_t ? 1 : B;
-  const int D = c.dim, Dp = padk(D), Dn = padn(D), z = c.latent, zp = padk(z), C = D * c.cond_mult;
-  Arena ar{(char*)workspace, 0, workspace_bytes};
-  EpsBufs b = plan_eps(m, B, T, Bt, ar);
-  if (ar.off > workspace_bytes) {
-    dn_set_error("dn_eps_forward: workspace %zu < required %zu", workspace_bytes, ar.off);
-    return DN_EWORKSPACE;
-  }
-  // a1: timestep embedding -> [Bt, C]
-  DN_TRY(dn_time_cond(t, Bt, m->w_freq, D / 2, m->tc_W, m->tc_b, C, b.cond, b.cond_act, dtype, C, s));
-  {  // all 56 FiLM / adaptive-norm projections in one contraction (:507,517 and :624,637)
-    DnGemmParams p = gemm_base(dtype, Bt, m->n_cond, C, 1);
-    p.terms[0].A = b.cond_act; p.terms[0].lda = C; p.terms[0].W = m->cond_W;
-    p.bias = m->cond_b; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
-    DN_TRY(dn_conv_gemm(&p, s));
-  }
-  const int gb_ld = shared_t ? 0 : m->n_cond;
+  const int dtype = c.dtype, M = B * T;
+  const int D = c.dim, Dp = padk(D), z = c.latent, zp = padk(z);
   DN_TRY(dn_convert_rows(x, DN_F32, z, b.xin, dtype, zp, M, z, s));
   {  // init_conv 1x1: latent -> dim (:734,864)
     DnGemmParams p = gemm_base(dtype, M, Dp, zp, T);
@@ -331,39 +324,93 @@ extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const 
     DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
     fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
-    DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, b.gb, gb_ld, b.wv, fin, s));
+    DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, gb, gb_ld, b.wv, fin, s));
   }
-  const float* gb_tf = b.gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
+  const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
   DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
   p.bias = m->final_b; p.out = eps_out; p.ldo = z; p.out_dtype = DN_F32;
-  (void)Dn; (void)es;
   return dn_conv_gemm(&p, s);
 }
 
-extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, const float* coef,
-                            int32_t timesteps, int32_t use_graph, void* workspace, size_t workspace_bytes, void* stream) {
+__global__ void copy_cond_row_kernel(const float* __restrict__ table, int n_cond, const int32_t* __restrict__ counter,
+                                     float* __restrict__ dst) {
+  const float4* src = reinterpret_cast<const float4*>(table + (size_t)(*counter) * n_cond);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_cond / 4; i += gridDim.x * 256) reinterpret_cast<float4*>(dst)[i] = src[i];
+}
+
+__global__ void iota_kernel(int32_t* t, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) t[i] = i;
+}
+
+}  // namespace
+
+extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
+                              int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && x && t && lengths && eps_out && workspace, "dn_eps_forward: null argument");
+  DN_CHECK_ARG(B > 0 && T > 0, "dn_eps_forward: B=%d T=%d", B, T);
+  DN_CHECK_ARG(T <= m->cfg.max_pos, "dn_eps_forward: T=%d exceeds the positional table (%d)", T, m->cfg.max_pos);
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int Bt = shared_t ? 1 : B;
+  Arena ar{(char*)workspace, 0, workspace_bytes};
+  EpsBufs b = plan_eps(m, B, T, Bt, ar);
+  if (ar.off > workspace_bytes) {
+    dn_set_error("dn_eps_forward: workspace %zu < required %zu", workspace_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  DN_TRY(eps_cond_rows(m, t, Bt, b.cond, b.gb, s));
+  return eps_core(m, x, b.gb, shared_t ? 0 : m->n_cond, lengths, B, T, eps_out, b, s);
+}
+
+static size_t ddim_extra_bytes(const DnEps* m, int B, int T, int start_step) {
+  const size_t C = (size_t)m->cfg.dim * m->cfg.cond_mult;
+  return (size_t)B * T * m->cfg.latent * 4 + (size_t)start_step * (m->n_cond + C) * 4 + (size_t)(B + start_step) * 4 + 4096;
+}
+
+extern "C" size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t start_step) {
+  if (!m || B <= 0 || T <= 0 || start_step < 1) return 0;
+  return eps_ws_core(m, B, T) + ddim_extra_bytes(m, B, T, start_step);
+}
+
+extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
+                            const float* coef, int32_t timesteps, int32_t use_graph, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   DN_CHECK_ARG(m && x && lengths && coef && workspace, "dn_ddim_loop: null argument");
   DN_CHECK_ARG(start_step >= 1 && start_step <= timesteps - 1, "dn_ddim_loop: start_step=%d must be in [1, %d]", start_step, timesteps - 1);
   hipStream_t s = (hipStream_t)stream;
-  const int z = m->cfg.latent, M = B * T;
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_ddim_loop: workspace must be 256-byte aligned");
+  const int z = m->cfg.latent, M = B * T, C = m->cfg.dim * m->cfg.cond_mult;
   const size_t core = eps_ws_core(m, B, T);
-  const size_t need = core + (size_t)M * z * 4 + (size_t)B * 4 + 1024;
+  const size_t need = core + ddim_extra_bytes(m, B, T, start_step);
   if (need > workspace_bytes) {
-    dn_set_error("dn_ddim_loop: workspace %zu < required %zu", workspace_bytes, need);
+    dn_set_error("dn_ddim_loop: workspace %zu < required %zu (see dn_ddim_workspace_bytes)", workspace_bytes, need);
     return DN_EWORKSPACE;
   }
-  char* base = (char*)workspace;
-  float* eps = (float*)(base + core);
-  int32_t* tvec = (int32_t*)(base + core + (((size_t)M * z * 4 + 255) & ~size_t(255)));
-  int32_t* counter = tvec + ((B + 63) / 64) * 64;
+  Arena core_ar{(char*)workspace, 0, core};
+  const EpsBufs bufs = plan_eps(m, B, T, 1, core_ar);
+  Arena ar{(char*)workspace + core, 0, workspace_bytes - core};
+  // fixed-size state first, so a cached graph stays valid when only start_step changes
+  float* eps = (float*)ar.take((size_t)M * z * 4);
+  int32_t* tvec = (int32_t*)ar.take((size_t)B * 4);
+  int32_t* counter = (int32_t*)ar.take(64);
+  float* table = (float*)ar.take((size_t)start_step * m->n_cond * 4);  // conditioning rows for t = 0..start_step-1
+  float* cond_all = (float*)ar.take((size_t)start_step * C * 4);
+  int32_t* tall = (int32_t*)ar.take((size_t)start_step * 4);
   const int last = start_step == 1 ? 0 : 1;  // the loop breaks after the t == 1 update (:1444-1445)
-  const int n_eval = start_step - last;       // t = start_step-1 ... last
+  int n_eval = start_step - last;             // t = start_step-1 ... last
+  if (max_evals > 0 && max_evals < n_eval) n_eval = max_evals;  // partial chain (benchmarks, chunked sampling)
+  // The 56 conditioning vectors depend only on t: build them for the whole chain once (fp32), so the
+  // 117 M conditioning weights are not re-streamed at every step.
+  hipLaunchKernelGGL(iota_kernel, dim3((start_step + 255) / 256), dim3(256), 0, s, tall, start_step);
+  DN_TRY(eps_cond_rows(m, tall, start_step, cond_all, table, s));
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
-    DN_TRY(dn_eps_forward(m, x, tvec, lengths, B, T, 1, eps, workspace, core, s));
+    hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_cond, counter, bufs.gb);
+    DN_TRY(eps_core(m, x, bufs.gb, 0, lengths, B, T, eps, bufs, s));
     DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, M, z, z, T, coef, tvec, s));
     hipLaunchKernelGGL(dec_counter_kernel, dim3(1), dim3(1), 0, s, counter);
     DN_CHECK_LAUNCH("dn_ddim_loop step");

@@ -97,7 +97,7 @@ class EpsEngine(_Engine):
         return out
 
     def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
-                  use_graph: bool = True) -> int:
+                  use_graph: bool = True, max_evals: int = 0) -> int:
         """In-place DDIM eta=0 chain on x [B,T,z] fp32 (reference latent_module.py:1411-1445).
         coef: fp32 [timesteps,4] from `scheduler.ddim_coef_table`.  Returns the number of model evaluations."""
         B, T, z = x.shape
@@ -105,11 +105,11 @@ class EpsEngine(_Engine):
         assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.device == self.device
         l32 = lengths if (lengths.dtype == torch.int32 and lengths.device == self.device) else _i32(lengths, self.device)
         self._keep = (l32, coef)
-        ws = self._workspace(self.workspace_bytes(B, T))
+        ws = self._workspace(int(self.lib.dn_ddim_workspace_bytes(self.handle, B, T, start_step)))
         wp, wn = self._aligned(ws)
         with torch.cuda.device(self.device):
             return _lib.check(self.lib.dn_ddim_loop(self.handle, x.data_ptr(), l32.data_ptr(), B, T, start_step,
-                                                    coef.data_ptr(), coef.shape[0], int(use_graph), wp, wn,
+                                                    max_evals, coef.data_ptr(), coef.shape[0], int(use_graph), wp, wn,
                                                     _lib.current_stream()), "dn_ddim_loop")
 
 

@@ -158,7 +158,7 @@ def pack_eps(sd: SD, cfg, dtype: int, max_pos: int = 2048) -> List[torch.Tensor]
         for j in (0, 4):
             p = f"transformer.layers.{l}.{j}.to_gamma_beta."
             add_cond(p + "weight", p + "bias")
-    cond_W = _mat(torch.cat(cond_rows, dim=0), dtype)
+    cond_W = _mat(torch.cat(cond_rows, dim=0), _lib.DN_F32)  # conditioning stays fp32 in every mode
     tensors = [
         sd["to_time_cond.0.weights"].float().clone(),
         sd["to_time_cond.1.weight"].float().contiguous().clone(),

@@ -1,0 +1,110 @@
+"""Random-init weights and synthetic inputs of the reference's shapes for benchmarks and smoke runs
+(there is no network for checkpoints).  State dicts use the reference's key layout and
+PyTorch's default fan-in initialisation scale, like freshly constructed reference modules.
+"""
+from types import SimpleNamespace
+from typing import Dict
+
+import torch
+
+
+def eps_config(dim=512, latent_dim=128, depth=12, heads=8, dim_head=64, wavenet_layers=8, wavenet_stacks=4, dim_cond_mult=4):
+    """Hyper-parameters of the eps-predictor `Model` (reference latent_module.py:709-728, diff_discrete.py:83-84)."""
+    return SimpleNamespace(dim=dim, latent_dim=latent_dim, depth=depth, heads=heads, dim_head=dim_head,
+                           wavenet_layers=wavenet_layers, wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult)
+
+
+class _Init:
+    def __init__(self, seed: int):
+        self.g = torch.Generator().manual_seed(seed)
+        self.sd: Dict[str, torch.Tensor] = {}
+
+    def lin(self, name, out, inp, bias=True, k=None):
+        shape = (out, inp) if k is None else (out, inp, k)
+        bound = (1.0 / (inp * (k or 1))) ** 0.5  # kaiming_uniform(a=sqrt(5)) bound of nn.Linear / nn.Conv1d
+        self.sd[name + ".weight"] = (torch.rand(*shape, generator=self.g) * 2 - 1) * bound
+        if bias:
+            self.sd[name + ".bias"] = (torch.rand(out, generator=self.g) * 2 - 1) * bound
+
+
+def random_eps_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    D, Z, C = cfg.dim, cfg.latent_dim, cfg.dim * cfg.dim_cond_mult
+    inner, hd = int(D * 4 * 2 / 3), cfg.heads * cfg.dim_head
+    it = _Init(seed)
+    it.lin("init_conv", D, Z, k=1)
+    it.sd["to_time_cond.0.weights"] = torch.randn(D // 2, generator=it.g)
+    it.lin("to_time_cond.1", C, D + 1)
+    it.lin("wavenet.init_conv", D, D, k=3)
+    for s in range(cfg.wavenet_stacks):
+        for i in range(cfg.wavenet_layers):
+            p = f"wavenet.stacks.{s}.blocks.{i}."
+            it.lin(p + "to_time_cond", 2 * D, C)
+            it.lin(p + "conv", D, D, k=3)
+            it.lin(p + "res_conv", D, D, k=1)
+            if s == cfg.wavenet_stacks - 1:
+                it.lin(p + "skip_conv", D, D, k=1)
+    it.lin("wavenet.final_conv", D, D, k=1)
+    for l in range(cfg.depth):
+        p = f"transformer.layers.{l}."
+        it.lin(p + "0.to_gamma_beta", 2 * D, C)
+        it.lin(p + "1.to_q", hd, D, bias=False)
+        it.lin(p + "1.to_kv", 2 * hd, D, bias=False)
+        it.lin(p + "1.to_out", D, hd, bias=False)
+        it.lin(p + "4.to_gamma_beta", 2 * D, C)
+        it.lin(p + "5.0", 2 * inner, D)
+        it.lin(p + "5.2.1", inner, inner, k=3)
+        it.lin(p + "5.3", D, inner)
+    it.sd["transformer.to_pred.0.gamma"] = torch.ones(D)
+    it.lin("transformer.to_pred.1", D, D, bias=False)
+    it.lin("final_proj", Z, D)
+    return it.sd
+
+
+def random_vae_state_dict(dim=768, latent_dim=128, depth=6, heads=8, dim_head=96, stacks=2, layers=3, vocab=1004,
+                          seed: int = 1) -> Dict[str, torch.Tensor]:
+    from .packing import vae_mults
+
+    it = _Init(seed)
+
+    def wave(prefix, cin, cout):
+        it.lin(prefix + "init_conv", cout, cin, k=3)
+        for s in range(stacks):
+            for i in range(layers):
+                p = f"{prefix}stacks.{s}.blocks.{i}."
+                it.lin(p + "conv", cout, cout, k=3)
+                it.lin(p + "res_conv", cout, cout, k=1)
+                if s == stacks - 1:
+                    it.lin(p + "skip_conv", cout, cout, k=1)
+        it.lin(prefix + "final_conv", cout, cout, k=1)
+
+    mults = vae_mults(latent_dim)
+    cur = dim
+    for n, m in enumerate(mults):
+        wave(f"encoder_wave.{n}.", cur, cur // m)
+        cur //= m
+    first = True
+    for n, m in enumerate(reversed(mults)):
+        tgt = cur * m
+        wave(f"decoder_wave.{n}.", cur // 2 if first else cur, tgt)
+        first = False
+        cur = tgt
+    inner, hd = int(dim * 4 * 2 / 3), heads * dim_head
+    for l in range(depth):
+        p = f"decoder_tf.layers.{l}."
+        it.sd[p + "0.gamma"] = torch.ones(dim)
+        it.lin(p + "1.to_q", hd, dim, bias=False)
+        it.lin(p + "1.to_kv", 2 * hd, dim, bias=False)
+        it.lin(p + "1.to_out", dim, hd, bias=False)
+        it.sd[p + "4.gamma"] = torch.ones(dim)
+        it.lin(p + "5.0", 2 * inner, dim)
+        it.lin(p + "5.2.1", inner, inner, k=3)
+        it.lin(p + "5.3", dim, inner)
+    it.sd["decoder_tf.to_pred.0.gamma"] = torch.ones(dim)
+    it.lin("decoder_tf.to_pred.1", dim, dim, bias=False)
+    it.lin("decoder_lm", vocab, dim)
+    return it.sd
+
+
+def eps_step_flops(B: int, T: int) -> float:
+    """Algorithmic FLOPs of one denoising step of the recipe-size eps-predictor (MAC = 2 FLOP)."""
+    return B * T * (283_824_136 + 24_576 * T) + B * 236_982_272
