@@ -81,7 +81,7 @@ def cpu_baseline(sd, cfg, B, T, timesteps, sample_b):
 
     def step(xx, tval):
         t = torch.full((xx.shape[0],), tval, dtype=torch.long)
-        return O.ddim_update(tab, xx, O.eps_forward(sd, ocfg, xx, t, mask[: xx.shape[0]]), t)
+        return O.ddim_update(tab, xx, O.eps_forward(sd, ocfg, xx, t, mask[: xx.shape[0], : xx.shape[1]]), t)
 
     with torch.no_grad():
         step(x[:1, :64], 500)  # warm-up (thread pool, allocator)

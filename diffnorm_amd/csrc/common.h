@@ -68,9 +68,28 @@ __device__ __forceinline__ float4 load4(const void* base, int64_t elem_off, int 
   return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Epilogue transcendentals.  These run once per output element inside MFMA kernels, so they are built
+// from one v_exp_f32 (+ v_rcp_f32) each instead of the libm expansions; absolute error <= ~3e-7, far
+// inside the fp32 budget of 1e-3 (checked against the oracle's exact forms in tests/test_hip_ops.py).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// exact-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = fast_rcp(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanh_sigmoid_gate(float h) { return tanhf(h) * (1.0f / (1.0f + expf(-h))); }
+// tanh(h) * sigmoid(h) from one exponential: q = e^-h, sigmoid = 1/(1+q), tanh = (1-q^2)/(1+q^2).
+// |h| is clamped to 30 first: beyond it the product is constant to 1e-13.
+__device__ __forceinline__ float tanh_sigmoid_gate(float h) {
+  const float hc = fminf(fmaxf(h, -30.0f), 30.0f);
+  const float q = __expf(-hc);
+  const float q2 = q * q;
+  return (1.0f - q2) * fast_rcp((1.0f + q2) * (1.0f + q));
+}
 
 }  // namespace dn
 

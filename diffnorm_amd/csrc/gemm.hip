@@ -2,38 +2,62 @@
 //
 //   out[g][m, n] = epi( sum_{term} sum_k A_term[g][m - shift_term, k] * W_term[g][n, k] )
 //
-// One 256-thread workgroup (4 waves, 2x2) owns a 128(m) x 128(n) output tile; the K loop walks
-// (term, 128-byte K-tile) pairs.  Both operand tiles are staged HBM/L2 -> LDS by LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wave-instruction) into two 32 KiB stages; the LDS image is
-// linear in lane order and the bank-conflict swizzle (16-byte chunk ^= row & 7) is applied on the
-// per-lane SOURCE address and again on the ds_read_b128 address.  Frames before the start of a
-// sequence (t < shift) are sourced from a 128-byte zero page, so activations stay dense [M, ld]
-// with no per-sequence padding.  Weights are the MFMA A operand and activations the B operand, so
-// each lane ends up with 4 consecutive output columns of one row: bias/FiLM vectors load as
-// float4 and stores are 8/16 bytes per lane.
+// A workgroup owns a BM(activation rows) x 128(weight rows) output tile, BM = 256 (8 waves) or 128
+// (4 waves), each wave a 64 x 64 sub-tile; the K loop walks (term, 128-byte K-tile) pairs through an LDS
+// ring (3 stages of 48 KiB at BM = 256).  Both operand tiles are staged L2/HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction); the LDS image is linear in lane order and the
+// bank-conflict swizzle (16-byte chunk ^= row & 7) is applied on the per-lane SOURCE address and again
+// on the ds_read_b128 address.  Frames before the start of a sequence (t < shift) are sourced from a
+// 128-byte zero page, so activations stay dense [M, ld] with no per-sequence padding.  Weights are the
+// MFMA A operand and activations the B operand, so each lane ends up with 4 consecutive output columns
+// of one row: bias/FiLM vectors load as float4 and stores are 8/16 bytes per lane.
 #include "common.h"
 
 namespace dn {
 
 __device__ uint4 g_zero_page[8];  // 128 bytes of zeros (static storage is zero-initialised)
 
-constexpr int BM = 128, BN = 128, ROWB = 128;       // tile rows; bytes of K per row per K-tile
-constexpr int TILE_BYTES = BM * ROWB;               // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // W tile then A tile
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;           // 64 KiB -> 2 workgroups per CU
+constexpr int BN = 128, ROWB = 128;   // weight rows per tile; bytes of K per row per K-tile
+constexpr int W_TILE_BYTES = BN * ROWB;  // 16 KiB
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+// LDS-DMA of 16 B per lane: lane l's bytes land at LDS address `lds_addr` + 16*l (wave-uniform base in M0).
+// Issued through inline asm on purpose: hipcc cannot tell which LDS bytes a global_load_lds writes, so with
+// the builtin it drains vmcnt(0) before the first ds_read of the tile being consumed and the prefetch never
+// overlaps the MFMAs.  The asm form is invisible to its waitcnt pass; completion is ordered by the counted
+// s_waitcnt vmcnt(N) + s_barrier at the top of the K loop (pipe_sync).
+__device__ __forceinline__ void glds16(const void* src, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr)
+      : "memory");
 }
 
-template <typename E, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p) {
+// wait until at most N of this wave's LDS-DMA pieces are outstanding, then workgroup barrier; one asm
+// statement with a memory clobber so no ds_read of the tile is scheduled above it.
+template <int N>
+__device__ __forceinline__ void pipe_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// Tile geometry: BM activation rows x 128 weight rows, BM/32 waves (each 64 x 64), STAGES-deep LDS ring.
+//   BM = 256: 8 waves, 48 KiB per stage, 3 stages (144 KiB, one workgroup per CU): two K-tiles in flight
+//             while the third is consumed -- the K loop is bound by L2/HBM latency, not bandwidth, and this
+//             is what keeps ~96 KiB per CU in flight.
+//   BM = 128: 4 waves, 32 KiB per stage, 2 stages (two workgroups per CU) for problems with few tiles.
+template <typename E, int EPI, int BM, int STAGES>
+__global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
-  constexpr int KT = ROWB / ES;  // K elements per K-tile
+  constexpr int KT = ROWB / ES;                     // K elements per K-tile
+  constexpr int NWAVES = BM / 32;
+  constexpr int WPW = 16 / NWAVES;                  // weight pieces (8 rows each) staged per wave
+  constexpr int PER_STAGE = 4 + WPW;                // LDS-DMA instructions per wave per stage
+  constexpr int STAGE_BYTES = W_TILE_BYTES + BM * ROWB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -41,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p)
   const int wm = wave >> 1, wn = wave & 1;
   const int g = blockIdx.y;
 
-  // XCD-aware tile order: blocks sharing blockIdx % 8 share an L2, give each XCD a contiguous run of
+  // XCD-aware tile order: blocks sharing blockIdx % 8 share an L2; give each XCD a contiguous run of
   // logical tiles with n fastest so the tiles that re-read one A row-panel sit behind one L2.
   const int n_tiles_n = (p.N * (EPI == DN_EPI_GEGLU ? 2 : 1) + BN - 1) / BN;
   int logical;
@@ -53,43 +77,58 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p)
   const int m0 = (logical / n_tiles_n) * BM;
   const int n0 = (logical % n_tiles_n) * BN;  // packed weight row of the tile
 
-  // ---- staging geometry: wave w stages rows [32w, 32w+32) of each tile, 8 rows per instruction ----
+  // ---- staging geometry: wave w stages A rows [32w, 32w+32) and W rows [8*WPW*w, ...), 8 rows per piece ----
   const int srow = lane >> 3;                 // row within the 8-row piece
   const int schunk = (lane & 7) ^ srow;       // swizzled 16-byte chunk this lane fetches
-  int64_t a_off[4];                           // element offset of row m (clamped) in A
-  int a_t[4];                                 // frame index of that row within its sequence
-  int64_t w_off[4];
+  int a_row[4], a_t[4];                       // (clamped) row m of A and its frame index within the sequence
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + wave * 32 + i * 8 + srow;
     m = m < p.M ? m : p.M - 1;
-    a_off[i] = (int64_t)m;
+    a_row[i] = m;
     a_t[i] = m % p.T;
-    w_off[i] = (int64_t)(n0 + wave * 32 + i * 8 + srow) * p.K;
   }
   const int ktiles_per_term = p.K / KT;
   const int nkt = p.n_terms * ktiles_per_term;
   const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
 
-  auto stage = [&](int kt, int buf) {
-    const int term = kt / ktiles_per_term;
-    const int kk = kt - term * ktiles_per_term;
+  // Per-lane source pointers of the term being staged; they advance by one K-tile (128 B) per stage and
+  // are rebuilt only at a term boundary, so the steady-state loop carries a few pointer adds, no multiplies.
+  const char* a_ptr[4];
+  const char* w_ptr[WPW];
+  int a_inc[4];
+  int s_term = 0, s_kk = 0;
+  auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
     const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
-    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES;
-    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES;
-    const int kbyte = kk * ROWB + schunk * 16;
-    char* wbase = smem + buf * STAGE_BYTES + wave * 4096;
-    char* abase = wbase + TILE_BYTES;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16(W + w_off[i] * ES + kbyte, wbase + i * 1024);
+      const bool valid = a_t[i] >= shift;  // frames before the sequence start read the zero page
+      a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * tm.lda * ES : zero_src;
+      a_inc[i] = valid ? ROWB : 0;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char* src = A + ((a_off[i] - shift) * tm.lda) * ES + kbyte;
-      src = a_t[i] >= shift ? src : zero_src;
-      glds16(src, abase + i * 1024);
+    for (int i = 0; i < WPW; ++i) w_ptr[i] = W + (int64_t)(n0 + (wave * WPW + i) * 8 + srow) * p.K * ES;
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
+  auto stage = [&](int slot) {
+    const uint32_t sbase = lds_base + slot * STAGE_BYTES;
+    const uint32_t wbase = sbase + wave * (WPW * 1024);
+    const uint32_t abase = sbase + W_TILE_BYTES + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) glds16(w_ptr[i], wbase + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_ptr[i], abase + i * 1024);
+    if (++s_kk == ktiles_per_term) {
+      s_kk = 0;
+      if (++s_term < p.n_terms) setup_term(s_term);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) w_ptr[i] += ROWB;
     }
   };
 
@@ -102,26 +141,83 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p)
   // fragment read addresses: row (l & 15) of a 16-row sub-tile, chunk ks*4 + (l >> 4), swizzled by row & 7
   const int frow = lane & 15, fq = lane >> 4;
   const int w_rd = (wn * 64 + frow) * ROWB;
-  const int a_rd = TILE_BYTES + (wm * 64 + frow) * ROWB;
+  const int a_rd = W_TILE_BYTES + (wm * 64 + frow) * ROWB;
   const int sw = frow & 7;
 
-  stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // (vmcnt(0) + barrier): tile kt landed for everyone, tile kt-1 fully consumed
-    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+  uint4 wf[2][4], af[2][4];  // fragments of one K-tile: [k-step][16-row sub-tile]
+  auto load_frags = [&](int slot) {
+    const char* sb = smem + slot * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + fq) ^ sw) << 4;
-      uint4 wf[4], af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB + coff);
+      for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB + coff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB + coff);
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB + coff);
+    }
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[nt], af[mt]);
+        for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[ks][nt], af[ks][mt]);
+  };
+
+  setup_term(0);
+  if constexpr (STAGES == 3) {
+    // Staggered two-group schedule (8 waves = group 0: waves 0-3, group 1: waves 4-7; waves w and w+4
+    // share a SIMD).  Every K-tile is two barrier-separated segments per wave: L = issue the LDS-DMA of
+    // tile k+2 and pull tile k's fragments LDS -> registers, C = 32 MFMAs from registers.  Group 1 runs one
+    // segment behind group 0, so on every SIMD one wave is in its matrix segment while its partner is in
+    // its memory segment.  Segment s = 2k / 2k+1 is (L_k, C_k) for group 0 and s = 2k+1 / 2k+2 for group 1.
+    //   RAW: tile k+1 must be in LDS before segment 2k+2; every wave retires its own pieces with a counted
+    //        vmcnt ahead of the barrier that ends odd segment 2k+1 (only tile k+2's 6 pieces stay in flight).
+    //   WAR: tile k+2 overwrites the slot of tile k-1, whose last reads (group 1, segment 2k-1) finished
+    //        before the barrier that opens segment 2k, the earliest segment that issues tile k+2.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2;
+    stage(0);
+    if (nkt > 1) stage(1);
+    if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();  // tile 0 landed
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) pipe_sync<63>();  // the stagger: group 1 sits out segment 0 (vmcnt(63) = no wait)
+    int slot = 0, fill = 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // ---- L segment
+      if (!(p.pad_ & 4)) load_frags(slot);  // LDS reads first: they drain while the TA chews the DMA addresses
+      if (kt + 2 < nkt && !(p.pad_ & 1)) stage(fill);
+      if (late) {  // this is an odd segment for group 1
+        if (kt + 2 < nkt) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+      } else {
+        pipe_sync<63>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C segment
+      __builtin_amdgcn_s_setprio(1);
+      if (!(p.pad_ & 2)) mma_all();
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (late) {
+        pipe_sync<63>();
+      } else {  // odd segment for group 0
+        if (kt + 2 < nkt) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot == 2 ? 0 : slot + 1;
+      fill = fill == 2 ? 0 : fill + 1;
+    }
+    if (!late) pipe_sync<63>();  // group 0 matches group 1's extra barrier
+  } else {
+    // Two-stage loop for the 4-wave tile (two workgroups per CU overlap each other): one barrier per K-tile.
+    stage(0);
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      pipe_sync<0>();  // tile kt landed for everyone, tile kt-1 fully consumed
+      if (kt + 1 < nkt) stage(slot ^ 1);
+      load_frags(slot);
+      mma_all();
+      slot ^= 1;
     }
   }
 
@@ -184,19 +280,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const DnGemmParams p)
   }
 }
 
-template <typename E, int EPI>
-static int launch(const DnGemmParams& p, hipStream_t s) {
+template <typename E, int EPI, int BM, int STAGES>
+static int launch_tile(const DnGemmParams& p, hipStream_t s) {
+  constexpr int lds = STAGES * (W_TILE_BYTES + BM * ROWB);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<E, EPI>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<E, EPI, BM, STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + BM - 1) / BM) * ((np + BN - 1) / BN), p.groups);
-  hipLaunchKernelGGL((conv_gemm_kernel<E, EPI>), grid, dim3(256), GEMM_LDS, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<E, EPI, BM, STAGES>), grid, dim3(BM * 2), lds, s, p);
   DN_CHECK_LAUNCH("dn_conv_gemm");
   return DN_OK;
+}
+
+template <typename E, int EPI>
+static int launch(const DnGemmParams& p, hipStream_t s) {
+  // 256-row tiles once they still give every CU a workgroup; 128-row tiles for small problems
+  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  const long tiles256 = (long)((p.M + 255) / 256) * ((np + BN - 1) / BN) * p.groups;
+  if (tiles256 >= 192) return launch_tile<E, EPI, 256, 3>(p, s);
+  return launch_tile<E, EPI, 128, 2>(p, s);
 }
 
 template <typename E>

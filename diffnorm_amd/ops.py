@@ -4,6 +4,7 @@ Used by the host-side mirror of the reference modules and by the parity tests; t
 CUDA tensors used as plain device buffers.
 """
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -67,6 +68,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
     if pos_table is not None:
         p.pos_table, p.pos_ld = pos_table.data_ptr(), pos_table.shape[-1]
         p.lengths = lengths.data_ptr()
+    p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0"))  # ablation switches for tools/gemm_bench.py only
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out
 

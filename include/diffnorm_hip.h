@@ -89,7 +89,8 @@ typedef struct {
   int64_t gb_gstride;
   const float* pos_table; /* POSEMB: fp32 [T+1, pos_ld] sinusoidal table, row 0 = zeros             */
   int32_t pos_ld;
-  int32_t pad_;
+  int32_t pad_;        /* profiling-only ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip LDS reads
+                          inside the K loop); 0 in every product call                               */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
 } DnGemmParams;
 

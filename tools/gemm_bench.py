@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Times the contraction shapes of one denoising step ([B=32,T=512]) through the C ABI (HIP events)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffnorm_amd import _lib, ops, packing
+
+dev = torch.device("cuda:0")
+B, T = 32, 512
+M = B * T
+dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def mk(rows, cols):
+    return (torch.randn(rows, cols, device=dev) * 0.5).to(dt)
+
+
+rows = []
+def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
+    Kp, Np = packing.padk(K), packing.padk(N)
+    a = mk(M, Kp) if groups == 1 else (torch.randn(groups, M, Kp, device=dev) * 0.5).to(dt)
+    nrows = packing.padn(N) if epi != _lib.EPI_GEGLU else 2 * Np
+    w = [(torch.randn(*( (groups,) if groups > 1 else ()), nrows, Kp, device=dev) * 0.02).to(dt) for _ in range(taps)]
+    out_dt = torch.float32 if epi == _lib.EPI_RESADD else dt
+    out = torch.empty(*((groups,) if groups > 1 else ()), M, Np, device=dev, dtype=out_dt)
+    bias = torch.zeros(*((groups,) if groups > 1 else ()), nrows, device=dev)
+    kw = {}
+    if epi == _lib.EPI_RESADD:
+        kw["res"] = out
+    if epi == _lib.EPI_FILM_GATE:
+        kw["res"] = torch.zeros_like(out)
+        kw["gamma_beta"] = torch.ones(1, groups * 2 * Np, device=dev)
+        kw["gb_shared"] = True
+        kw["gb_half"] = Np
+        kw["shift_by_group"] = True
+    terms = [(a, w[j], taps - 1 - j) for j in range(taps)]
+    sec = timeit(lambda: ops.conv_gemm(terms, out, T, Np, bias=bias, epilogue=epi, groups=groups, **kw))
+    flops = 2.0 * M * K * taps * N * groups * (2 if epi == _lib.EPI_GEGLU else 1)
+    rows.append((name, count, sec * 1e6, flops / sec / 1e12, count * sec * 1e3))
+    print(f"{name:28s} x{count:2d}  {sec*1e6:8.1f} us  {flops/sec/1e12:7.1f} TF/s   {count*sec*1e3:6.3f} ms/step", flush=True)
+
+only = sys.argv[2] if len(sys.argv) > 2 else None
+if only == "ffn":
+    shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
+    sys.exit(0)
+shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
+shape("wn_dilated k3 512 g8", 512, 512, taps=3, groups=8, epi=_lib.EPI_FILM_GATE, count=4)
+shape("wn_res 1x1 512 g8", 512, 512, groups=8, count=4)
+shape("ffn_in GEGLU 512->2x1365", 512, 1365, epi=_lib.EPI_GEGLU, count=12)
+shape("ffn_out 1365->512 resadd", 1365, 512, epi=_lib.EPI_RESADD, count=12)
+shape("qkv 512->1536", 512, 1536, count=12)
+shape("attn_out 512->512 resadd", 512, 512, epi=_lib.EPI_RESADD, count=12)
+shape("wn_init k3 512", 512, 512, taps=3, count=1)
+shape("linear 512->512", 512, 512, count=3)
+print("total GEMM ms/step: %.3f" % sum(r[4] for r in rows))
