@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on host threads of the CPU baseline (host share of one GPU)")
     return ap.parse_args()
 
 
@@ -63,14 +64,32 @@ def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters, 2.0 * M * (3 * inner) * inner
 
 
-def cpu_baseline(sd, cfg, B, T, timesteps, sample_b):
+def usable_cores(cap):
+    """Threads the CPU leg may use: affinity mask, cgroup CPU quota, and the per-GPU host share (`cap`)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sd, cfg, B, T, timesteps, sample_b, max_threads):
     """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/golden) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
 
     import diffnorm_oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores(max_threads)
     torch.set_num_threads(cores)
     ocfg = O.EpsConfig(dim=cfg.dim, latent_dim=cfg.latent_dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head,
                        wavenet_layers=cfg.wavenet_layers, wavenet_stacks=cfg.wavenet_stacks, dim_cond_mult=cfg.dim_cond_mult)
@@ -175,7 +194,7 @@ def main():
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "traffic": None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B))
+            result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B), args.cpu_threads)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     if world > 1:
