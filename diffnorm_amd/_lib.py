@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffnorm_hip.so")
 DN_F32, DN_BF16 = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB = range(6)
 DN_MAX_TERMS = 8
+TAG_FFN_CONV, TAG_WN_DILATED = 1, 2
 
 
 class DiffNormHipError(RuntimeError):
@@ -59,6 +60,8 @@ class VaeConfig(C.Structure):
 _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 SYMBOLS = {
     "dn_conv_gemm": (C.c_int, [C.POINTER(GemmParams), _vp]),
+    "dn_profile_start": (C.c_int, [_i32, _i32]),
+    "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),
     "dn_rmsnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "dn_time_cond": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),

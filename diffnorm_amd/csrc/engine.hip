@@ -95,6 +95,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
         p.gamma_beta = gb + (size_t)st * L * 2 * cp; p.gb_ld = gb_ld; p.gb_half = cp; p.gb_gstride = 2 * cp;
       }
       p.out = out_s; p.ldo = cp; p.out_gstride = plane;
+      p.pad_ = DN_TAG_WN_DILATED << 8;
       DN_TRY(dn_conv_gemm(&p, s));
     }
   }
@@ -175,6 +176,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
         p.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
       }
       p.bias = w.ffconv_b + (size_t)l * ip; p.out = tb.fc; p.ldo = ip;
+      p.pad_ = DN_TAG_FFN_CONV << 8;
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {  // Linear(inner -> D) + residual (:902,704)

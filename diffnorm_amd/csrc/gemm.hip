@@ -280,6 +280,14 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   }
 }
 
+// In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
+// around every dn_conv_gemm whose tag (bits 8..15 of DnGemmParams.pad_) matches.  Eager launches only.
+struct LaunchProfile {
+  int tag = 0, cap = 0, n = 0;
+  hipEvent_t* ev = nullptr;  // 2*cap events
+};
+static LaunchProfile g_prof;
+
 template <typename E, int EPI, int BM, int STAGES>
 static int launch_tile(const DnGemmParams& p, hipStream_t s) {
   constexpr int lds = STAGES * (W_TILE_BYTES + BM * ROWB);
@@ -291,7 +299,10 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
   }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + BM - 1) / BM) * ((np + BN - 1) / BN), p.groups);
+  const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
   hipLaunchKernelGGL((conv_gemm_kernel<E, EPI, BM, STAGES>), grid, dim3(BM * 2), lds, s, p);
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm");
   return DN_OK;
 }
@@ -347,4 +358,34 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   if (p.epilogue == DN_EPI_FILM_GATE && p.gamma_beta) DN_CHECK_ARG(p.gb_half % 4 == 0 && p.gb_ld % 4 == 0, "dn_conv_gemm: gamma_beta strides must be multiples of 4");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return p.dtype == DN_BF16 ? dn::dispatch_epi<dn::BF16>(p, s) : dn::dispatch_epi<dn::F32>(p, s);
+}
+
+extern "C" int dn_profile_start(int32_t tag, int32_t max_launches) {
+  DN_CHECK_ARG(tag > 0 && tag < 256 && max_launches > 0 && max_launches <= 4096, "dn_profile_start: bad arguments");
+  DN_CHECK_ARG(dn::g_prof.cap == 0, "dn_profile_start: a profile is already open");
+  dn::g_prof.ev = new hipEvent_t[2 * max_launches];
+  for (int i = 0; i < 2 * max_launches; ++i)
+    if (hipEventCreate(&dn::g_prof.ev[i]) != hipSuccess) {
+      dn_set_error("dn_profile_start: hipEventCreate failed");
+      return DN_ELAUNCH;
+    }
+  dn::g_prof.tag = tag; dn::g_prof.n = 0; dn::g_prof.cap = max_launches;
+  return DN_OK;
+}
+
+extern "C" int dn_profile_stop(float* avg_ms, int32_t* n_launches) {
+  DN_CHECK_ARG(dn::g_prof.cap > 0, "dn_profile_stop: no open profile");
+  double tot = 0;
+  for (int i = 0; i < dn::g_prof.n; ++i) {
+    float ms = 0;
+    (void)hipEventSynchronize(dn::g_prof.ev[2 * i + 1]);
+    (void)hipEventElapsedTime(&ms, dn::g_prof.ev[2 * i], dn::g_prof.ev[2 * i + 1]);
+    tot += ms;
+  }
+  if (avg_ms) *avg_ms = dn::g_prof.n ? (float)(tot / dn::g_prof.n) : 0.f;
+  if (n_launches) *n_launches = dn::g_prof.n;
+  for (int i = 0; i < 2 * dn::g_prof.cap; ++i) (void)hipEventDestroy(dn::g_prof.ev[i]);
+  delete[] dn::g_prof.ev;
+  dn::g_prof = dn::LaunchProfile();
+  return DN_OK;
 }

@@ -1,0 +1,152 @@
+"""`--task speech_decoder` (reference fairseq/tasks/speech_decoder_task.py:33-259): unit dictionary, model /
+criterion construction and the train / valid step contract around the HIP-backed models.
+
+Dataset readers (npy feature manifests + unit TSVs) are scope row f1 and not built; `load_dataset` serves the
+synthetic (feat, unit) pairs the BASELINE configs use.  `train_step` runs the forward (the loss dict is real);
+backward kernels are scope row f2, so it raises unless `ignore_grad` is set.
+"""
+import torch
+
+from ..registry import MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY, CRITERION_REGISTRY, FairseqTask, register_task
+
+
+class UnitDictionary:
+    """fairseq Dictionary for discrete units: 4 specials (<s>, <pad>, </s>, <unk>) + units "0".."N-1"
+    (reference fairseq/data/dictionary.py:20-40, speech_decoder_task.py:132-155) -> len = N + 4, unit u -> index u + 4."""
+
+    def __init__(self, n_units: int):
+        self.symbols = ["<s>", "<pad>", "</s>", "<unk>"] + [str(i) for i in range(n_units)]
+        self.indices = {s: i for i, s in enumerate(self.symbols)}
+        self.bos_index, self.pad_index, self.eos_index, self.unk_index = 0, 1, 2, 3
+
+    def __len__(self):
+        return len(self.symbols)
+
+    def pad(self):
+        return self.pad_index
+
+    def unk(self):
+        return self.unk_index
+
+    def eos(self):
+        return self.eos_index
+
+    def index(self, sym):
+        return self.indices.get(sym, self.unk_index)
+
+    def string(self, tensor):
+        return " ".join(self.symbols[int(i)] for i in tensor)
+
+
+class SyntheticReprUnitDataset(torch.utils.data.Dataset):
+    """Synthetic stand-in for ReprToReprUnitDataset producing the criterion's sample dict
+    (reference fairseq/data/audio/repr_to_repr_unit_dataset.py:239-258): N(0,1) features, units U{4..1003}, 0 = pad."""
+
+    def __init__(self, n, min_len, max_len, dim=768, vocab=1004, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.lens = torch.randint(min_len, max_len + 1, (n,), generator=g)
+        self.dim, self.vocab, self.seed = dim, vocab, seed
+
+    def __len__(self):
+        return len(self.lens)
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        T = int(self.lens[i])
+        return {"id": i, "feat": torch.randn(T, self.dim, generator=g), "unit": torch.randint(4, self.vocab, (T,), generator=g)}
+
+    def collater(self, items):
+        B, T = len(items), max(it["feat"].shape[0] for it in items)
+        feat = torch.zeros(B, T, self.dim)
+        unit = torch.zeros(B, T, dtype=torch.long)
+        lens = torch.tensor([it["feat"].shape[0] for it in items])
+        for b, it in enumerate(items):
+            feat[b, : lens[b]], unit[b, : lens[b]] = it["feat"], it["unit"]
+        return {"id": torch.tensor([it["id"] for it in items]),
+                "net_input": {"src_tokens": feat, "src_lengths": lens},
+                "target": feat, "target_unit": unit, "target_lengths": lens,
+                "reduce_target": feat, "reduce_target_unit": unit, "reduce_target_lengths": lens,
+                "ntokens": int(lens.sum()), "nsentences": B}
+
+
+class _SpeechTaskBase(FairseqTask):
+    @classmethod
+    def add_args(cls, parser):
+        parser.add_argument("data", help="manifest root path")
+        parser.add_argument("--config-yaml", type=str, default="config.yaml")
+        parser.add_argument("--max-source-positions", default=6000, type=int)
+        parser.add_argument("--max-target-positions", default=1024, type=int)
+        parser.add_argument("--target-is-code", action="store_true")
+        parser.add_argument("--target-code-size", type=int, default=None, help="# discrete units")
+        parser.add_argument("--save-audio", action="store_true")
+        parser.add_argument("--n-frames-per-step", type=int, default=1)
+        parser.add_argument("--eval-inference", action="store_true")
+        parser.add_argument("--eval-args", type=str, default="{}")
+        parser.add_argument("--eos-prob-threshold", type=float, default=0.5)
+        parser.add_argument("--mcd-normalize-type", type=str, default="targ")
+        parser.add_argument("--vocoder", type=str, default="griffin_lim")
+        parser.add_argument("--spec-bwd-max-iter", type=int, default=8)
+        parser.add_argument("--infer-target-lang", type=str, default="")
+        parser.add_argument("--dummy-config", type=str)
+        parser.add_argument("--vocoder-config", type=str)
+        parser.add_argument("--tgt-feat-dir", type=str)
+        parser.add_argument("--src-feat-dir", type=str)
+
+    def __init__(self, args, tgt_dict):
+        super().__init__(args)
+        self.args = args
+        self.tgt_dict = tgt_dict
+
+    @classmethod
+    def setup_task(cls, args, **kwargs):
+        n_units = getattr(args, "target_code_size", None) or 1000
+        return cls(args, UnitDictionary(n_units))
+
+    @property
+    def target_dictionary(self):
+        return self.tgt_dict
+
+    @property
+    def source_dictionary(self):
+        return None
+
+    def max_positions(self):
+        return getattr(self.args, "max_source_positions", 6000), getattr(self.args, "max_target_positions", 1024)
+
+    def load_dataset(self, split, epoch=1, combine=False, **kwargs):
+        n = kwargs.get("n", 64)
+        self.datasets[split] = SyntheticReprUnitDataset(n, kwargs.get("min_len", 64), kwargs.get("max_len", 512),
+                                                        vocab=len(self.tgt_dict), seed=hash(split) % 1000)
+        return self.datasets[split]
+
+    def build_model(self, args, from_checkpoint=False):
+        arch = args.arch
+        ARCH_CONFIG_REGISTRY[arch](args)
+        return ARCH_MODEL_REGISTRY[arch].build_model(args, self)
+
+    def build_criterion(self, args):
+        return CRITERION_REGISTRY[args.criterion](self)
+
+    def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+        model.train()
+        loss, sample_size, logging_output = criterion(model, sample)
+        if not ignore_grad:
+            raise NotImplementedError("backward kernels for the HIP path are scope row f2 (not built); "
+                                      "train_step supports ignore_grad=True (forward + logging) only")
+        return loss * 0, sample_size, logging_output
+
+    def valid_step(self, sample, model, criterion):
+        model.eval()
+        with torch.no_grad():
+            return criterion(model, sample)
+
+    def valid_step_with_inference(self, sample, model, generator):
+        pass  # as upstream (speech_decoder_task.py:241-242)
+
+    def optimizer_step(self, optimizer, model, update_num):
+        optimizer.step()
+
+
+@register_task("speech_decoder")
+class SpeechDecoderTask(_SpeechTaskBase):
+    pass

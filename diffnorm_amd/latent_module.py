@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's hot-path modules (same names, constructor arguments, method
+signatures, return values and state-dict keys as fairseq/models/text_to_speech/latent_module.py upstream),
+computing through libdiffnorm_hip.so.
+
+The classes are `torch.nn.Module`s only so that they own `Parameter`s under the reference's state-dict
+keys and plug into fairseq unchanged; every `forward` dispatches to the C-ABI engine.
+There is no CPU path: calling them without a HIP device raises `DiffNormHipError`.
+
+Random draws follow the reference: the VAE posterior noise comes from torch's *CPU* generator with
+shape [B, z, T] (reference distributions.py:38-40), the DDIM start noise from the device generator
+(latent_module.py:1409); both can be injected for parity runs.
+"""
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, engine, ops, scheduler, synthetic
+from .scheduler import DDPMScheduler  # re-exported under its reference name  # noqa: F401
+
+
+def exists(x):
+    return x is not None
+
+
+def lengths_to_mask(lengths: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
+    """`arange < len` (reference fairseq/data/data_utils.py:542-552)."""
+    max_len = int(lengths.max()) if max_len is None else max_len
+    return torch.arange(max_len, device=lengths.device).view(1, -1) < lengths.view(-1, 1)
+
+
+def _mask_to_lengths(mask: torch.Tensor) -> torch.Tensor:
+    """The path only ever sees right-padded masks (lengths_to_mask); the kernels take lengths."""
+    lengths = mask.sum(dim=1)
+    if not torch.equal(mask, lengths_to_mask(lengths, mask.shape[1])):
+        raise ValueError("input_mask must be a right-padded mask (arange < length)")
+    return lengths
+
+
+def label_smoothed_nll_loss(lprobs, target, epsilon, ignore_index=None, reduce=True):
+    """reference fairseq/criterions/label_smoothed_cross_entropy.py:34-51 (device-side reductions)."""
+    if target.dim() == lprobs.dim() - 1:
+        target = target.unsqueeze(-1)
+    nll = -lprobs.gather(dim=-1, index=target)
+    smooth = -lprobs.sum(dim=-1, keepdim=True)
+    if ignore_index is not None:
+        pad = target.eq(ignore_index)
+        nll = nll.masked_fill(pad, 0.0)
+        smooth = smooth.masked_fill(pad, 0.0)
+    else:
+        nll, smooth = nll.squeeze(-1), smooth.squeeze(-1)
+    if reduce:
+        nll, smooth = nll.sum(), smooth.sum()
+    eps_i = epsilon / (lprobs.size(-1) - 1)
+    return (1.0 - epsilon - eps_i) * nll + eps_i * smooth, nll
+
+
+class _ParamTree(nn.Module):
+    """Owns parameters under dotted state-dict keys by growing anonymous sub-modules on demand."""
+
+    def _attach(self, key: str, tensor: torch.Tensor, buffer: bool = False):
+        node = self
+        parts = key.split(".")
+        for name in parts[:-1]:
+            if name not in node._modules:
+                node.add_module(name, nn.Module())
+            node = node._modules[name]
+        if buffer:
+            node.register_buffer(parts[-1], tensor)
+        else:
+            node.register_parameter(parts[-1], nn.Parameter(tensor))
+
+    def _adopt(self, tensors: Dict[str, torch.Tensor]):
+        for k, v in tensors.items():
+            self._attach(k, v)
+        self._engine = None
+        self._engine_key = None
+
+    def _state_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class Model(_ParamTree):
+    """eps-predictor (reference latent_module.py:709-876): WaveNet (FiLM time conditioning) -> sinusoidal
+    positions -> time-conditioned transformer -> Linear.  Same constructor keywords as upstream."""
+
+    def __init__(self, dim, latent_dim, *, depth=12, dim_head=64, heads=8, ff_mult=4, wavenet_layers=8, wavenet_stacks=4,
+                 dim_cond_mult=4, use_flash_attn=False, dim_prompt=None, num_latents_m=64, resampler_depth=2,
+                 cond_drop_prob=0., condition_on_prompt=False, dtype="bf16", seed=0):
+        super().__init__()
+        if condition_on_prompt:
+            raise NotImplementedError("prompt conditioning (use_cond=True) is row f3 of the scope table, not built yet")
+        if ff_mult != 4:
+            raise NotImplementedError("the engine packs ff_mult = 4 (the only value the recipe uses)")
+        self.dim, self.latent_dim = dim, latent_dim
+        self.cond_drop_prob = cond_drop_prob
+        self.condition_on_prompt = False
+        self.cfg = synthetic.eps_config(dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult)
+        self.arith = dtype
+        self._adopt(synthetic.random_eps_state_dict(self.cfg, seed))
+        self._attach("pos_embed._float_tensor", torch.zeros(1), buffer=True)  # key present upstream (:774-779)
+
+    def engine(self) -> engine.EpsEngine:
+        key = self._state_key()
+        if self._engine is None or self._engine_key != key:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items() if not k.startswith("pos_embed")}
+            self._engine = engine.EpsEngine(sd, self.cfg, dtype=self.arith, device=self.device)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x, times, prompt=None, prompt_mask=None, input_mask=None, cond=None, cond_drop_prob=None):
+        """x [B,T,latent], times [B] (raw integer steps), input_mask [B,T] bool -> eps_hat [B,T,latent]."""
+        if input_mask is None:
+            input_mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
+        lengths = _mask_to_lengths(input_mask)
+        shared = bool((times == times[0]).all())
+        return self.engine().forward(x, times, lengths, shared_t=shared)
+
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
+        return self.forward(*args, **kwargs)  # no prompt branch: guidance is the identity (:813-826)
+
+
+class SpeechVAEEncoderDecoder(_ParamTree):
+    """reference latent_module.py:1035-1142 (WaveNet encoder -> diagonal Gaussian -> WaveNet + transformer decoder
+    -> 1004-way unit logits).  `latent_dim` is the upstream constructor flag (16 / 32 / 128)."""
+
+    def __init__(self, dim=768, latent_dim=16, dtype="bf16", seed=1):
+        super().__init__()
+        self.dim, self.latent_dim = dim, latent_dim
+        self.arith = dtype
+        self._adopt(synthetic.random_vae_state_dict(dim, latent_dim, seed=seed))
+
+    def max_positions(self):
+        return None
+
+    def engine(self) -> engine.VaeEngine:
+        key = self._state_key()
+        if self._engine is None or self._engine_key != key:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            self._engine = engine.VaeEngine(sd, dim=self.dim, latent_dim=self.latent_dim, dtype=self.arith, device=self.device)
+            self._engine_key = key
+        return self._engine
+
+    def _posterior_noise(self, B, T, noise):
+        e = self.engine()
+        if noise is None:  # CPU generator, [B, z, T] like upstream, then to the device
+            noise = torch.randn(B, e.z, T).transpose(1, 2)
+        return noise
+
+    @torch.no_grad()
+    def encode_feature(self, feature, noise=None):
+        """feature [B,T,dim] -> posterior sample.  Upstream returns [B,z,T]; so does this (a transposed view)."""
+        e = self.engine()
+        B, T, _ = feature.shape
+        z = e.sample_posterior(e.encode_params(feature), self._posterior_noise(B, T, noise))
+        return z.transpose(1, 2)
+
+    def decode_feature(self, latent, mask):
+        """latent [B,T,z], mask [B,T] -> (decoded_feature [B,T,dim], lm_result [B,T,1004])."""
+        recon, logits, _ = self.engine().decode(latent, _mask_to_lengths(mask), want_units=False)
+        return recon, logits
+
+    def forward(self, input_feature, input_token, mask, noise=None):
+        """-> (mse_loss, lm_result, kl_loss) (:1118-1142); forward only (backward kernels: scope row f2)."""
+        e = self.engine()
+        B, T, _ = input_feature.shape
+        lengths = _mask_to_lengths(mask)
+        params = e.encode_params(input_feature)
+        z, kl = e.sample_posterior(params, self._posterior_noise(B, T, noise), lengths, want_kl=True)
+        decoded, logits, _ = e.decode(z, lengths, want_units=False)
+        sel = mask.to(decoded.device).unsqueeze(2).expand(-1, -1, decoded.shape[2])
+        mse = torch.mean((decoded[sel] - input_feature.to(decoded.device)[sel]) ** 2)
+        return mse, logits, kl.mean()
+
+
+class LatentDiscreteModel(nn.Module):
+    """reference latent_module.py:1300-1613.  `speech_decoder` is the fairseq model whose `.encoder` is the VAE."""
+
+    def __init__(self, speech_decoder, dim, latent_dim, target_sample_hz=None, timesteps=1000, use_ddim=True,
+                 noise_schedule='sigmoid', objective='v', schedule_kwargs: dict = dict(), time_difference=0.,
+                 min_snr_loss_weight=True, min_snr_gamma=5, train_prob_self_cond=0.9, scale=1., use_cond=False,
+                 multitask=True, dtype="bf16"):
+        super().__init__()
+        assert objective in {'x0', 'eps', 'v'}, 'objective must be either predict x0 or noise'
+        self.speech_decoder = speech_decoder.encoder
+        self.use_cond, self.multitask = use_cond, multitask
+        self.model = Model(dim, latent_dim, condition_on_prompt=use_cond, dtype=dtype)
+        self.scheduler = DDPMScheduler(timesteps, scale=scale)
+        self.dim, self.timesteps, self.objective = dim, timesteps, objective
+        self.min_snr_loss_weight, self.min_snr_gamma = min_snr_loss_weight, min_snr_gamma
+        self._coef = None
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def max_positions(self):
+        return None
+
+    def _tables(self):
+        if self._coef is None or self._coef[0].device != self.device:
+            s = self.scheduler
+            self._coef = (s.ddim_coef_table(self.device), s.f32("sqrt_alphas_cumprod", self.device),
+                          s.f32("sqrt_one_minus_alphas_cumprod", self.device))
+        return self._coef
+
+    @torch.no_grad()
+    def ddim_sample(self, tgt_feature, prompt=None, prompt_mask=None, input_mask=None, cond_scale=1., ref_units=None,
+                    start_step=50, post_noise=None, start_noise=None, use_graph=True):
+        """-> (list of unit tensors, match, total, recon_feature), as upstream (:1385-1471)."""
+        dev = self.device
+        coef, sa, s1 = self._tables()
+        B, T, _ = tgt_feature.shape
+        if input_mask is None:
+            input_mask = torch.ones(B, T, dtype=torch.bool, device=dev)
+        input_mask = input_mask.to(dev)
+        lengths = _mask_to_lengths(input_mask).to(torch.int32)
+        z = self.speech_decoder.encode_feature(tgt_feature, noise=post_noise).transpose(1, 2).contiguous()
+        if start_noise is None:
+            start_noise = torch.randn(z.shape, device=dev)
+        t_start = torch.full((B,), start_step, dtype=torch.int32, device=dev)
+        x = ops.q_sample(z, start_noise.to(dev, torch.float32).contiguous(), sa, s1, t_start, T)  # (:1405-1409)
+        self.model.engine().ddim_loop(x, lengths, start_step, coef, use_graph=use_graph)        # (:1411-1445)
+        recon, _, units = self.speech_decoder.engine().decode(x, lengths, want_logits=False)     # (:1448-1451)
+        pred_units = units.long()
+        match = total = 0
+        if ref_units is not None:
+            match = (pred_units[input_mask] == ref_units.to(dev)[input_mask]).sum().item()
+        total = int(input_mask.sum().item())
+        lens = lengths.tolist()
+        out_tokens = [pred_units[i, : lens[i]] for i in range(B)]
+        return out_tokens, match, total, recon
+
+    def forward(self, audio, audio_units, src_feature=None, src_mask=None, tgt_mask=None, prompt=None, pitch=None,
+                times=None, post_noise=None, jitter_noise=None, true_noise=None, *args, **kwargs):
+        """Training loss dict (:1514-1613), forward only.  t, the posterior noise, the beta_0 jitter and the target
+        noise can be injected (parity runs); otherwise they are drawn like upstream."""
+        dev = self.device
+        _, sa_t, s1_t = self._tables()
+        B, T, _ = audio.shape
+        tgt_mask = tgt_mask.to(dev)
+        lengths = _mask_to_lengths(tgt_mask).to(torch.int32)
+        if times is None:
+            times = torch.randint(1, self.timesteps, (B,), device=dev)  # never 0 (:1528)
+        times = times.to(dev)
+        t32 = times.to(torch.int32)
+        z = self.speech_decoder.encode_feature(audio, noise=post_noise).transpose(1, 2).contiguous()
+        jitter_noise = torch.randn(z.shape, device=dev) if jitter_noise is None else jitter_noise.to(dev)
+        true_noise = torch.randn(z.shape, device=dev) if true_noise is None else true_noise.to(dev, torch.float32).contiguous()
+        beta0 = float(self.scheduler.f32("betas")[0])
+        x1 = (z + jitter_noise * beta0).contiguous()  # beta_0, not sqrt(beta_0) (:1534-1536)
+        xt = ops.q_sample(x1, true_noise, sa_t, s1_t, t32, T)
+        eps = self.model(xt, times, input_mask=tgt_mask, cond_drop_prob=0.1)
+        snr = self.scheduler.get_snr(times)
+        weight = snr.clamp(max=5.0) / snr
+        mse = ((eps - true_noise) ** 2).masked_fill(~tgt_mask.unsqueeze(2), 0.0).flatten(1).mean(dim=1)
+        noise_mse = (mse * weight).mean()
+        sa = self.scheduler.get_sqrt_alpha_cum(times, xt.shape)
+        s1 = self.scheduler.get_sqrt_one_minus_alpha_cum(times, xt.shape)
+        x1_hat = ((xt - s1 * eps) / sa.clamp(min=1e-10)).contiguous()
+        dec, logits = self.speech_decoder.decode_feature(x1_hat, tgt_mask)
+        sel = tgt_mask.unsqueeze(2).expand(-1, -1, dec.shape[2])
+        recon_mse = torch.mean((dec[sel] - audio.to(dev)[sel]) ** 2)
+        lprobs = torch.log_softmax(logits, dim=-1).view(-1, logits.size(-1))
+        unit = audio_units.to(dev).view(-1)
+        keep = unit.ne(0)
+        acc = torch.sum(lprobs.argmax(1).masked_select(keep).eq(unit.masked_select(keep))) / torch.sum(keep)
+        smooth, _ = label_smoothed_nll_loss(lprobs, unit, 0.1, ignore_index=0, reduce=True)
+        smooth = smooth / keep.sum()
+        recon = 50 * recon_mse + smooth
+        total = noise_mse + recon / self.timesteps if self.multitask else noise_mse
+        return {"total_loss": total, "nll_loss": smooth, "recon_mse_loss": recon_mse, "noise_loss": noise_mse, "acc": acc}

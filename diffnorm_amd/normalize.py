@@ -1,0 +1,78 @@
+"""Speech-unit normalisation driver: the host-side loop of the reference's
+research/TranSpeech/diff_norm_synthesis.py (:25-46 unit de-duplication, :132-171 batch assembly, :200-222 sampling
+and TSV lines), sharded over ranks by `diffnorm_amd.sharding`."""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import sharding
+
+TSV_HEADER = "id\tsrc_audio\tsrc_n_frames\ttgt_audio\ttgt_n_frames"
+
+
+def reduce_token(tokens: Sequence[int]) -> Tuple[List[int], List[int], torch.Tensor]:
+    """Run-length de-duplication: (units without consecutive repeats, run lengths, index of each run's first frame)."""
+    dedup, durations, keep = [], [], []
+    for i, tok in enumerate(tokens):
+        if i == 0 or tok != tokens[i - 1]:
+            dedup.append(tok)
+            keep.append(i)
+            durations.append(1)
+        else:
+            durations[-1] += 1
+    return dedup, durations, torch.tensor(keep, dtype=torch.long)
+
+
+@dataclass
+class Utterance:
+    audio_id: str
+    src_audio: str
+    src_n_frames: int
+    feat: torch.Tensor          # [T_full, 768] mHuBERT features of the target speech
+    tgt_unit: Sequence[int]     # frame-level units (length T_full)
+    reduce_tgt_unit: Sequence[int]  # de-duplicated units
+
+
+def assemble_batch(items: Sequence[Utterance], device):
+    """Selects the first frame of every unit run, zero-pads to the longest utterance (reference :132-171)."""
+    feats, units = [], []
+    for it in items:
+        _, _, keep = reduce_token(list(it.tgt_unit))
+        f = it.feat[keep]
+        assert f.shape[0] == len(it.reduce_tgt_unit), "reduced units do not match the de-duplicated frames"
+        feats.append(f)
+        units.append(torch.tensor(list(it.reduce_tgt_unit), dtype=torch.long))
+    lens = torch.tensor([f.shape[0] for f in feats], dtype=torch.long)
+    B, T = len(items), int(lens.max())
+    feat = torch.zeros(B, T, feats[0].shape[1])
+    unit = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        feat[b, : lens[b]], unit[b, : lens[b]] = feats[b], units[b]
+    # one pinned staging buffer + one async copy per tensor instead of one H2D per utterance (reference :145)
+    if torch.cuda.is_available():
+        feat, unit = feat.pin_memory(), unit.pin_memory()
+    return feat.to(device, non_blocking=True), unit.to(device, non_blocking=True), lens.to(device)
+
+
+def tsv_line(it: Utterance, pred_units: Sequence[int]) -> str:
+    dedup, _, _ = reduce_token(list(pred_units))
+    return f"{it.audio_id}\t{it.src_audio}\t{it.src_n_frames}\t{' '.join(str(u) for u in dedup)}\t{len(pred_units)}"
+
+
+def normalize(ddim_sample: Callable, utterances: Sequence[Utterance], start_step: int = 50, batch_size: int = 100,
+              device="cuda:0", group=None) -> Optional[List[str]]:
+    """Runs `ddim_sample(feat, input_mask=..., ref_units=..., start_step=...)` (LatentDiscreteModel.ddim_sample) over this
+    rank's batches and gathers the TSV lines of all ranks in utterance order (every rank returns the full list)."""
+    rank, world = sharding.rank_world(group)
+    batches = sharding.batch_indices(len(utterances), batch_size)
+    mine = sharding.my_batches(len(batches), rank, world)
+    local = []
+    for b in mine:
+        items = [utterances[i] for i in batches[b]]
+        feat, ref_units, lens = assemble_batch(items, device)
+        mask = torch.arange(feat.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1)
+        pred, _, _, _ = ddim_sample(feat, input_mask=mask, cond_scale=1.0, ref_units=ref_units, start_step=start_step)
+        local.append([tsv_line(it, p.tolist()) for it, p in zip(items, pred)])
+    per_batch = sharding.gather_in_order(local, mine, len(batches), group)
+    return [line for lines in per_batch for line in lines]

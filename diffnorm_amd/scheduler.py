@@ -59,11 +59,8 @@ class ScheduleTables:
     def ddim_coef_table(self, device=None) -> torch.Tensor:
         """[timesteps, 4] fp32 rows {sqrt_abar, sqrt(1-abar), sqrt(abar_prev), sqrt(1-abar_prev)} with the
         last two formed in fp32 from the fp32-cast abar_prev, as the eta=0 update does (:1426-1437)."""
-        sa = self.sqrt_alphas_cumprod.astype(np.float32)
-        s1 = self.sqrt_one_minus_alphas_cumprod.astype(np.float32)
-        abp = self.alphas_cumprod_prev.astype(np.float32)
-        tab = np.stack([sa, s1, np.sqrt(abp), np.sqrt(np.float32(1.0) - abp)], axis=1).astype(np.float32)
-        t = torch.from_numpy(np.ascontiguousarray(tab))
+        sa, s1, abp = self.f32("sqrt_alphas_cumprod"), self.f32("sqrt_one_minus_alphas_cumprod"), self.f32("alphas_cumprod_prev")
+        t = torch.stack([sa, s1, torch.sqrt(abp), torch.sqrt(1 - abp)], dim=1).contiguous()  # torch.sqrt, as upstream
         return t.to(device) if device is not None else t
 
 

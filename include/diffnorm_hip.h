@@ -89,12 +89,21 @@ typedef struct {
   int64_t gb_gstride;
   const float* pos_table; /* POSEMB: fp32 [T+1, pos_ld] sinusoidal table, row 0 = zeros             */
   int32_t pos_ld;
-  int32_t pad_;        /* profiling-only ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip LDS reads
-                          inside the K loop); 0 in every product call                               */
+  int32_t pad_;        /* profiling only.  bits 0..7: ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip
+                          LDS reads inside the K loop), 0 in every product call; bits 8..15: launch tag
+                          (DN_TAG_*) matched by dn_profile_start                                    */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
 } DnGemmParams;
 
 int dn_conv_gemm(const DnGemmParams* p, void* stream);
+
+/* launch tags set by the engine on its dominant contractions */
+enum { DN_TAG_FFN_CONV = 1, DN_TAG_WN_DILATED = 2 };
+
+/* Times the next `max_launches` eager dn_conv_gemm launches carrying `tag` with HIP events recorded on their
+ * launch stream (not under graph capture); dn_profile_stop synchronises them and returns the average. */
+int dn_profile_start(int32_t tag, int32_t max_launches);
+int dn_profile_stop(float* avg_ms, int32_t* n_launches);
 
 /* Fused key-masked multi-head self-attention, flash-style (no [B,H,T,T] tensor).
  * Replaces Attend.forward (non-flash branch) latent_module.py:299-343 between the to_q/to_kv and

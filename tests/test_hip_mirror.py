@@ -1,0 +1,113 @@
+"""GPU parity of the host-side mirror (reference class names / signatures / state-dict keys) and of the fairseq plugin
+surface, against the golden vectors of the real reference and the CPU oracle."""
+import argparse
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import diffnorm_oracle as O
+from gen_golden_configs import CHAIN_EPS, CHAIN_VAE, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol):
+    err = (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+    assert err <= tol, f"max abs err {err} > {tol}"
+
+
+@pytest.fixture(scope="module")
+def ldm():
+    from diffnorm_amd.latent_module import LatentDiscreteModel, SpeechVAEEncoderDecoder
+
+    vae = SpeechVAEEncoderDecoder(dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="f32")
+    vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
+    assert set(vae.state_dict()) == set(vsd), "VAE state-dict keys differ from the reference layout"
+    vae.load_state_dict(vsd, strict=True)
+    m = LatentDiscreteModel(types.SimpleNamespace(encoder=vae), CHAIN_EPS.dim, CHAIN_VAE.z, timesteps=200, dtype="f32")
+    esd = O.make_eps_state_dict(CHAIN_EPS, "chain")
+    assert set(m.model.state_dict()) == set(esd) | {"pos_embed._float_tensor"}
+    m.model.load_state_dict(dict(esd, **{"pos_embed._float_tensor": torch.zeros(1)}), strict=True)
+    # the diffusion checkpoint layout: model.* + speech_decoder.* 
+    assert any(k.startswith("speech_decoder.decoder_lm") for k in m.state_dict()) and any(k.startswith("model.wavenet") for k in m.state_dict())
+    return m.to(DEV).eval()
+
+
+def test_ddim_sample_matches_reference(ldm, golden):
+    g = golden("chain_small")
+    feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+    lens, units = T_(g["lens"]), T_(g["units"])
+    mask = O.lengths_to_mask(lens, 48)
+    for start in (5, 50):
+        toks, match, total, recon = ldm.ddim_sample(feat.to(DEV), input_mask=mask.to(DEV), ref_units=(units - 4).to(DEV),
+                                                    start_step=start, post_noise=T_(g[f"s{start}_post_noise"]),
+                                                    start_noise=T_(g[f"s{start}_start_noise"]))
+        assert total == int(g[f"s{start}_total"]) and match == int(g[f"s{start}_match"])
+        assert torch.cat(toks).cpu().tolist() == g[f"s{start}_units"].tolist()
+        close(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask], 1e-3)
+        assert [t.shape[0] for t in toks] == lens.tolist()
+
+
+def test_reference_rng_draw_order(ldm, golden):
+    """Without injected noise the mirror draws the posterior noise from the CPU generator as [B,z,T], like upstream."""
+    g = golden("chain_small")
+    feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+    mask = O.lengths_to_mask(T_(g["lens"]), 48)
+    torch.manual_seed(105)  # the generator state the golden run used for start_step=5
+    z = ldm.speech_decoder.encode_feature(feat.to(DEV)).transpose(1, 2)
+    want = O.vae_encode(O.make_vae_state_dict(CHAIN_VAE, "chain"), CHAIN_VAE, feat, T_(g["s5_post_noise"]))
+    close(z, want, 1e-3)
+
+
+def test_training_forward_losses_match_reference(ldm, golden):
+    g = golden("chain_small")
+    feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+    lens, units = T_(g["lens"]), T_(g["units"])
+    mask = O.lengths_to_mask(lens, 48)
+    with torch.no_grad():
+        ld = ldm(feat.to(DEV), units.to(DEV), tgt_mask=mask.to(DEV), times=T_(g["train_times"]), post_noise=T_(g["train_post"]),
+                 jitter_noise=T_(g["train_jitter"]), true_noise=T_(g["train_true"]))
+    for k, tol in (("total_loss", 1e-3), ("nll_loss", 1e-3), ("recon_mse_loss", 1e-3), ("noise_loss", 1e-3), ("acc", 0.02)):
+        close(ld[k], g["train_" + k], tol)
+    mse, logits, kl = ldm.speech_decoder(feat.to(DEV), units, mask.to(DEV), noise=T_(g["vae_post"]))
+    close(mse, g["vae_mse"], 1e-3)
+    close(kl, g["vae_kl"], 1e-4)
+    close(logits[:, :8], g["vae_logits_head"], 1e-3)
+
+
+def test_plugin_vae_criterion_end_to_end():
+    """--task speech_decoder --arch speech_vae_decoder --criterion speech_vae_decoder_loss on a synthetic batch."""
+    from diffnorm_amd.fairseq_plugin import registry as R
+    import diffnorm_amd.fairseq_plugin  # noqa: F401
+
+    tp = argparse.ArgumentParser()
+    R.TASK_REGISTRY["speech_decoder"].add_args(tp)
+    task = R.TASK_REGISTRY["speech_decoder"].setup_task(tp.parse_args(["/data", "--target-code-size", "1000"]))
+    mp = argparse.ArgumentParser()
+    R.MODEL_REGISTRY["speech_vae_decoder"].add_args(mp)
+    margs = mp.parse_args(["--latent_dim", "128", "--hip-dtype", "f32"])
+    margs.arch, margs.criterion = "speech_vae_decoder", "speech_vae_decoder_loss"
+    model = task.build_model(margs).to(DEV)
+    crit = task.build_criterion(margs)
+    ds = task.load_dataset("valid", n=4, min_len=20, max_len=40)
+    batch = ds.collater([ds[i] for i in range(4)])
+    torch.manual_seed(7)
+    loss, sample_size, log = task.valid_step(batch, model, crit)
+    assert sample_size == 4 and set(log) >= {"loss", "nll_loss", "mse_loss", "kl_loss", "acc", "ntokens", "nsentences"}
+    sd = {k[len("encoder."):]: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.manual_seed(7)
+    B, T = batch["reduce_target"].shape[:2]
+    noise = torch.randn(B, 128, T).transpose(1, 2)
+    want = O.vae_criterion(sd, O.VaeConfig(), batch["reduce_target"], batch["reduce_target_unit"], batch["reduce_target_lengths"], noise)
+    close(loss, want["loss"], 2e-3)
+    close(log["mse_loss"], want["mse_loss"], 1e-3)
+    close(log["kl_loss"], want["kl_loss"], 1e-3)
+    with pytest.raises(NotImplementedError):
+        task.train_step(batch, model, crit, optimizer=None, update_num=0)
