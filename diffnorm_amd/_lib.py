@@ -46,6 +46,16 @@ class AttnParams(C.Structure):
                 ("scale", C.c_float), ("pad2_", C.c_int32)]
 
 
+class GaussianStep(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("model_out", C.c_void_p), ("noise", C.c_void_p), ("sample", C.c_void_p),
+                ("pred_xstart", C.c_void_p), ("t", C.c_void_p), ("table", C.c_void_p), ("N", C.c_int32),
+                ("inner", C.c_int32), ("learned_range", C.c_int32), ("clip_denoised", C.c_int32), ("sampler", C.c_int32),
+                ("eta", C.c_float)]
+
+
+GD_COLS = 9
+
+
 class EpsConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "latent", "depth", "heads", "dim_head", "wn_layers",
                                          "wn_stacks", "cond_mult", "dtype", "max_pos")]
@@ -67,6 +77,7 @@ SYMBOLS = {
     "dn_time_cond": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "dn_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dn_gaussian_step": (C.c_int, [C.POINTER(GaussianStep), _vp]),
     "dn_posterior_sample": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_argmax_units": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_randn": (C.c_int, [_vp, _i64, _u64, _u64, _vp]),

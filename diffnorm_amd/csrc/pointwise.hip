@@ -261,6 +261,50 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ generic Gaussian step
+// One reverse step of the OpenAI-style scheduler for an eps-predicting model: pred_xstart (optionally clipped),
+// posterior mean, fixed / learned-range variance, then either the ancestral sample (p_sample) or the DDIM update.
+// table: fp32 [T, DN_GD_COLS] = {sqrt_recip_abar, sqrt_recipm1_abar, post_coef1, post_coef2, fixed_log_var,
+// min_log, max_log, abar, abar_prev} -- the fp32 casts of the float64 schedule, as _extract_into_tensor makes.
+__global__ __launch_bounds__(256) void gaussian_step_kernel(const DnGaussianStep p) {
+  const int64_t total = (int64_t)p.N * p.inner;
+  const int cmul = p.learned_range ? 2 : 1;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / p.inner);
+    const int64_t rem = i - (int64_t)n * p.inner;
+    const int tn = p.t[n];
+    const float* tb = p.table + (int64_t)tn * DN_GD_COLS;
+    const float xv = p.x[i];
+    const float eps = p.model_out[(int64_t)n * p.inner * cmul + rem];
+    float x0 = __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));
+    if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    float logvar = tb[4];
+    if (p.learned_range) {
+      const float v = p.model_out[(int64_t)n * p.inner * 2 + p.inner + rem];
+      const float frac = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);
+      logvar = __fadd_rn(__fmul_rn(frac, tb[6]), __fmul_rn(__fsub_rn(1.0f, frac), tb[5]));
+    }
+    const float nz = tn != 0 ? 1.0f : 0.0f;
+    const float nv = p.noise ? p.noise[i] : 0.0f;
+    float out;
+    if (p.sampler == 0) {  // p_sample: mean + 1[t != 0] * exp(0.5 * log_variance) * noise
+      const float mean = __fadd_rn(__fmul_rn(tb[2], x0), __fmul_rn(tb[3], xv));
+      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, expf(__fmul_rn(0.5f, logvar))), nv));
+    } else {  // ddim_sample
+      const float e2 = __fdiv_rn(__fsub_rn(__fmul_rn(tb[0], xv), x0), tb[1]);
+      const float ab = tb[7], abp = tb[8];
+      const float sigma = __fmul_rn(__fmul_rn(p.eta, sqrtf(__fdiv_rn(__fsub_rn(1.0f, abp), __fsub_rn(1.0f, ab)))),
+                                    sqrtf(__fsub_rn(1.0f, __fdiv_rn(ab, abp))));
+      const float mean = __fadd_rn(__fmul_rn(x0, sqrtf(abp)),
+                                   __fmul_rn(sqrtf(__fsub_rn(__fsub_rn(1.0f, abp), __fmul_rn(sigma, sigma))), e2));
+      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, sigma), nv));
+    }
+    p.sample[i] = out;
+    if (p.pred_xstart) p.pred_xstart[i] = x0;
+  }
+}
+
 static inline int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -338,5 +382,13 @@ extern "C" int dn_convert_rows(const void* src, int32_t src_dtype, int32_t lds, 
   hipLaunchKernelGGL(convert_rows_kernel, dim3(ew_grid((int64_t)M * ldd)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, lds, dst,
                      dst_dtype, ldd, M, C);
   DN_CHECK_LAUNCH("dn_convert_rows");
+  return DN_OK;
+}
+
+extern "C" int dn_gaussian_step(const DnGaussianStep* p, void* stream) {
+  DN_CHECK_ARG(p && p->x && p->model_out && p->sample && p->t && p->table, "dn_gaussian_step: null argument");
+  DN_CHECK_ARG(p->N > 0 && p->inner > 0 && (p->sampler == 0 || p->sampler == 1), "dn_gaussian_step: bad shape / sampler");
+  hipLaunchKernelGGL(gaussian_step_kernel, dim3(ew_grid((int64_t)p->N * p->inner)), dim3(256), 0, (hipStream_t)stream, *p);
+  DN_CHECK_LAUNCH("dn_gaussian_step");
   return DN_OK;
 }

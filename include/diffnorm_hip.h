@@ -149,6 +149,22 @@ int dn_q_sample(const float* x, const float* noise, float* out, void* out_act, i
                 int32_t ld_act, int32_t M, int32_t C, int32_t ld, int32_t T, const float* coef_a,
                 const float* coef_b, const int32_t* t, void* stream);
 
+/* One reverse step of GaussianDiffusion for an eps-predicting model (diffusion/gaussian_diffusion.py:254-417 p_mean_variance
+ * + p_sample, :513-560 ddim_sample): pred_xstart = sqrt_recip*x - sqrt_recipm1*eps [clamped to +-1], posterior mean,
+ * FIXED_LARGE / FIXED_SMALL (table column 4) or LEARNED_RANGE variance (model_out has 2x channels on dim 1), then
+ * sampler 0: mean + 1[t!=0]*exp(.5 logvar)*noise, sampler 1: DDIM with `eta`.  Tensors are fp32 [N, inner] (inner = C*L
+ * contiguous; model_out [N, 2*inner] when learned_range).  table: fp32 [T, DN_GD_COLS].                              */
+#define DN_GD_COLS 9
+typedef struct {
+  const float* x; const float* model_out; const float* noise; /* noise may be NULL (treated as 0) */
+  float* sample; float* pred_xstart;                          /* pred_xstart may be NULL */
+  const int32_t* t;                                           /* [N] */
+  const float* table;
+  int32_t N, inner, learned_range, clip_denoised, sampler;
+  float eta;
+} DnGaussianStep;
+int dn_gaussian_step(const DnGaussianStep* p, void* stream);
+
 /* DiagonalGaussianDistribution (distributions.py:24-41, 62-74): params fp32 [M, ldp] = [mean ; logvar];
  * z = mean + exp(0.5*clamp(logvar,-30,20))*noise; kl_rows (optional, fp32 [M]) = 0.5*sum_c(mean^2+var-1-logvar)
  * for valid frames, 0 for pads.                                                                    */
