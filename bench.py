@@ -64,6 +64,20 @@ def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters, 2.0 * M * (3 * inner) * inner
 
 
+def traffic_from_profiles():
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic*.json:
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 x2 read correction); None when no pass is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores(cap):
     """Threads the CPU leg may use: affinity mask, cgroup CPU quota, and the per-GPU host share (`cap`)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -109,7 +123,7 @@ def cpu_baseline(sd, cfg, B, T, timesteps, sample_b, max_threads):
             x = step(x, timesteps - 2 - n)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > 8.0 or n >= 3:
+            if dt > 10.0 or n >= 64:
                 break
     steps_per_s = n / dt * (sample_b / B)  # sequences are independent: a B-sequence step costs B/sample_b as much
     return {"value": steps_per_s, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
@@ -200,7 +214,7 @@ def main():
                                                     f"[{B * T} x 4095] x [4095 x 1365]",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "launches_timed": n_l.value,
-                         "avg_launch_ms_isolated_back_to_back": ksec_iso * 1e3, "traffic": None},
+                         "avg_launch_ms_isolated_back_to_back": ksec_iso * 1e3, "traffic": traffic_from_profiles()},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B), args.cpu_threads)

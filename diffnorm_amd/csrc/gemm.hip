@@ -11,6 +11,8 @@
 // 128-byte zero page, so activations stay dense [M, ld] with no per-sequence padding.  Weights are the
 // MFMA A operand and activations the B operand, so each lane ends up with 4 consecutive output columns
 // of one row: bias/FiLM vectors load as float4 and stores are 8/16 bytes per lane.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dn {
@@ -42,6 +44,71 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t lds_addr) {
 template <int N>
 __device__ __forceinline__ void pipe_sync() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// Row-wise epilogue of one wave's 64 x 64 fp32 slab `ep` ([64][EP_LD] floats in LDS): slab row r is output row
+// m_base + r, slab column c is packed weight row n_base + c (n_base a multiple of 64).  16 lanes cover the 64
+// columns of a row, so bias / FiLM / residual loads and the output stores are whole 128-256 B row segments.
+constexpr int EP_LD = 68;
+
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
+  const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
+  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (p.out_dtype == DN_BF16 ? 2 : 4);
+  if constexpr (EPI == DN_EPI_GEGLU) {
+    // value columns 0..31 and gate columns 32..63 of the slab -> 32 output columns: 8 lanes per row, 8 rows per pass
+    const int c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      const int m = m_base + row;
+      const int np = n_base + c4;              // packed row of the value
+      const int n = (n_base >> 1) + c4;        // output column
+      if (m >= p.M || n >= p.N) continue;
+      const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+      const float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
+      const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
+      const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
+      store4(out, (int64_t)m * p.ldo + n, p.out_dtype, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
+             gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
+    }
+  } else {
+    const int c4 = (lane & 15) * 4;
+    const int n = n_base + c4;
+    const float4 bv = (bias && n < p.N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = j * 4 + (lane >> 4);
+      const int m = m_base + row;
+      if (m >= p.M || n >= p.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+      float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+      if constexpr (EPI == DN_EPI_SILU) {
+        v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+      } else if constexpr (EPI == DN_EPI_FILM_GATE) {
+        if (p.gamma_beta) {
+          const float* gb = p.gamma_beta + p.gb_gstride * g + (int64_t)(m / p.T) * p.gb_ld + n;
+          const float4 ga = *reinterpret_cast<const float4*>(gb);
+          const float4 be = *reinterpret_cast<const float4*>(gb + p.gb_half);
+          v0 = v0 * ga.x + be.x; v1 = v1 * ga.y + be.y; v2 = v2 * ga.z + be.z; v3 = v3 * ga.w + be.w;
+        }
+        const char* res = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (p.res_dtype == DN_BF16 ? 2 : 4);
+        const float4 rv = load4(res, (int64_t)m * p.ldr + n, p.res_dtype);
+        v0 = tanh_sigmoid_gate(v0) + rv.x; v1 = tanh_sigmoid_gate(v1) + rv.y;
+        v2 = tanh_sigmoid_gate(v2) + rv.z; v3 = tanh_sigmoid_gate(v3) + rv.w;
+      } else if constexpr (EPI == DN_EPI_RESADD) {
+        const float* res = reinterpret_cast<const float*>(p.res) + p.res_gstride * g;
+        const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
+        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+      } else if constexpr (EPI == DN_EPI_POSEMB) {
+        const int b = m / p.T, t = m - b * p.T;
+        const int pos = t < p.lengths[b] ? t + 1 : 0;
+        const float4 pe = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
+        v0 += pe.x; v1 += pe.y; v2 += pe.z; v3 += pe.w;
+      }
+      store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+    }
+  }
 }
 
 // Tile geometry: BM activation rows x 128 weight rows, BM/32 waves (each 64 x 64), STAGES-deep LDS ring.
@@ -194,7 +261,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- C segment
-      __builtin_amdgcn_s_setprio(1);
+      if (!(p.pad_ & 8)) __builtin_amdgcn_s_setprio(1);
       if (!(p.pad_ & 2)) mma_all();
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -222,61 +289,191 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   }
 
   // ------------------------------------------------------------------ epilogue
-  const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
-  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (p.out_dtype == DN_BF16 ? 2 : 4);
+  // The accumulators hold, per lane, 4 consecutive columns of 16 different rows; stored from there a wave
+  // instruction would touch 16 rows x 32 bytes.  Each wave therefore transposes its 64 x 64 fp32 tile through a
+  // private LDS slab ([64][68] floats, the ring is dead by now) and runs the epilogue row-wise: 16 lanes cover the
+  // 64 columns of one row, so bias / FiLM / residual loads and the output stores are whole 128-256 B row segments.
+  if constexpr (STAGES != 3) __syncthreads();  // the 2-stage loop ends without a barrier: ring reads must be over
+  float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + frow;
-    if (m >= p.M) continue;
-    const int b = m / p.T;
-    const int t = m - b * p.T;
-    (void)t;
-    if constexpr (EPI == DN_EPI_GEGLU) {
+  for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int np = n0 + wn * 64 + nt * 16 + fq * 4;       // packed row of the value
-        const int n = (n0 >> 1) + wn * 32 + nt * 16 + fq * 4;  // output column
-        if (n >= p.N) continue;
-        float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
-        float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
-        const f32x4 v = acc[nt][mt], gt = acc[nt + 2][mt];
-        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, gelu_erf(gt[0] + bg.x) * (v[0] + bv.x),
-               gelu_erf(gt[1] + bg.y) * (v[1] + bv.y), gelu_erf(gt[2] + bg.z) * (v[2] + bv.z),
-               gelu_erf(gt[3] + bg.w) * (v[3] + bv.w));
-      }
+    for (int nt = 0; nt < 4; ++nt)
+      *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[nt][mt];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in-order: writes precede the reads below
+
+  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane);
+}
+
+// ------------------------------------------------------------------------------------------ 256 x 256 tile
+// The large-problem variant.  At 256 x 128 the K loop is pinned by two per-CU paths that cannot be made faster, only
+// relieved: the L2 -> LDS DMA path (~60 B/clk: 48 KiB per K-tile ~ 800 cycles) and the LDS fragment reads, each about as
+// long as the 1024 MFMA cycles they feed (ablation in DESIGN.md).  Doubling the weight tile halves both per MFMA:
+//   tile 256 (activation rows) x 256 (weight rows), 8 waves, each 64 (m) x 128 (n): 32 MFMAs per 32-deep K-tile from
+//   12 fragment reads (16 -> 12 per 32 MFMAs) and 4 DMA pieces (6 -> 4);
+//   K-tiles are 64 bytes per row (32 bf16 / 16 f32) so a 4-stage ring is 128 KiB: three K-tiles in flight;
+//   64-byte rows put 4 rows in a bank row: the conflict-free swizzle is chunk ^= 2 * ((row >> 3) & 1).
+// Schedule: the same staggered two-group L / C segments as above, one K-tile per segment pair.
+constexpr int ROWB2 = 64;
+
+template <typename E, int EPI>
+__global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int KT = ROWB2 / ES;
+  constexpr int BMB = 256, BNB = 256, STAGES = 4;
+  constexpr int TILE = 256 * ROWB2;          // 16 KiB per operand tile
+  constexpr int STAGE_BYTES = 2 * TILE;      // W tile then A tile
+  constexpr int PER_STAGE = 4;               // DMA pieces per wave per stage (2 W + 2 A, 16 rows each)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.y;
+  const int np_total = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);   // packed weight rows that carry output
+  const int n_tiles_n = (np_total + BNB - 1) / BNB;
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (logical / n_tiles_n) * BMB;
+  const int n0 = (logical % n_tiles_n) * BNB;
+  const int w_rows = (np_total + 127) / 128 * 128;  // rows the packed weight really has: clamp the ragged last tile
+
+  // ---- staging: wave w stages rows [32w, 32w+32) of both tiles, 16 rows x 64 B per piece
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+  int a_row[2], a_t[2], w_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + wave * 32 + i * 16 + srow;
+    m = m < p.M ? m : p.M - 1;
+    a_row[i] = m;
+    a_t[i] = m % p.T;
+    int n = n0 + wave * 32 + i * 16 + srow;
+    w_row[i] = n < w_rows ? n : w_rows - 1;
+  }
+  const int ktiles_per_term = p.K / KT;
+  const int nkt = p.n_terms * ktiles_per_term;
+  const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+  const char* a_ptr[2];
+  const char* w_ptr[2];
+  int a_inc[2];
+  int s_term = 0, s_kk = 0;
+  auto setup_term = [&](int term) {
+    const DnGemmTerm& tm = p.terms[term];
+    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool valid = a_t[i] >= shift;
+      a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * tm.lda * ES : zero_src;
+      a_inc[i] = valid ? ROWB2 : 0;
+      w_ptr[i] = W + (int64_t)w_row[i] * p.K * ES;
+    }
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
+  auto stage = [&](int slot) {
+    const uint32_t wbase = lds_base + slot * STAGE_BYTES + wave * 2048;
+    const uint32_t abase = wbase + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(w_ptr[i], wbase + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_ptr[i], abase + i * 1024);
+    if (++s_kk == ktiles_per_term) {
+      s_kk = 0;
+      if (++s_term < p.n_terms) setup_term(s_term);
     } else {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-        if (n >= p.N) continue;
-        float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
-              v3 = acc[nt][mt][3] + bv.w;
-        if constexpr (EPI == DN_EPI_SILU) {
-          v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-        } else if constexpr (EPI == DN_EPI_FILM_GATE) {
-          if (p.gamma_beta) {
-            const float* gb = p.gamma_beta + p.gb_gstride * g + (int64_t)b * p.gb_ld + n;
-            const float4 ga = *reinterpret_cast<const float4*>(gb);
-            const float4 be = *reinterpret_cast<const float4*>(gb + p.gb_half);
-            v0 = v0 * ga.x + be.x; v1 = v1 * ga.y + be.y; v2 = v2 * ga.z + be.z; v3 = v3 * ga.w + be.w;
-          }
-          const char* res = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (p.res_dtype == DN_BF16 ? 2 : 4);
-          const float4 rv = load4(res, (int64_t)m * p.ldr + n, p.res_dtype);
-          v0 = tanh_sigmoid_gate(v0) + rv.x; v1 = tanh_sigmoid_gate(v1) + rv.y;
-          v2 = tanh_sigmoid_gate(v2) + rv.z; v3 = tanh_sigmoid_gate(v3) + rv.w;
-        } else if constexpr (EPI == DN_EPI_RESADD) {
-          const float* res = reinterpret_cast<const float*>(p.res) + p.res_gstride * g;
-          const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
-          v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-        } else if constexpr (EPI == DN_EPI_POSEMB) {
-          const int pos = t < p.lengths[b] ? t + 1 : 0;
-          const float4 pe = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
-          v0 += pe.x; v1 += pe.y; v2 += pe.z; v3 += pe.w;
-        }
-        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+      for (int i = 0; i < 2; ++i) {
+        a_ptr[i] += a_inc[i];
+        w_ptr[i] += ROWB2;
       }
     }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: row (l & 15) of a 16-row sub-tile, 16-byte chunk (l >> 4) of the 64-byte row, swizzled
+  const int frow = lane & 15, fq = lane >> 4;
+  const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
+  const int w_rd = (wn * 128 + frow) * ROWB2 + coff;
+  const int a_rd = TILE + (wm * 64 + frow) * ROWB2 + coff;
+  uint4 wf[8], af[4];
+  auto load_frags = [&](int slot) {
+    const char* sb = smem + slot * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB2);
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[nt], af[mt]);
+  };
+
+  // Segment s = 2k / 2k+1 is (L_k, C_k) for group 0 (waves 0-3) and 2k+1 / 2k+2 for group 1 (waves 4-7).
+  //   RAW: tile k+1 must be in LDS before segment 2k+2: every wave retires its pieces of tile k+1 with a counted
+  //        vmcnt ahead of the barrier that ends odd segment 2k+1 (tiles k+2, k+3 may stay in flight: 2*PER_STAGE).
+  //   WAR: tile k+3 overwrites the slot of tile k-1, last read in segment 2k-1; it is issued in segments >= 2k.
+  setup_term(0);
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nkt) stage(st);
+  if (nkt > 2) pipe_sync<2 * PER_STAGE>(); else if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();  // tile 0 landed
+  __builtin_amdgcn_sched_barrier(0);
+  if (late) pipe_sync<63>();  // the stagger
+  int slot = 0, fill = STAGES - 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = nkt - 1 - kt;  // tiles after kt
+    // ---- L segment
+    if (!(p.pad_ & 4)) load_frags(slot);
+    if (kt + STAGES - 1 < nkt && !(p.pad_ & 1)) stage(fill);
+    if (late) {
+      if (ahead >= 3) pipe_sync<2 * PER_STAGE>(); else if (ahead == 2) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+    } else {
+      pipe_sync<63>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C segment
+    if (!(p.pad_ & 8)) __builtin_amdgcn_s_setprio(1);
+    if (!(p.pad_ & 2)) mma_all();
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) {
+      pipe_sync<63>();
+    } else {
+      if (ahead >= 3) pipe_sync<2 * PER_STAGE>(); else if (ahead == 2) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot == STAGES - 1 ? 0 : slot + 1;
+    fill = fill == STAGES - 1 ? 0 : fill + 1;
+  }
+  if (!late) pipe_sync<63>();
+
+  // ---- epilogue: two 64 x 64 halves of the wave's 64 (m) x 128 (n) tile through its LDS slab
+  float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[h * 4 + nt][mt];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + h * 64, g, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
   }
 }
 
@@ -290,7 +487,8 @@ static LaunchProfile g_prof;
 
 template <typename E, int EPI, int BM, int STAGES>
 static int launch_tile(const DnGemmParams& p, hipStream_t s) {
-  constexpr int lds = STAGES * (W_TILE_BYTES + BM * ROWB);
+  constexpr int ring = STAGES * (W_TILE_BYTES + BM * ROWB), slabs = (BM / 32) * 64 * 68 * 4;
+  constexpr int lds = ring > slabs ? ring : slabs;  // K-loop ring, reused as the epilogue's transpose slabs
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<E, EPI, BM, STAGES>),
@@ -308,11 +506,36 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
 }
 
 template <typename E, int EPI>
-static int launch(const DnGemmParams& p, hipStream_t s) {
-  // 256-row tiles once they still give every CU a workgroup; 128-row tiles for small problems
+static int launch_big(const DnGemmParams& p, hipStream_t s) {
+  constexpr int ring = 4 * 2 * 256 * ROWB2, slabs = 8 * 64 * EP_LD * 4;
+  constexpr int lds = ring > slabs ? ring : slabs;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
-  const long tiles256 = (long)((p.M + 255) / 256) * ((np + BN - 1) / BN) * p.groups;
-  if (tiles256 >= 192) return launch_tile<E, EPI, 256, 3>(p, s);
+  dim3 grid(((p.M + 255) / 256) * ((np + 255) / 256), p.groups);
+  const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI>), grid, dim3(512), lds, s, p);
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
+  DN_CHECK_LAUNCH("dn_conv_gemm");
+  return DN_OK;
+}
+
+template <typename E, int EPI>
+static int launch(const DnGemmParams& p, hipStream_t s) {
+  // 256 x 256 tiles when they still cover the chip (>= ~1.4 workgroups per CU or an exact fit), 256 x 128 tiles
+  // while those give every CU a workgroup, 128 x 128 tiles for small problems.  DN_GEMM_TILE forces a variant.
+  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  const long mt256 = (p.M + 255) / 256;
+  const long tiles_big = mt256 * ((np + 255) / 256) * p.groups;
+  const long tiles_mid = mt256 * ((np + BN - 1) / BN) * p.groups;
+  static const int force = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
+  if (force == 3 || (force == 0 && tiles_big >= 360)) return launch_big<E, EPI>(p, s);
+  if (force == 2 || (force == 0 && tiles_mid >= 192)) return launch_tile<E, EPI, 256, 3>(p, s);
   return launch_tile<E, EPI, 128, 2>(p, s);
 }
 

@@ -90,7 +90,7 @@ typedef struct {
   const float* pos_table; /* POSEMB: fp32 [T+1, pos_ld] sinusoidal table, row 0 = zeros             */
   int32_t pos_ld;
   int32_t pad_;        /* profiling only.  bits 0..7: ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip
-                          LDS reads inside the K loop), 0 in every product call; bits 8..15: launch tag
+                          LDS reads inside the K loop, bit3 no s_setprio), 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start                                    */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
 } DnGemmParams;
