@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="one stream per chain instead of two forked half-batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on host threads of the CPU baseline (host share of one GPU)")
@@ -170,11 +171,11 @@ def main():
 
     with torch.cuda.stream(stream):
         if W > 0:
-            n = eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=W)
+            n = eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=W, split=not args.no_split)
             assert n == W
         barrier()
         t0 = time.perf_counter()
-        n = eng.ddim_loop(x, lengths, start - W, coef, use_graph=not args.no_graph, max_evals=K)
+        n = eng.ddim_loop(x, lengths, start - W, coef, use_graph=not args.no_graph, max_evals=K, split=not args.no_split)
         barrier()
         dt = time.perf_counter() - t0
         assert n == K
@@ -193,7 +194,7 @@ def main():
             import ctypes
             lib = _lib.load()
             _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV, 12 * 5), "dn_profile_start")
-            eng.ddim_loop(x, lengths, start - W - K, coef, use_graph=False, max_evals=5)
+            eng.ddim_loop(x, lengths, start - W - K, coef, use_graph=False, max_evals=5, split=False)
             avg_ms, n_l = ctypes.c_float(), ctypes.c_int32()
             _lib.check(lib.dn_profile_stop(ctypes.byref(avg_ms), ctypes.byref(n_l)), "dn_profile_stop")
             ksec = avg_ms.value * 1e-3
@@ -206,7 +207,7 @@ def main():
             "config": {"workload": f"configs[2]: DDIM/DDPM-schedule reverse chain, eps-predictor Model(512, z=128) on "
                                    f"[B={B},T={T}] latents per GPU, {args.timesteps}-step cosine schedule, random-init weights",
                        "batch_per_gpu": B, "frames": T, "latent_dim": cfg.latent_dim, "timesteps": args.timesteps,
-                       "hip_graph": not args.no_graph, "parallelism": f"batch-sharded x{world} (no collective)"},
+                       "hip_graph": not args.no_graph, "half_batch_streams": 1 if args.no_split else 2, "parallelism": f"batch-sharded x{world} (no collective)"},
             "frame_steps_per_s": world * K * B * T / dt,
             "step_tflops": step_flops * K / dt / 1e12,
             "step_mfma_frac": step_flops * K / dt / 1e12 / peak,

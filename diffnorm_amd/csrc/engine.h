@@ -69,6 +69,8 @@ struct DnEps {
   float* graph_x;
   const int32_t* graph_len;
   const float* graph_coef;
+  int graph_flags;
+  void *side_stream, *ev_fork, *ev_join;  // DN_LOOP_SPLIT2: second half-batch stream and its fork/join events
 };
 constexpr int kEpsTensors = 7 + dn::kWavenetTensors + dn::kTransformerTensors + 3;
 

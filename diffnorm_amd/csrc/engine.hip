@@ -281,6 +281,9 @@ extern "C" int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights,
 extern "C" void dn_eps_destroy(DnEps* m) {
   if (!m) return;
   if (m->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)m->graph_exec);
+  if (m->ev_fork) (void)hipEventDestroy((hipEvent_t)m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy((hipEvent_t)m->ev_join);
+  if (m->side_stream) (void)hipStreamDestroy((hipStream_t)m->side_stream);
   delete m;
 }
 
@@ -375,25 +378,44 @@ static size_t ddim_extra_bytes(const DnEps* m, int B, int T, int start_step) {
 
 extern "C" size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t start_step) {
   if (!m || B <= 0 || T <= 0 || start_step < 1) return 0;
-  return eps_ws_core(m, B, T) + ddim_extra_bytes(m, B, T, start_step);
+  const size_t whole = eps_ws_core(m, B, T);
+  const size_t halves = B >= 2 ? eps_ws_core(m, B / 2, T) + eps_ws_core(m, B - B / 2, T) : 0;  // DN_LOOP_SPLIT2
+  return (whole > halves ? whole : halves) + ddim_extra_bytes(m, B, T, start_step);
 }
 
 extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
-                            const float* coef, int32_t timesteps, int32_t use_graph, void* workspace, size_t workspace_bytes,
+                            const float* coef, int32_t timesteps, int32_t flags, void* workspace, size_t workspace_bytes,
                             void* stream) {
+  int use_graph = flags & DN_LOOP_GRAPH;
+  const bool split = (flags & DN_LOOP_SPLIT2) && B >= 2;
   DN_CHECK_ARG(m && x && lengths && coef && workspace, "dn_ddim_loop: null argument");
   DN_CHECK_ARG(start_step >= 1 && start_step <= timesteps - 1, "dn_ddim_loop: start_step=%d must be in [1, %d]", start_step, timesteps - 1);
   hipStream_t s = (hipStream_t)stream;
   DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_ddim_loop: workspace must be 256-byte aligned");
   const int z = m->cfg.latent, M = B * T, C = m->cfg.dim * m->cfg.cond_mult;
-  const size_t core = eps_ws_core(m, B, T);
+  // Two half-batches on two streams (a fork/join inside the captured step): the halves are independent chains, so the
+  // fill / drain of one half's launches overlaps the other half's main loops (measured -5 % per step at [32,512]).
+  const int B0 = split ? B / 2 : B, B1 = B - B0;
+  const size_t core0 = eps_ws_core(m, B0, T), core1 = split ? eps_ws_core(m, B1, T) : 0, core = core0 + core1;
   const size_t need = core + ddim_extra_bytes(m, B, T, start_step);
   if (need > workspace_bytes) {
     dn_set_error("dn_ddim_loop: workspace %zu < required %zu (see dn_ddim_workspace_bytes)", workspace_bytes, need);
     return DN_EWORKSPACE;
   }
-  Arena core_ar{(char*)workspace, 0, core};
-  const EpsBufs bufs = plan_eps(m, B, T, 1, core_ar);
+  Arena core_ar{(char*)workspace, 0, core0};
+  const EpsBufs bufs = plan_eps(m, B0, T, 1, core_ar);
+  Arena core_ar1{(char*)workspace + core0, 0, core1};
+  EpsBufs bufs1 = bufs;
+  if (split) bufs1 = plan_eps(m, B1, T, 1, core_ar1);
+  if (split && !m->side_stream) {
+    if (hipStreamCreateWithFlags((hipStream_t*)&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags((hipEvent_t*)&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags((hipEvent_t*)&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+      dn_set_error("dn_ddim_loop: could not create the side stream");
+      return DN_ELAUNCH;
+    }
+  }
+  hipStream_t s2 = (hipStream_t)m->side_stream;
   Arena ar{(char*)workspace + core, 0, workspace_bytes - core};
   // fixed-size state first, so a cached graph stays valid when only start_step changes
   float* eps = (float*)ar.take((size_t)M * z * 4);
@@ -412,8 +434,23 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
     hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_cond, counter, bufs.gb);
-    DN_TRY(eps_core(m, x, bufs.gb, 0, lengths, B, T, eps, bufs, s));
-    DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, M, z, z, T, coef, tvec, s));
+    if (split) {  // fork: the second half runs on the side stream behind the shared conditioning row
+      const size_t off = (size_t)B0 * T * z;
+      if (hipEventRecord((hipEvent_t)m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)m->ev_fork, 0) != hipSuccess) {
+        dn_set_error("dn_ddim_loop: fork failed");
+        return DN_ELAUNCH;
+      }
+      DN_TRY(eps_core(m, x + off, bufs.gb, 0, lengths + B0, B1, T, eps + off, bufs1, s2));
+      DN_TRY(dn_ddim_step(x + off, eps + off, x + off, nullptr, DN_F32, z, B1 * T, z, z, T, coef, tvec + B0, s2));
+    }
+    DN_TRY(eps_core(m, x, bufs.gb, 0, lengths, B0, T, eps, bufs, s));
+    DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, B0 * T, z, z, T, coef, tvec, s));
+    if (split) {  // join
+      if (hipEventRecord((hipEvent_t)m->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, (hipEvent_t)m->ev_join, 0) != hipSuccess) {
+        dn_set_error("dn_ddim_loop: join failed");
+        return DN_ELAUNCH;
+      }
+    }
     hipLaunchKernelGGL(dec_counter_kernel, dim3(1), dim3(1), 0, s, counter);
     DN_CHECK_LAUNCH("dn_ddim_loop step");
     return DN_OK;
@@ -423,7 +460,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   if (!s) use_graph = 0;  // the null stream cannot be captured
   if (use_graph && n_eval > 2) {
     const bool cached = m->graph_exec && m->graph_B == B && m->graph_T == T && m->graph_ws == workspace && m->graph_x == x &&
-                        m->graph_len == lengths && m->graph_coef == coef;
+                        m->graph_len == lengths && m->graph_coef == coef && m->graph_flags == flags;
     if (!cached) {
       DN_TRY(one_step());  // eager first step: also settles the per-kernel attributes outside capture
       done = 1;
@@ -451,7 +488,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
         return DN_ELAUNCH;
       }
       m->graph_exec = exec; m->graph_B = B; m->graph_T = T; m->graph_ws = workspace; m->graph_x = x;
-      m->graph_len = lengths; m->graph_coef = coef;
+      m->graph_len = lengths; m->graph_coef = coef; m->graph_flags = flags;
     }
     for (; done < n_eval; ++done) {
       hipError_t e = hipGraphLaunch((hipGraphExec_t)m->graph_exec, s);

@@ -97,7 +97,7 @@ class EpsEngine(_Engine):
         return out
 
     def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
-                  use_graph: bool = True, max_evals: int = 0) -> int:
+                  use_graph: bool = True, max_evals: int = 0, split: bool = True) -> int:
         """In-place DDIM eta=0 chain on x [B,T,z] fp32 (reference latent_module.py:1411-1445).
         coef: fp32 [timesteps,4] from `scheduler.ddim_coef_table`.  Returns the number of model evaluations."""
         B, T, z = x.shape
@@ -109,7 +109,8 @@ class EpsEngine(_Engine):
         wp, wn = self._aligned(ws)
         with torch.cuda.device(self.device):
             return _lib.check(self.lib.dn_ddim_loop(self.handle, x.data_ptr(), l32.data_ptr(), B, T, start_step,
-                                                    max_evals, coef.data_ptr(), coef.shape[0], int(use_graph), wp, wn,
+                                                    max_evals, coef.data_ptr(), coef.shape[0],
+                                                    (1 if use_graph else 0) | (2 if split else 0), wp, wn,
                                                     _lib.current_stream()), "dn_ddim_loop")
 
 

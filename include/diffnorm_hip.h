@@ -228,11 +228,13 @@ int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengths, int32_t
  * start_step == 1) with the eta=0 update after each.  coef: fp32 [timesteps,4] as dn_ddim_step.
  * x fp32 [B,T,latent] is updated in place.  The conditioning rows of all steps are built once, in
  * fp32, before the loop.  max_evals > 0 stops after that many evaluations (the caller continues with
- * start_step - max_evals).  use_graph != 0 captures one step into a hipGraph and replays it.  Workspace:
+ * start_step - max_evals).  flags: DN_LOOP_* bits.  Workspace:
  * dn_ddim_workspace_bytes.  Returns the number of model evaluations (>= 0) or a negative error.                 */
+enum { DN_LOOP_GRAPH = 1,  /* capture one step into a hipGraph and replay it */
+       DN_LOOP_SPLIT2 = 2  /* run the two half-batches as parallel branches (side stream / forked graph) */ };
 size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t start_step);
 int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step,
-                 int32_t max_evals, const float* coef, int32_t timesteps, int32_t use_graph, void* workspace,
+                 int32_t max_evals, const float* coef, int32_t timesteps, int32_t flags, void* workspace,
                  size_t workspace_bytes, void* stream);
 
 const char* dn_last_error(void);
