@@ -13,6 +13,8 @@
 // 16-lane group).  In f32 mode each v_mfma_f32_16x16x4_f32 takes one P register and one scalar LDS
 // read of V.  LDS rows are 256 B (bf16) / 512 B (f32) with an XOR swizzle that makes the K row reads,
 // the V transposed reads and the f32 scalar reads bank-conflict-free (see lds_off).
+#include <type_traits>
+
 #include "common.h"
 
 namespace dn {
@@ -44,8 +46,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   constexpr int KS_D = DHP * ES / 64;    // 64-byte k-steps along the head dim (QK^T)
   constexpr int NCH = DHP * ES / 16;     // 16-byte chunks per K/V row
   constexpr int DT = DHP / 16;           // 16-wide output tiles along the head dim
-  char* k_lds = smem;
-  char* v_lds = smem + KV_TILE * ROWB;
+  constexpr int TILE_LDS = KV_TILE * ROWB;
+  char* k_lds = smem;                  // [2][KV_TILE][ROWB]
+  char* v_lds = smem + 2 * TILE_LDS;   // [2][KV_TILE][ROWB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -84,21 +87,45 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     sc = 0.f;
   }
 
-  for (int kv0 = 0; kv0 < len; kv0 += KV_TILE) {
-    __syncthreads();  // previous tile fully consumed
-    for (int idx = tid; idx < KV_TILE * NCH; idx += 256) {
+  // K/V tiles are double-buffered in LDS and register-staged one tile ahead: the global loads of tile j+1 are
+  // issued before tile j is consumed and written to the other buffer after it, so HBM/L2 latency hides under
+  // the MFMAs and softmax of tile j; one barrier per tile.
+  constexpr int NPT = (KV_TILE * NCH + 255) / 256;  // 16-byte chunks per thread per tensor per tile
+  uint4 kreg[NPT], vreg[NPT];
+  auto issue_loads = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int idx = tid + i * 256;
       const int row = idx / NCH, ch = idx - row * NCH;
       const int key = kv0 + row;
-      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-      if (key < T && ch * 16 < dhb) {
-        kv4 = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
-        vv4 = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
+      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
+      if (idx < KV_TILE * NCH && key < T && ch * 16 < dhb) {
+        kreg[i] = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
+        vreg[i] = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
       }
-      const int off = lds_off<E>(row, ch * 16);
-      *reinterpret_cast<uint4*>(k_lds + off) = kv4;
-      *reinterpret_cast<uint4*>(v_lds + off) = vv4;
     }
-    __syncthreads();
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / NCH, ch = idx - row * NCH;
+      if (idx < KV_TILE * NCH) {
+        const int off = buf * TILE_LDS + lds_off<E>(row, ch * 16);
+        *reinterpret_cast<uint4*>(k_lds + off) = kreg[i];
+        *reinterpret_cast<uint4*>(v_lds + off) = vreg[i];
+      }
+    }
+  };
+  issue_loads(0);
+  write_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kv0 = 0; kv0 < len; kv0 += KV_TILE) {
+    const bool more = kv0 + KV_TILE < len;
+    if (more) issue_loads(kv0 + KV_TILE);
+    const char* kt_lds = k_lds + buf * TILE_LDS;
+    const char* vt_lds = v_lds + buf * TILE_LDS;
 
     // ---- S^T = K . Q^T : acc_s[kt][qt][r] = S[query qt*16+fr][key kt*16 + 4*fg + r]
     f32x4 acc_s[4][2];
@@ -108,45 +135,55 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(k_lds + lds_off<E>(kt * 16 + fr, ks * 64 + fg * 16));
+        const uint4 kf = *reinterpret_cast<const uint4*>(kt_lds + lds_off<E>(kt * 16 + fr, ks * 64 + fg * 16));
         mma_kstep<E>(acc_s[kt][0], kf, qf[0][ks]);
         mma_kstep<E>(acc_s[kt][1], kf, qf[1][ks]);
       }
     }
 
-    // ---- online softmax (log2 domain), per query tile
+    // ---- online softmax (log2 domain), per query tile.  The running max is kept on the raw scores (scaling by a
+    // positive constant commutes with max), so the scale folds into one FMA per score: p = 2^(s*sc - m*sc); the
+    // exponential is the bare v_exp_f32.  Key masking costs a compare + select per score and is compiled only into
+    // the tile that straddles `len` (a wave-uniform branch).
+    auto softmax_tile = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = NEG_BIG;
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = NEG_BIG;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + kt * 16 + fg * 4 + r;
-          const float s = key < len ? acc_s[kt][qt][r] * sc : NEG_BIG;
-          acc_s[kt][qt][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f(m_run[qt] - m_new);
-      float rs = 0.f;
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (MASKED) {
+              const int key = kv0 + kt * 16 + fg * 4 + r;
+              acc_s[kt][qt][r] = key < len ? acc_s[kt][qt][r] : NEG_BIG;
+            }
+            mx = fmaxf(mx, acc_s[kt][qt][r]);
+          }
+        mx = quad_xor_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc);
+        const float neg_ms = -m_new * sc;
+        float rs = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f(acc_s[kt][qt][r] - m_new);
-          acc_s[kt][qt][r] = pv;
-          rs += pv;
-        }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      l_run[qt] = l_run[qt] * alpha + rs;
-      m_run[qt] = m_new;
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            acc_s[kt][qt][r] = pv;
+            rs += pv;
+          }
+        rs = quad_xor_sum(rs);
+        l_run[qt] = l_run[qt] * alpha + rs;
+        m_run[qt] = m_new;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
-    }
+        for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
+      }
+    };
+    if (kv0 + KV_TILE > len)
+      softmax_tile(std::true_type{});
+    else
+      softmax_tile(std::false_type{});
 
     // ---- O^T += V^T . P^T
     if constexpr (ES == 2) {
@@ -167,9 +204,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
         for (int dt = 0; dt < DT; ++dt) {
           const int byte = dt * 32 + (fr & 3) * 8;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(v_lds + lds_off<E>(krow0, byte)));
+              (__attribute__((address_space(3))) s16x4*)(vt_lds + lds_off<E>(krow0, byte)));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(v_lds + lds_off<E>(krow1, byte)));
+              (__attribute__((address_space(3))) s16x4*)(vt_lds + lds_off<E>(krow1, byte)));
           uint4 vf;
           const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
           vf.x = lo2.x; vf.y = lo2.y; vf.z = hi2.x; vf.w = hi2.y;
@@ -185,12 +222,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           const int key = kt * 16 + fg * 4 + r;  // k-slot fg of MFMA (kt, r)
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const float vv = *reinterpret_cast<const float*>(v_lds + lds_off<E>(key, (dt * 16 + fr) * 4));
+            const float vv = *reinterpret_cast<const float*>(vt_lds + lds_off<E>(key, (dt * 16 + fr) * 4));
             acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][0][r], acc_o[dt][0], 0, 0, 0);
             acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][1][r], acc_o[dt][1], 0, 0, 0);
           }
         }
     }
+    if (more) write_tile(buf ^ 1);  // the other buffer was last read one barrier ago
+    __syncthreads();
+    buf ^= 1;
   }
 
   // ---- O = acc / l ; lane holds dims dt*16 + 4*fg + 0..3 of query qt*16 + fr
@@ -212,7 +252,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 
 template <typename E, int DHP>
 static int launch_attn(const DnAttnParams& p, hipStream_t s) {
-  constexpr int lds = 2 * KV_TILE * AttnGeom<E>::ROWB;
+  constexpr int lds = 4 * KV_TILE * AttnGeom<E>::ROWB;  // K and V, double-buffered
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

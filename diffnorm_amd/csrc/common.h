@@ -68,6 +68,22 @@ __device__ __forceinline__ float4 load4(const void* base, int64_t elem_off, int 
   return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
 }
 
+// Reductions over the four lanes {l, l^16, l^32, l^48} with the gfx950 half/row swaps instead of ds_bpermute:
+// v_permlane32_swap(a, b) exchanges lanes 32-63 of a with lanes 0-31 of b, v_permlane16_swap the odd 16-lane rows of a
+// with the even rows of b; fed the same value twice they leave {x[l], x[l^32]} resp. {x[l], x[l^16]} in the two results.
+__device__ __forceinline__ float quad_xor_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float quad_xor_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // Epilogue transcendentals.  These run once per output element inside MFMA kernels, so they are built
 // from one v_exp_f32 (+ v_rcp_f32) each instead of the libm expansions; absolute error <= ~3e-7, far
 // inside the fp32 budget of 1e-3 (checked against the oracle's exact forms in tests/test_hip_ops.py).

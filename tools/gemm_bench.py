@@ -65,3 +65,17 @@ shape("attn_out 512->512 resadd", 512, 512, epi=_lib.EPI_RESADD, count=12)
 shape("wn_init k3 512", 512, 512, taps=3, count=1)
 shape("linear 512->512", 512, 512, count=3)
 print("total GEMM ms/step: %.3f" % sum(r[4] for r in rows))
+
+# attention [B=32,T=512,H=8,dh=64]
+hd = 512
+qkv = (torch.randn(M, 3 * hd, device=dev) * 0.5).to(dt)
+ao = torch.empty(M, hd, device=dev, dtype=dt)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+sec = timeit(lambda: ops.attention(qkv, qkv[:, hd:], qkv[:, 2 * hd:], ao, B, T, 8, 64, lens, ldq=3 * hd, ldk=3 * hd, ldv=3 * hd))
+fl = 4.0 * T * T * 64 * 8 * B
+print(f"{'attention 8x64 T=512':28s} x12  {sec*1e6:8.1f} us  {fl/sec/1e12:7.1f} TF/s   {12*sec*1e3:6.3f} ms/step")
+xr = torch.randn(M, 512, device=dev)
+xn = torch.empty(M, 512, device=dev, dtype=dt)
+gbv = torch.randn(1, 1024, device=dev)
+sec = timeit(lambda: ops.rmsnorm(xr, xn, T, gamma_beta=gbv, gb_shared=True, gb_half=512))
+print(f"{'rmsnorm 512':28s} x25  {sec*1e6:8.1f} us  {M*512*6/sec/1e12:7.2f} TB/s   {25*sec*1e3:6.3f} ms/step")
