@@ -75,38 +75,73 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
   } else {
     const int c4 = (lane & 15) * 4;
     const int n = n_base + c4;
-    const float4 bv = (bias && n < p.N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+    if (n >= p.N) return;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+    // The side inputs of a row (residual, FiLM gamma/beta, positional row) are global loads; issued inside the
+    // per-row loop each would sit behind the previous row's store (the compiler must assume `out` aliases them) and
+    // expose a full memory round trip per row.  So the rows go in batches of RB: all loads of a batch first, then
+    // the arithmetic and the stores.
+    constexpr int RB = (EPI == DN_EPI_FILM_GATE) ? 4 : 8;
+    int b0 = 0, t0 = 0;  // (sequence, frame) of this lane's first row, advanced incrementally (no division per row)
+    if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_POSEMB) {
+      const int m_first = m_base + (lane >> 4);
+      b0 = m_first / p.T;
+      t0 = m_first - b0 * p.T;
+    }
+    const char* resb = nullptr;
+    const int res_dtype = EPI == DN_EPI_RESADD ? DN_F32 : p.res_dtype;  // the residual stream is always fp32
+    if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_RESADD)
+      resb = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (res_dtype == DN_BF16 ? 2 : 4);
+    const float* gbb = nullptr;
+    if constexpr (EPI == DN_EPI_FILM_GATE) gbb = p.gamma_beta ? p.gamma_beta + p.gb_gstride * g + n : nullptr;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = j * 4 + (lane >> 4);
-      const int m = m_base + row;
-      if (m >= p.M || n >= p.N) continue;
-      const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-      float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
-      if constexpr (EPI == DN_EPI_SILU) {
-        v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-      } else if constexpr (EPI == DN_EPI_FILM_GATE) {
-        if (p.gamma_beta) {
-          const float* gb = p.gamma_beta + p.gb_gstride * g + (int64_t)(m / p.T) * p.gb_ld + n;
-          const float4 ga = *reinterpret_cast<const float4*>(gb);
-          const float4 be = *reinterpret_cast<const float4*>(gb + p.gb_half);
-          v0 = v0 * ga.x + be.x; v1 = v1 * ga.y + be.y; v2 = v2 * ga.z + be.z; v3 = v3 * ga.w + be.w;
+    for (int jb = 0; jb < 16; jb += RB) {
+      float4 rv[RB], ga[RB], be[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int m = m_base + (jb + i) * 4 + (lane >> 4);
+        rv[i] = ga[i] = be[i] = make_float4(0, 0, 0, 0);
+        if (m >= p.M) continue;
+        if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_RESADD) rv[i] = load4(resb, (int64_t)m * p.ldr + n, res_dtype);
+        if constexpr (EPI == DN_EPI_FILM_GATE) {
+          if (gbb) {
+            const float* gr = gbb + (int64_t)b0 * p.gb_ld;
+            ga[i] = *reinterpret_cast<const float4*>(gr);
+            be[i] = *reinterpret_cast<const float4*>(gr + p.gb_half);
+          }
         }
-        const char* res = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (p.res_dtype == DN_BF16 ? 2 : 4);
-        const float4 rv = load4(res, (int64_t)m * p.ldr + n, p.res_dtype);
-        v0 = tanh_sigmoid_gate(v0) + rv.x; v1 = tanh_sigmoid_gate(v1) + rv.y;
-        v2 = tanh_sigmoid_gate(v2) + rv.z; v3 = tanh_sigmoid_gate(v3) + rv.w;
-      } else if constexpr (EPI == DN_EPI_RESADD) {
-        const float* res = reinterpret_cast<const float*>(p.res) + p.res_gstride * g;
-        const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
-        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-      } else if constexpr (EPI == DN_EPI_POSEMB) {
-        const int b = m / p.T, t = m - b * p.T;
-        const int pos = t < p.lengths[b] ? t + 1 : 0;
-        const float4 pe = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
-        v0 += pe.x; v1 += pe.y; v2 += pe.z; v3 += pe.w;
+        if constexpr (EPI == DN_EPI_POSEMB) {
+          const int pos = t0 < p.lengths[b0] ? t0 + 1 : 0;
+          rv[i] = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
+        }
+        if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_POSEMB) {
+          t0 += 4;  // next row of this lane is 4 frames on
+          while (t0 >= p.T) {
+            t0 -= p.T;
+            ++b0;
+          }
+        }
       }
-      store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int row = (jb + i) * 4 + (lane >> 4);
+        const int m = m_base + row;
+        if (m >= p.M) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+        float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+        if constexpr (EPI == DN_EPI_SILU) {
+          v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+        } else if constexpr (EPI == DN_EPI_FILM_GATE) {
+          if (gbb) {
+            v0 = v0 * ga[i].x + be[i].x; v1 = v1 * ga[i].y + be[i].y; v2 = v2 * ga[i].z + be[i].z; v3 = v3 * ga[i].w + be[i].w;
+          }
+          v0 = tanh_sigmoid_gate(v0) + rv[i].x; v1 = tanh_sigmoid_gate(v1) + rv[i].y;
+          v2 = tanh_sigmoid_gate(v2) + rv[i].z; v3 = tanh_sigmoid_gate(v3) + rv[i].w;
+        } else if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
+          v0 += rv[i].x; v1 += rv[i].y; v2 += rv[i].z; v3 += rv[i].w;
+        }
+        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+      }
     }
   }
 }

@@ -75,7 +75,7 @@ class EpsEngine(_Engine):
     def __del__(self):
         if getattr(self, "handle", None) and self.handle.value:
             self.lib.dn_eps_destroy(self.handle)
-            self.handle = C.c_void_p()
+            self.handle = None
 
     def workspace_bytes(self, B: int, T: int) -> int:
         return int(self.lib.dn_eps_workspace_bytes(self.handle, B, T))
@@ -137,7 +137,7 @@ class VaeEngine(_Engine):
     def __del__(self):
         if getattr(self, "handle", None) and self.handle.value:
             self.lib.dn_vae_destroy(self.handle)
-            self.handle = C.c_void_p()
+            self.handle = None
 
     def workspace_bytes(self, B: int, T: int) -> int:
         return int(self.lib.dn_vae_workspace_bytes(self.handle, B, T))
