@@ -13,6 +13,8 @@
 // of one row: bias/FiLM vectors load as float4 and stores are 8/16 bytes per lane.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace dn {
@@ -51,26 +53,46 @@ __device__ __forceinline__ void pipe_sync() {
 // columns of a row, so bias / FiLM / residual loads and the output stores are whole 128-256 B row segments.
 constexpr int EP_LD = 68;
 
-template <int EPI>
-__device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
+template <bool BF>
+__device__ __forceinline__ void store4t(void* base, int64_t off, float a, float b, float c, float d) {
+  if constexpr (BF)
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  else
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = make_float4(a, b, c, d);
+}
+template <bool BF>
+__device__ __forceinline__ float4 load4t(const void* base, int64_t off) {
+  if constexpr (BF) {
+    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+  }
+}
+
+// OUT_BF / RES_BF: storage types fixed at compile time; FULL: every row of the slab is inside M (no per-row guards).
+template <int EPI, bool OUT_BF, bool RES_BF, bool FULL>
+__device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
-  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (p.out_dtype == DN_BF16 ? 2 : 4);
+  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (OUT_BF ? 2 : 4);
   if constexpr (EPI == DN_EPI_GEGLU) {
     // value columns 0..31 and gate columns 32..63 of the slab -> 32 output columns: 8 lanes per row, 8 rows per pass
     const int c4 = (lane & 7) * 4;
+    const int np = n_base + c4;              // packed row of the value
+    const int n = (n_base >> 1) + c4;        // output column
+    if (n >= p.N) return;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
+    const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = j * 8 + (lane >> 3);
       const int m = m_base + row;
-      const int np = n_base + c4;              // packed row of the value
-      const int n = (n_base >> 1) + c4;        // output column
-      if (m >= p.M || n >= p.N) continue;
+      if (!FULL && m >= p.M) continue;
       const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
       const float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
-      const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
-      const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
-      store4(out, (int64_t)m * p.ldo + n, p.out_dtype, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
-             gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
+      store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
+                      gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
     }
   } else {
     const int c4 = (lane & 15) * 4;
@@ -81,7 +103,8 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
     // per-row loop each would sit behind the previous row's store (the compiler must assume `out` aliases them) and
     // expose a full memory round trip per row.  So the rows go in batches of RB: all loads of a batch first, then
     // the arithmetic and the stores.
-    constexpr int RB = (EPI == DN_EPI_FILM_GATE) ? 4 : 8;
+    constexpr int RB = EPI == DN_EPI_FILM_GATE ? 4 : 8;  // FiLM rows carry up to three side vectors each
+    constexpr bool HAS_RES = EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_RESADD;
     int b0 = 0, t0 = 0;  // (sequence, frame) of this lane's first row, advanced incrementally (no division per row)
     if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_POSEMB) {
       const int m_first = m_base + (lane >> 4);
@@ -89,22 +112,29 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
       t0 = m_first - b0 * p.T;
     }
     const char* resb = nullptr;
-    const int res_dtype = EPI == DN_EPI_RESADD ? DN_F32 : p.res_dtype;  // the residual stream is always fp32
-    if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_RESADD)
-      resb = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (res_dtype == DN_BF16 ? 2 : 4);
+    if constexpr (HAS_RES) resb = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * (RES_BF ? 2 : 4);
     const float* gbb = nullptr;
     if constexpr (EPI == DN_EPI_FILM_GATE) gbb = p.gamma_beta ? p.gamma_beta + p.gb_gstride * g + n : nullptr;
+    const bool gb_shared = p.gb_ld == 0;
+    float4 gas = make_float4(1, 1, 1, 1), bes = make_float4(0, 0, 0, 0);
+    if constexpr (EPI == DN_EPI_FILM_GATE)
+      if (gbb && gb_shared) {  // one conditioning row for the whole batch (sampling): load it once per lane
+        gas = *reinterpret_cast<const float4*>(gbb);
+        bes = *reinterpret_cast<const float4*>(gbb + p.gb_half);
+      }
 #pragma unroll
     for (int jb = 0; jb < 16; jb += RB) {
       float4 rv[RB], ga[RB], be[RB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int m = m_base + (jb + i) * 4 + (lane >> 4);
-        rv[i] = ga[i] = be[i] = make_float4(0, 0, 0, 0);
-        if (m >= p.M) continue;
-        if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_RESADD) rv[i] = load4(resb, (int64_t)m * p.ldr + n, res_dtype);
+        rv[i] = make_float4(0, 0, 0, 0);
+        ga[i] = gas;
+        be[i] = bes;
+        if (!FULL && m >= p.M) continue;
+        if constexpr (HAS_RES) rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
         if constexpr (EPI == DN_EPI_FILM_GATE) {
-          if (gbb) {
+          if (gbb && !gb_shared) {
             const float* gr = gbb + (int64_t)b0 * p.gb_ld;
             ga[i] = *reinterpret_cast<const float4*>(gr);
             be[i] = *reinterpret_cast<const float4*>(gr + p.gb_half);
@@ -115,10 +145,15 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
           rv[i] = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
         }
         if constexpr (EPI == DN_EPI_FILM_GATE || EPI == DN_EPI_POSEMB) {
-          t0 += 4;  // next row of this lane is 4 frames on
-          while (t0 >= p.T) {
-            t0 -= p.T;
-            ++b0;
+          if (p.T >= 4) {  // next row of this lane is 4 frames on: at most one sequence boundary
+            t0 += 4;
+            if (t0 >= p.T) {
+              t0 -= p.T;
+              ++b0;
+            }
+          } else {
+            b0 = (m + 4) / p.T;
+            t0 = (m + 4) - b0 * p.T;
           }
         }
       }
@@ -126,7 +161,7 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
       for (int i = 0; i < RB; ++i) {
         const int row = (jb + i) * 4 + (lane >> 4);
         const int m = m_base + row;
-        if (m >= p.M) continue;
+        if (!FULL && m >= p.M) continue;
         const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
         float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
         if constexpr (EPI == DN_EPI_SILU) {
@@ -140,10 +175,31 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
         } else if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           v0 += rv[i].x; v1 += rv[i].y; v2 += rv[i].z; v3 += rv[i].w;
         }
-        store4(out, (int64_t)m * p.ldo + n, p.out_dtype, v0, v1, v2, v3);
+        store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, v0, v1, v2, v3);
       }
     }
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
+  const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
+  const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
+  constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
+  const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
+#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane)
+  if constexpr (RESADD) {
+    if (full) DN_EP(false, false, true); else DN_EP(false, false, false);
+  } else if constexpr (EPI == DN_EPI_FILM_GATE) {
+    if (obf && rbf) { if (full) DN_EP(true, true, true); else DN_EP(true, true, false); }
+    else if (!obf && !rbf) { if (full) DN_EP(false, false, true); else DN_EP(false, false, false); }
+    else if (obf) DN_EP(true, false, false);
+    else DN_EP(false, true, false);
+  } else {
+    if (obf) { if (full) DN_EP(true, false, true); else DN_EP(true, false, false); }
+    else { if (full) DN_EP(false, false, true); else DN_EP(false, false, false); }
+  }
+#undef DN_EP
 }
 
 // Tile geometry: BM activation rows x 128 weight rows, BM/32 waves (each 64 x 64), STAGES-deep LDS ring.
@@ -499,17 +555,21 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
 
   // ---- epilogue: two 64 x 64 halves of the wave's 64 (m) x 128 (n) tile through its LDS slab
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  // the two halves are spelled out with compile-time accumulator indices: a rolled loop would index `acc` at run time
+  // and push the whole accumulator file to scratch
+  auto half = [&](auto hc) {
+    constexpr int H = decltype(hc)::value;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[h * 4 + nt][mt];
+        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[H * 4 + nt][mt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + h * 64, g, lane);
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
-  }
+  };
+  half(std::integral_constant<int, 0>{});
+  half(std::integral_constant<int, 1>{});
 }
 
 // In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
