@@ -35,7 +35,10 @@ class GemmParams(C.Structure):
                 ("ldr", C.c_int32), ("res_dtype", C.c_int32), ("res_gstride", C.c_int64),
                 ("gamma_beta", C.c_void_p), ("gb_ld", C.c_int32), ("gb_half", C.c_int32),
                 ("gb_gstride", C.c_int64), ("pos_table", C.c_void_p), ("pos_ld", C.c_int32),
-                ("pad_", C.c_int32), ("lengths", C.c_void_p)]
+                ("pad_", C.c_int32), ("lengths", C.c_void_p),
+                ("norm_out", C.c_void_p), ("norm_ld", C.c_int32), ("norm_dtype", C.c_int32), ("norm_D", C.c_int32),
+                ("norm_gb_ld", C.c_int32), ("norm_gamma", C.c_void_p), ("norm_gb", C.c_void_p),
+                ("norm_gb_half", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class AttnParams(C.Structure):

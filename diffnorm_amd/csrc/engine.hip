@@ -3,6 +3,7 @@
 // allocates or synchronises; every intermediate lives in the caller's workspace (bump-allocated by
 // the plan_* functions, which also serve the *_workspace_bytes queries).
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -130,15 +131,36 @@ TfBufs plan_tf(const TransformerW& w, int M, int es, Arena& ar) {
   return b;
 }
 
-// xres fp32 [M, padk(dim)] is updated in place; `pred` receives to_pred's output.
+// Fills the fused-RMSNorm fields of a RESADD / POSEMB contraction (see DnGemmParams.norm_out).
+void set_norm(DnGemmParams& p, void* xn, int Dp, int D, int dtype, const float* gamma, const float* gb, int gb_ld) {
+  p.norm_out = xn; p.norm_ld = Dp; p.norm_dtype = dtype; p.norm_D = D;
+  p.norm_gamma = gamma; p.norm_gb = gb; p.norm_gb_ld = gb_ld; p.norm_gb_half = Dp;
+}
+
+// gamma / conditioning row of the norm in front of (layer l, sub-block j): j = 0 attention, 1 feed-forward;
+// l == depth selects to_pred's norm.
+struct NormSrc { const float* gamma; const float* gb; };
+NormSrc norm_src(const TransformerW& w, const float* gb, int l, int j) {
+  const int D = w.dim, Dp = padk(D);
+  if (l == w.depth) return {w.pred_gamma, nullptr};
+  const float* g = j == 0 ? w.g1 : w.g2;
+  return {g ? g + (size_t)l * D : nullptr, gb ? gb + (size_t)(2 * l + j) * 2 * Dp : nullptr};
+}
+
+// xres fp32 [M, padk(dim)] is updated in place; `pred` receives to_pred's output.  When the model width fits the
+// whole-row tile (padk(dim) <= 512) every RMSNorm is fused into the contraction that produces its input: the caller
+// supplies the first one (`xn_ready`: tb.xn already holds layer 0's attention norm) or it runs standalone once.
 int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T, const int32_t* lengths, const float* gb, int gb_ld,
-                    const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, hipStream_t s) {
+                    const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
   const int es = esize(dtype), M = B * T;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
+  const bool fuse = Dp <= 512 && !getenv("DN_NO_FUSE_NORM");  // (the switch exists for A/B timing only)
+  auto standalone_norm = [&](int l, int j) -> int {
+    const NormSrc ns = norm_src(w, gb, l, j);
+    return dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, ns.gamma, ns.gb, gb_ld, Dp, s);
+  };
+  if (!(fuse && xn_ready)) DN_TRY(standalone_norm(0, 0));
   for (int l = 0; l < w.depth; ++l) {
-    const float* gb1 = gb ? gb + (size_t)(2 * l) * 2 * Dp : nullptr;
-    const float* gb2 = gb ? gb + (size_t)(2 * l + 1) * 2 * Dp : nullptr;
-    DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.g1 ? w.g1 + (size_t)l * D : nullptr, gb1, gb_ld, Dp, s));
     {  // to_q ; to_kv in one contraction (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
@@ -154,13 +176,17 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       a.scale = 1.0f / sqrtf((float)w.dim_head);
       DN_TRY(dn_attention(&a, s));
     }
-    {  // to_out + residual (:932,692)
+    {  // to_out + residual (:932,692) [+ the feed-forward block's norm (:703)]
       DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
       p.terms[0].A = tb.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      if (fuse) {
+        const NormSrc ns = norm_src(w, gb, l, 1);
+        set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      }
       DN_TRY(dn_conv_gemm(&p, s));
     }
-    DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.g2 ? w.g2 + (size_t)l * D : nullptr, gb2, gb_ld, Dp, s));
+    if (!fuse) DN_TRY(standalone_norm(l, 1));
     {  // Linear(D -> 2*inner) + GEGLU (:899,881-884)
       DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
@@ -179,16 +205,20 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       p.pad_ = DN_TAG_FFN_CONV << 8;
       DN_TRY(dn_conv_gemm(&p, s));
     }
-    {  // Linear(inner -> D) + residual (:902,704)
+    {  // Linear(inner -> D) + residual (:902,704) [+ the next layer's attention norm (:691) or to_pred's norm (:677)]
       DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
       p.terms[0].A = tb.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
       p.bias = w.ffout_b + (size_t)l * Dp;
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      if (fuse) {
+        const NormSrc ns = norm_src(w, gb, l + 1, 0);
+        set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      }
       DN_TRY(dn_conv_gemm(&p, s));
     }
+    if (!fuse) DN_TRY(standalone_norm(l + 1, 0));
   }
-  // to_pred = RMSNorm(gamma) + Linear(D, D, no bias) (:676-679)
-  DN_TRY(dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, w.pred_gamma, nullptr, 0, 0, s));
+  // to_pred = RMSNorm(gamma) + Linear(D, D, no bias) (:676-679); its norm came out of the last contraction above
   DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
   p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = w.pred_W;
   p.out = pred; p.ldo = pred_ld; p.out_dtype = pred_dtype;
@@ -329,10 +359,13 @@ int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const i
     DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
     fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    const bool fuse_norm = Dp <= 512 && !getenv("DN_NO_FUSE_NORM");
+    if (fuse_norm)  // layer 0's attention norm rides on the contraction that opens the residual stream
+      set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp, gb_ld);
     DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, gb, gb_ld, b.wv, fin, s));
   }
   const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, Dp <= 512 && !getenv("DN_NO_FUSE_NORM"), s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
@@ -650,7 +683,7 @@ extern "C" int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengt
   }
   float* rec = dense_recon ? recon : b.recon;
   const int rec_ld = dense_recon ? D : Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, b.tf, rec, rec_ld, DN_F32, s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, b.tf, rec, rec_ld, DN_F32, false, s));
   if (recon && !dense_recon) DN_TRY(dn_convert_rows(rec, DN_F32, Dp, recon, DN_F32, D, M, D, s));
   if (!want_lm) return DN_OK;
   DN_TRY(dn_convert_rows(rec, DN_F32, rec_ld, b.pred_act, dtype, Dp, M, D, s));

@@ -572,6 +572,208 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   half(std::integral_constant<int, 1>{});
 }
 
+// ------------------------------------------------------------------------------------------ whole-row tile + fused RMSNorm
+// For the two contractions per transformer layer that close a residual branch (to_out and the FFN's last Linear, N = D)
+// and the WaveNet's final 1x1 conv: a 64 (rows) x 512 (all columns) tile, so one workgroup sees complete rows of the new
+// residual stream and can emit the next block's RMSNorm (adaptive gamma/beta or learned gamma) in the same launch.  That
+// removes the separate norm kernel -- one fp32 read + one bf16 write of the stream per norm, 25 per denoising step.
+// 8 waves, wave w owns columns [64w, 64w+64) of all 64 rows; 2-stage ring of 72 KiB (weights 64 KiB + rows 8 KiB).
+template <typename E, int EPI>
+__global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int KT = ROWB / ES;
+  constexpr int A_TILE = 64 * ROWB, W_TILE = 512 * ROWB, STAGE_BYTES = W_TILE + A_TILE;
+  constexpr int PART_OFF = 8 * 64 * EP_LD * 4;  // per-row partial sums of squares live behind the 8 slabs
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y;
+  const int m0 = blockIdx.x * 64;
+  const int w_rows = (p.N + 127) / 128 * 128;
+
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;
+  int a_row, a_t, w_row[8];
+  {
+    int m = m0 + wave * 8 + srow;
+    m = m < p.M ? m : p.M - 1;
+    a_row = m;
+    a_t = m % p.T;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = wave * 64 + i * 8 + srow;
+      w_row[i] = n < w_rows ? n : w_rows - 1;
+    }
+  }
+  const int ktiles_per_term = p.K / KT;
+  const int nkt = p.n_terms * ktiles_per_term;
+  const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+  const char* a_ptr;
+  const char* w_ptr[8];
+  int a_inc;
+  int s_term = 0, s_kk = 0;
+  auto setup_term = [&](int term) {
+    const DnGemmTerm& tm = p.terms[term];
+    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
+    const bool valid = a_t >= shift;
+    a_ptr = valid ? A + (int64_t)(a_row - shift) * tm.lda * ES : zero_src;
+    a_inc = valid ? ROWB : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w_ptr[i] = W + (int64_t)w_row[i] * p.K * ES;
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
+  auto stage = [&](int slot) {
+    const uint32_t sbase = lds_base + slot * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16(w_ptr[i], sbase + (wave * 8 + i) * 1024);
+    glds16(a_ptr, sbase + W_TILE + wave * 1024);
+    if (++s_kk == ktiles_per_term) {
+      s_kk = 0;
+      if (++s_term < p.n_terms) setup_term(s_term);
+    } else {
+      a_ptr += a_inc;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w_ptr[i] += ROWB;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  const int sw = frow & 7;
+  const int w_rd = (wave * 64 + frow) * ROWB;
+  const int a_rd = W_TILE + frow * ROWB;
+
+  setup_term(0);
+  stage(0);
+  int slot = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    pipe_sync<0>();
+    if (kt + 1 < nkt) stage(slot ^ 1);
+    const char* sb = smem + slot * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + fq) ^ sw) << 4;
+      uint4 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB + coff);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[nt], af[mt]);
+    }
+    slot ^= 1;
+  }
+  __syncthreads();  // ring reads over: the slabs may overwrite it
+
+  // ---- epilogue 1: transpose, residual / positional add, fp32 stream store, per-row partial sums of squares
+  float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+  float* part = reinterpret_cast<float*>(smem + PART_OFF);  // [64 rows][8 waves]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[nt][mt];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  const int c4 = (lane & 15) * 4;
+  const int n = wave * 64 + c4;
+  const bool col_ok = n < p.N;
+  const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
+  const float4 bv = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+  float* out = reinterpret_cast<float*>(p.out) + p.out_gstride * g;  // RESADD / POSEMB always write the fp32 stream
+  const float* resb = EPI == DN_EPI_RESADD ? reinterpret_cast<const float*>(p.res) + p.res_gstride * g : nullptr;
+  int b0 = 0, t0 = 0;
+  {
+    const int m_first = m0 + (lane >> 4);
+    b0 = m_first / p.T;
+    t0 = m_first - b0 * p.T;
+  }
+  int bs[16];  // sequence of each of this lane's rows (for the adaptive norm rows)
+  float4 xv[16];
+#pragma unroll
+  for (int jb = 0; jb < 16; jb += 8) {
+    float4 rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + (jb + i) * 4 + (lane >> 4);
+      rv[i] = make_float4(0, 0, 0, 0);
+      bs[jb + i] = b0;
+      if (m < p.M && col_ok) {
+        if constexpr (EPI == DN_EPI_RESADD) {
+          rv[i] = *reinterpret_cast<const float4*>(resb + (int64_t)m * p.ldr + n);
+        } else {
+          const int pos = t0 < p.lengths[b0] ? t0 + 1 : 0;
+          rv[i] = *reinterpret_cast<const float4*>(p.pos_table + (int64_t)pos * p.pos_ld + n);
+        }
+      }
+      if (p.T >= 4) {
+        t0 += 4;
+        if (t0 >= p.T) {
+          t0 -= p.T;
+          ++b0;
+        }
+      } else {
+        b0 = (m + 4) / p.T;
+        t0 = (m + 4) - b0 * p.T;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (jb + i) * 4 + (lane >> 4);
+      const int m = m0 + row;
+      const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+      float4 v = make_float4(a4.x + bv.x + rv[i].x, a4.y + bv.y + rv[i].y, a4.z + bv.z + rv[i].z, a4.w + bv.w + rv[i].w);
+      if (!col_ok) v = make_float4(0, 0, 0, 0);
+      xv[jb + i] = v;
+      if (m < p.M && col_ok) *reinterpret_cast<float4*>(out + (int64_t)m * p.ldo + n) = v;
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;  // columns >= norm_D are exact zeros (zero-padded weights)
+      ss += __shfl_xor(ss, 1, 16);
+      ss += __shfl_xor(ss, 2, 16);
+      ss += __shfl_xor(ss, 4, 16);
+      ss += __shfl_xor(ss, 8, 16);
+      if ((lane & 15) == 0) part[row * 8 + wave] = ss;
+    }
+  }
+  if (!p.norm_out) return;
+  __syncthreads();
+
+  // ---- epilogue 2: the next block's RMSNorm of the rows just produced
+  const float scale = sqrtf((float)p.norm_D);
+  const bool in_d = n < p.norm_D;
+  const float4 gam = (p.norm_gamma && in_d) ? *reinterpret_cast<const float4*>(p.norm_gamma + n) : make_float4(1, 1, 1, 1);
+  const bool nbf = p.norm_dtype == DN_BF16;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int row = j * 4 + (lane >> 4);
+    const int m = m0 + row;
+    if (m >= p.M || n >= p.norm_ld) continue;
+    const float4 p0 = *reinterpret_cast<const float4*>(part + row * 8);
+    const float4 p1 = *reinterpret_cast<const float4*>(part + row * 8 + 4);
+    const float denom = fmaxf(sqrtf(p0.x + p0.y + p0.z + p0.w + p1.x + p1.y + p1.z + p1.w), 1e-12f);
+    float4 y = make_float4(xv[j].x / denom * scale * gam.x, xv[j].y / denom * scale * gam.y, xv[j].z / denom * scale * gam.z,
+                           xv[j].w / denom * scale * gam.w);
+    if (p.norm_gb && in_d) {
+      const float* gr = p.norm_gb + (int64_t)bs[j] * p.norm_gb_ld + n;
+      const float4 ga = *reinterpret_cast<const float4*>(gr);
+      const float4 be = *reinterpret_cast<const float4*>(gr + p.norm_gb_half);
+      y = make_float4(y.x * ga.x + be.x, y.y * ga.y + be.y, y.z * ga.z + be.z, y.w * ga.w + be.w);
+    }
+    if (!in_d) y = make_float4(0, 0, 0, 0);
+    if (nbf) store4t<true>(p.norm_out, (int64_t)m * p.norm_ld + n, y.x, y.y, y.z, y.w);
+    else store4t<false>(p.norm_out, (int64_t)m * p.norm_ld + n, y.x, y.y, y.z, y.w);
+  }
+}
+
 // In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
 // around every dn_conv_gemm whose tag (bits 8..15 of DnGemmParams.pad_) matches.  Eager launches only.
 struct LaunchProfile {
@@ -621,7 +823,26 @@ static int launch_big(const DnGemmParams& p, hipStream_t s) {
 }
 
 template <typename E, int EPI>
+static int launch_row(const DnGemmParams& p, hipStream_t s) {
+  constexpr int ring = 2 * (512 + 64) * ROWB, slabs = 8 * 64 * EP_LD * 4 + 64 * 8 * 4;
+  constexpr int lds = ring > slabs ? ring : slabs;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_row_kernel<E, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  dim3 grid((p.M + 63) / 64, p.groups);
+  hipLaunchKernelGGL((conv_gemm_row_kernel<E, EPI>), grid, dim3(512), lds, s, p);
+  DN_CHECK_LAUNCH("dn_conv_gemm (row tile)");
+  return DN_OK;
+}
+
+template <typename E, int EPI>
 static int launch(const DnGemmParams& p, hipStream_t s) {
+  if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
+    if (p.norm_out) return launch_row<E, EPI>(p, s);
+  }
   // 256 x 256 tiles when they still cover the chip (>= ~1.4 workgroups per CU or an exact fit), 256 x 128 tiles
   // while those give every CU a workgroup, 128 x 128 tiles for small problems.  DN_GEMM_TILE forces a variant.
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
@@ -674,6 +895,13 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   if (p.epilogue == DN_EPI_RESADD) DN_CHECK_ARG(p.out_dtype == DN_F32, "dn_conv_gemm: RESADD writes fp32");
   if (p.epilogue == DN_EPI_POSEMB) DN_CHECK_ARG(p.pos_table && p.lengths && p.pos_ld % 4 == 0, "dn_conv_gemm: POSEMB needs pos_table and lengths");
   if (p.epilogue == DN_EPI_FILM_GATE && p.gamma_beta) DN_CHECK_ARG(p.gb_half % 4 == 0 && p.gb_ld % 4 == 0, "dn_conv_gemm: gamma_beta strides must be multiples of 4");
+  if (p.norm_out) {
+    DN_CHECK_ARG(p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB, "dn_conv_gemm: norm_out needs a RESADD or POSEMB epilogue");
+    DN_CHECK_ARG(p.N <= 512 && p.out_dtype == DN_F32, "dn_conv_gemm: the fused norm needs N <= 512 and an fp32 stream");
+    DN_CHECK_ARG(p.norm_D > 0 && p.norm_D <= p.N && p.norm_D % 4 == 0 && p.norm_ld % 4 == 0 && p.norm_ld >= p.norm_D && p.norm_ld <= 512,
+                 "dn_conv_gemm: bad norm_D=%d / norm_ld=%d", p.norm_D, p.norm_ld);
+    DN_CHECK_ARG(!p.norm_gb || (p.norm_gb_ld % 4 == 0 && p.norm_gb_half % 4 == 0), "dn_conv_gemm: norm_gb strides must be multiples of 4");
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return p.dtype == DN_BF16 ? dn::dispatch_epi<dn::BF16>(p, s) : dn::dispatch_epi<dn::F32>(p, s);
 }

@@ -29,7 +29,9 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS, groups: int = 1,
               res: Optional[torch.Tensor] = None, gamma_beta: Optional[torch.Tensor] = None, gb_shared: bool = False,
               gb_half: int = 0, pos_table: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
-              shift_by_group: bool = False, a_grouped: bool = True):
+              shift_by_group: bool = False, a_grouped: bool = True, norm_out: Optional[torch.Tensor] = None,
+              norm_D: int = 0, norm_gamma: Optional[torch.Tensor] = None, norm_gb: Optional[torch.Tensor] = None,
+              norm_gb_shared: bool = False, norm_gb_half: int = 0):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
@@ -68,6 +70,12 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
     if pos_table is not None:
         p.pos_table, p.pos_ld = pos_table.data_ptr(), pos_table.shape[-1]
         p.lengths = lengths.data_ptr()
+    if norm_out is not None:  # fused RMSNorm of the produced rows (RESADD / POSEMB, N <= 512)
+        p.norm_out, p.norm_ld, p.norm_dtype, p.norm_D = norm_out.data_ptr(), norm_out.shape[-1], _code(norm_out), norm_D
+        p.norm_gamma = _lib.ptr(norm_gamma)
+        p.norm_gb = _lib.ptr(norm_gb)
+        p.norm_gb_ld = 0 if (norm_gb is None or norm_gb_shared) else norm_gb.stride(0)
+        p.norm_gb_half = norm_gb_half
     p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0"))  # ablation switches for tools/gemm_bench.py only
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out

@@ -93,6 +93,14 @@ typedef struct {
                           LDS reads inside the K loop, bit3 no s_setprio), 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start                                    */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
+  /* RESADD / POSEMB with N <= 512 only: when norm_out != NULL one workgroup owns whole output rows and also emits
+   * the NEXT block's RMSNorm of the row it just produced (latent_module.py:620-639, 691, 703):
+   * y = out_row / max(|out_row|, 1e-12) * sqrt(norm_D) [* norm_gamma] [* g + b], pad columns zeroed.            */
+  void* norm_out;          /* [M, norm_ld] in norm_dtype                                             */
+  int32_t norm_ld, norm_dtype, norm_D, norm_gb_ld; /* norm_gb_ld: 0 = one conditioning row for the batch */
+  const float* norm_gamma; /* learned gamma [norm_D] or NULL                                         */
+  const float* norm_gb;    /* adaptive rows [Bc, norm_gb_ld]: gamma at col 0.., beta at norm_gb_half.. or NULL */
+  int32_t norm_gb_half, pad2_;
 } DnGemmParams;
 
 int dn_conv_gemm(const DnGemmParams* p, void* stream);

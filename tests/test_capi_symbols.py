@@ -50,7 +50,8 @@ def test_struct_layout_matches_header(lib, tmp_path):
         "DnGemmParams": (_lib.GemmParams, ["terms", "n_terms", "dtype", "M", "N", "K", "T", "groups", "epilogue", "bias",
                                            "bias_gstride", "out", "ldo", "out_dtype", "out_gstride", "res", "ldr", "res_dtype",
                                            "res_gstride", "gamma_beta", "gb_ld", "gb_half", "gb_gstride", "pos_table", "pos_ld",
-                                           "lengths"]),
+                                           "lengths", "norm_out", "norm_ld", "norm_dtype", "norm_D", "norm_gb_ld", "norm_gamma",
+                                           "norm_gb", "norm_gb_half"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
                                            "dtype", "lengths", "scale"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",

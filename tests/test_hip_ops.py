@@ -165,6 +165,56 @@ def test_geglu_and_resadd_and_posemb(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("D,K,B,T", [(512, 512, 2, 100), (192, 320, 3, 37), (64, 64, 1, 130)])
+def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
+    """Whole-row contraction: residual add + the next block's RMSNorm (adaptive per-sample rows, learned gamma, plain)
+    in one launch (reference latent_module.py:620-639 after :692 / :704), and the POSEMB variant (:867-868 + :691)."""
+    ops_, packing, _lib = ops
+    code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
+    Dp, M = padk(D), B * T
+    rnd = bf16r if dtype == "bf16" else (lambda z: z)
+    a = seeded((B, T, K), 1)
+    w = seeded((D, K), 2, K ** -0.5)
+    bias = seeded((D,), 3, 0.1)
+    xres = seeded((B, T, D), 4)
+    gb = seeded((B, 2 * Dp), 5)
+    gamma = 1 + seeded((D,), 6, 0.1)
+    want_x = xres + torch.nn.functional.linear(rnd(a), rnd(w), bias)
+    tol = 3e-2 if dtype == "bf16" else 2e-5
+    for mode in ("adaptive", "learned", "plain"):
+        xd = pad_cols(xres, Dp).view(M, Dp).to(DEV).contiguous()
+        xn = torch.full((M, Dp), float("nan"), device=DEV, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+        kw = dict(norm_out=xn, norm_D=D)
+        if mode == "adaptive":
+            kw.update(norm_gb=gb.to(DEV), norm_gb_half=Dp)
+            want_n = O.rms_norm(want_x) * gb[:, :D].unsqueeze(1) + gb[:, Dp:Dp + D].unsqueeze(1)
+        elif mode == "learned":
+            kw.update(norm_gamma=gamma.to(DEV))
+            want_n = O.rms_norm(want_x, gamma)
+        else:
+            want_n = O.rms_norm(want_x)
+        ops_.conv_gemm([(act(pad_cols(a, padk(K)).view(M, -1), dtype), packing._mat(w, code).to(DEV), 0)], xd, T, Dp,
+                       bias=packing._vec(bias, Dp).to(DEV), epilogue=_lib.EPI_RESADD, res=xd, **kw)
+        assert maxerr(xd.cpu().view(B, T, Dp)[..., :D], want_x) < (2e-4 if dtype == "bf16" else 1e-4)
+        got_n = xn.float().cpu().view(B, T, Dp)
+        assert maxerr(got_n[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
+        assert got_n[..., D:].abs().max().item() == 0 if Dp > D else True
+    # positional-embedding variant
+    lens = torch.tensor([T] + [max(1, T // 2)] * (B - 1))
+    mask = O.lengths_to_mask(lens, T)
+    want_x = torch.nn.functional.linear(rnd(a), rnd(w), bias) + O.positional_embedding(mask, D)
+    tab = packing.sinusoidal_table(T + 1, D, Dp).to(DEV)
+    xd = torch.empty(M, Dp, device=DEV)
+    xn = torch.empty(M, Dp, device=DEV, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+    ops_.conv_gemm([(act(pad_cols(a, padk(K)).view(M, -1), dtype), packing._mat(w, code).to(DEV), 0)], xd, T, Dp,
+                   bias=packing._vec(bias, Dp).to(DEV), epilogue=_lib.EPI_POSEMB, pos_table=tab, lengths=lens.to(DEV).int(),
+                   norm_out=xn, norm_D=D, norm_gb=gb.to(DEV), norm_gb_half=Dp)
+    assert maxerr(xd.cpu().view(B, T, Dp)[..., :D], want_x) < (2e-4 if dtype == "bf16" else 1e-4)
+    want_n = O.rms_norm(want_x) * gb[:, :D].unsqueeze(1) + gb[:, Dp:Dp + D].unsqueeze(1)
+    assert maxerr(xn.float().cpu().view(B, T, Dp)[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("heads,dh,B,T,lens", [(8, 64, 2, 200, [200, 77]), (8, 96, 1, 130, [101]), (4, 16, 3, 40, [40, 1, 23]),
                                                (2, 32, 2, 64, [64, 0])])
 def test_attention(ops, dtype, heads, dh, B, T, lens):
