@@ -41,6 +41,19 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t lds_addr) {
       : "memory");
 }
 
+// Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): pieces that differ only
+// by a uniform row offset share one offset VGPR.
+__device__ __forceinline__ void glds16_s(uint32_t voff, uint64_t sbase, uint32_t lds_addr) {
+  uint32_t keep;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbase), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32));
+  const uint64_t base = ((uint64_t)hi << 32) | lo;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(base), "s"(lds_addr)
+      : "memory");
+}
+
 // wait until at most N of this wave's LDS-DMA pieces are outstanding, then workgroup barrier; one asm
 // statement with a memory clobber so no ds_read of the tile is scheduled above it.
 template <int N>
@@ -73,7 +86,8 @@ __device__ __forceinline__ float4 load4t(const void* base, int64_t off) {
 
 // OUT_BF / RES_BF: storage types fixed at compile time; FULL: every row of the slab is inside M (no per-row guards).
 template <int EPI, bool OUT_BF, bool RES_BF, bool FULL>
-__device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
+__device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
+                                                   int ncols) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (OUT_BF ? 2 : 4);
   if constexpr (EPI == DN_EPI_GEGLU) {
@@ -97,7 +111,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
   } else {
     const int c4 = (lane & 15) * 4;
     const int n = n_base + c4;
-    if (n >= p.N) return;
+    if (n >= p.N || c4 >= ncols) return;  // ncols < 64: only the slab's first columns carry this wave's outputs
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
     // The side inputs of a row (residual, FiLM gamma/beta, positional row) are global loads; issued inside the
     // per-row loop each would sit behind the previous row's store (the compiler must assume `out` aliases them) and
@@ -182,12 +196,13 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
 }
 
 template <int EPI>
-__device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane) {
+__device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
+                                              int ncols = 64) {
   const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
   const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
-#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane)
+#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols)
   if constexpr (RESADD) {
     if (full) DN_EP(false, false, true); else DN_EP(false, false, false);
   } else if constexpr (EPI == DN_EPI_FILM_GATE) {
@@ -774,6 +789,269 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
   }
 }
 
+// ------------------------------------------------------------------------------------------ 256 x 352 "fat" tile
+// The FFN's causal conv (N = K/3 = 1408 padded inner width) is 45 % of a denoising step's FLOPs, and 1408 = 4 x 352:
+// a 256 (rows) x 352 (columns) tile covers [16384 x 1408] with exactly 64 x 4 = 256 workgroups -- one round on the 256
+// CUs with no ragged last column tile (the 256 x 256 tiling needs 384 workgroups = 1.5 rounds and pads N to 1536).
+// Four waves, ONE PER SIMD, each a 128 (m) x 176 (n) sub-tile = 88 accumulator tiles (352 registers of the 512 a lone
+// wave may use): per 32-deep K-tile a wave issues 88 MFMAs against 19 fragment reads and ~10 DMA pieces, so the LDS and
+// the L2->LDS path run at a fraction of their rates and the MFMA pipe is the only busy resource.  With no partner wave
+// the overlap is inside the instruction stream: weight fragments stream one n-tile ahead of the MFMAs that use them,
+// the next K-tile's activation fragments are fetched under the last two n-tiles, the DMA runs three K-tiles ahead in
+// a 4-stage 152 KiB ring, and there is one barrier per K-tile, placed mid-stream.
+// 88 accumulator tiles are 352 registers: more than the 256 AGPRs.  The compiler keeps every MFMA accumulator of a
+// function in one register class and would shuttle the overflow through spare AGPRs (accvgpr moves + MFMA-result
+// nops on the critical path), so the tiles are pinned by hand: n-tiles 0..7 (64 tiles) in AGPRs, n-tiles 8..10
+// (24 tiles) in ordinary VGPRs, each MFMA written with the matching constraint.  Hazards the compiler can no longer
+// see: an accumulator is touched once per K-tile (88 MFMAs apart), operands come from LDS behind s_waitcnt, and the
+// epilogue's first read is separated from the last MFMA by explicit s_nops.
+//
+// The K loop of that kernel is scheduled by hand as well.  A lone wave hides LDS latency only inside its own
+// instruction stream; the compiler's s_waitcnt placement drains the LDS queue at the loop header (it cannot prove what
+// is pending across the back edge), which exposes a full loaded-LDS latency per K-tile.  So the fragment reads are
+// inline asm too (the compiler then tracks nothing), every use is preceded by an explicit counted s_waitcnt that
+// carries the registers it guards as in/out operands (a true dependence: no consumer can be moved above it), and all
+// of these statements are `volatile`, which keeps them in program order.  LDS returns data in order, so "at most N
+// younger requests outstanding" is exact; a pending scalar load only makes a wait longer, never shorter.
+#ifndef DN_FAT_ABL
+#define DN_FAT_ABL 0
+#endif
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+template <bool IN_AGPR>
+__device__ __forceinline__ void mma_pinned_bf16(f32x4& acc, const u32x4& w, const u32x4& a) {
+  if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+
+template <int OFFSET>
+__device__ __forceinline__ void lds_request(u32x4& dst, uint32_t addr) {
+  static_assert(OFFSET >= 0 && OFFSET < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFSET));
+}
+
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& r) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
+}
+__device__ __forceinline__ void lds_wait_all_but(std::integral_constant<int, 2>) { asm volatile("s_waitcnt lgkmcnt(2)"); }
+// register copy that stays behind the wait above it (a plain C++ copy could be scheduled ahead of the wait and read a
+// register whose LDS data is still in flight)
+__device__ __forceinline__ void copy_after_wait(u32x4& dst, const u32x4& src) {
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.x) : "v"(src.x));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.y) : "v"(src.y));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.z) : "v"(src.z));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.w) : "v"(src.w));
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <typename E, int EPI>
+__global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
+  static_assert(std::is_same<E, BF16>::value, "the 256 x 352 tile is built for bf16 operands only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int KT = ROWB2 / ES;
+  constexpr int BMF = 256, BNF = 352, STAGES = 4;
+  constexpr int W_BYTES = BNF * ROWB2, A_BYTES = BMF * ROWB2, STAGE_BYTES = W_BYTES + A_BYTES;  // 22528 + 16384
+  constexpr int PER = 10;  // DMA pieces per wave per stage: 4 of the 16 row pieces, 6 of the 22 weight pieces (2 waves repeat one)
+  constexpr int NT = 11, MT = 8;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.y;
+  const int n_tiles_n = p.N / BNF;
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (logical / n_tiles_n) * BMF;
+  const int n0 = (logical % n_tiles_n) * BNF;
+
+  // ---- staging: 16-row x 64-byte pieces; wave w takes row pieces 4w..4w+3 and weight pieces w, w+4, .., (w+20 or 21).
+  // Weight pieces differ by a uniform row offset: one per-lane 32-bit offset + a scalar base per piece (saddr form).
+  // Row pieces keep per-lane 64-bit pointers (a lane whose frame precedes the sequence start reads the zero page).
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+  const int ktiles_per_term = p.K / KT;
+  const int nkt = p.n_terms * ktiles_per_term;
+  const char* a_ptr[4];
+  int a_inc[4];
+  uint32_t w_voff = 0;
+  uint64_t w_base = 0;  // uniform: term weight base + tile's first row
+  int s_term = 0, s_kk = 0;
+  auto setup_term = [&](int term) {
+    const DnGemmTerm& tm = p.terms[term];
+    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + (wave * 4 + i) * 16 + srow;
+      m = m < p.M ? m : p.M - 1;
+      const bool valid = (m % p.T) >= shift;
+      a_ptr[i] = valid ? A + (int64_t)(m - shift) * tm.lda * ES : zero_src;
+      a_inc[i] = valid ? ROWB2 : 0;
+    }
+    w_base = (uint64_t)(uintptr_t)tm.W + ((uint64_t)tm.w_gstride * g + (uint64_t)n0 * p.K) * ES;
+    w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
+  const uint64_t piece_stride = (uint64_t)16 * p.K * ES;
+  // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces
+  auto stage_piece = [&](auto i_c, int slot) {
+    constexpr int i = decltype(i_c)::value;
+    const uint32_t sbase = lds_base + slot * STAGE_BYTES;
+    if constexpr (i < 6) {
+      int pc = wave + 4 * i;
+      pc = pc < 22 ? pc : 21;  // waves 2, 3 repeat the last piece: every wave issues PER pieces
+      glds16_s(w_voff, w_base + pc * piece_stride, sbase + pc * 1024);
+    } else {
+      glds16(a_ptr[i - 6], sbase + W_BYTES + (wave * 4 + i - 6) * 1024);
+    }
+  };
+  auto stage_advance = [&]() {
+    if (++s_kk == ktiles_per_term) {
+      s_kk = 0;
+      if (++s_term < p.n_terms) setup_term(s_term);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
+      w_voff += ROWB2;
+    }
+  };
+  auto stage = [&](int slot) {
+    static_for<PER>([&](auto i_c) { stage_piece(i_c, slot); });
+    stage_advance();
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
+  const uint32_t w_rd = lds_base + (wn * 176 + frow) * ROWB2 + coff;            // + slot * STAGE_BYTES + nt * 1024
+  const uint32_t a_rd = lds_base + W_BYTES + (wm * 128 + frow) * ROWB2 + coff;  // + slot * STAGE_BYTES + mt * 1024
+
+  // One K-tile = 11 n-tiles of 8 MFMAs.  With the LDS ~2/3 busy (76 KiB of fragment reads + 38 KiB of DMA writes per
+  // K-tile) its latency is several hundred cycles, so every fragment is requested long before its first use:
+  //   * weight fragments run TWO n-tiles (256 MFMA cycles) ahead: fragments 0 and 1 of a K-tile live in wa / wb
+  //     (requested under n-tiles 9 and 10 of the previous K-tile), fragments 2..10 rotate through the ring wr[3]
+  //     (9 = 3 x 3 uses, so the ring phase is the same in every K-tile and every register index is a constant);
+  //   * the next K-tile's 8 activation fragments are requested one per n-tile under n-tiles 1..8 into `nxt` and
+  //     copied to `cur` at the top of the next K-tile, two n-tiles after the last request.
+  // Requests per n-tile, in order: [weight fragment nt+2] [nxt[nt-1] if 1 <= nt <= 8]; the counted waits below follow.
+  // The barrier sits before n-tile 1, the first point that touches tile kt+1:
+  //   RAW: tile kt+1 is read only after every wave's counted vmcnt for it and that barrier.
+  //   WAR: the DMA of tile kt+3 reuses the slot of tile kt-1 and is issued after the barrier of iteration kt, which
+  //        every wave reaches only after it has finished iteration kt-1.
+  // (After the last K-tile the cross-tile requests read a stale slot; the values are never used.)
+  u32x4 wa, wb, wr[3], cur[MT], nxt[MT];
+  auto ktile = [&](int kt, int slot) {
+    const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
+    const uint32_t w_cur = w_rd + slot * STAGE_BYTES, w_nxt = w_rd + nslot * STAGE_BYTES, a_nxt = a_rd + nslot * STAGE_BYTES;
+    lds_wait_all_but(std::integral_constant<int, 2>{});  // younger than nxt[7]: wa, wb
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) copy_after_wait(cur[mt], nxt[mt]);
+    static_for<NT>([&](auto nt_c) {
+      constexpr int nt = decltype(nt_c)::value;
+      if constexpr (nt == 1) {
+        if (kt + 2 < nkt) pipe_sync<PER>(); else pipe_sync<0>();
+      }
+      // the DMA of tile kt+3 into the slot tile kt-1 lived in: one piece per n-tile (a piece costs the wave ~60+ issue
+      // cycles during which its MFMA pipe drains; bunched pieces also queue behind each other in the address path)
+      if constexpr (nt >= 1) {
+        if (kt + 3 < nkt && !(DN_FAT_ABL & 1)) {
+          stage_piece(std::integral_constant<int, nt - 1>{}, slot == 0 ? STAGES - 1 : slot - 1);
+          if constexpr (nt == PER) stage_advance();
+        }
+      }
+      if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
+      else if constexpr (nt + 2 == NT) lds_request<0>(wa, w_nxt);
+      else lds_request<1024>(wb, w_nxt);
+      if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
+      // requests younger than this n-tile's weight fragment
+      constexpr int younger = 2 + (nt >= 3 ? 1 : 0) + (nt >= 2 && nt <= 9 ? 1 : 0) + (nt >= 1 && nt <= 8 ? 1 : 0);
+      u32x4& w = [&]() -> u32x4& {
+        if constexpr (nt == 0) return wa;
+        else if constexpr (nt == 1) return wb;
+        else return wr[(nt - 2) % 3];
+      }();
+      lds_wait<younger>(w);
+#pragma unroll
+      for (int mt = 0; mt < ((DN_FAT_ABL & 2) ? 1 : MT); ++mt) {
+        if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
+        else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
+      }
+    });
+  };
+
+#ifdef DN_FAT_STAMPS  // diagnostic build only (tools/fat_clock.py): in-kernel clock and K-loop cycles
+  const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  setup_term(0);
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nkt) stage(st);
+  if (nkt > 2) pipe_sync<2 * PER>(); else if (nkt > 1) pipe_sync<PER>(); else pipe_sync<0>();
+#ifdef DN_FAT_STAMPS
+  const uint64_t dbg_c1 = __builtin_readcyclecounter();
+#endif
+  static_for<MT>([&](auto mt_c) { lds_request<decltype(mt_c)::value * 1024>(nxt[decltype(mt_c)::value], a_rd); });
+  lds_request<0>(wa, w_rd);
+  lds_request<1024>(wb, w_rd);
+  {
+    int slot = 0, kt = 0;
+    auto next = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; return ++kt < nkt; };
+    do ktile(kt, slot); while (next());
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA results land before the epilogue reads them
+#ifdef DN_FAT_STAMPS
+  const uint64_t dbg_c2 = __builtin_readcyclecounter();
+#endif
+  __syncthreads();
+#ifdef DN_FAT_STAMPS
+  if ((p.pad_ & (1 << 20)) && tid == 0) {  // stamps go to a buffer of their own (pos_table is unused by this epilogue)
+    uint64_t* d = reinterpret_cast<uint64_t*>(const_cast<float*>(p.pos_table)) + 4 * (blockIdx.x + gridDim.x * blockIdx.y);
+    d[0] = dbg_c1 - dbg_c0; d[1] = dbg_c2 - dbg_c1; d[2] = __builtin_amdgcn_s_memrealtime() - dbg_r0; d[3] = dbg_r0;
+  }
+#endif
+
+  // ---- epilogue: the 128 x 176 sub-tile as 2 x 3 slabs of 64 x 64 (the third carries 48 columns)
+  float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+  auto slab = [&](auto mh_c, auto nh_c) {
+    constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
+    constexpr int NTS = NH == 2 ? 3 : 4;  // n-tiles in this slab
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTS; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[NH * 4 + nt][MH * 4 + mt];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + MH * 64, n0 + wn * 176 + NH * 64, g, lane, NTS * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+}
+
 // In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
 // around every dn_conv_gemm whose tag (bits 8..15 of DnGemmParams.pad_) matches.  Eager launches only.
 struct LaunchProfile {
@@ -839,17 +1117,44 @@ static int launch_row(const DnGemmParams& p, hipStream_t s) {
 }
 
 template <typename E, int EPI>
+static int launch_fat(const DnGemmParams& p, hipStream_t s) {
+  constexpr int ring = 4 * (352 + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
+  constexpr int lds = ring > slabs ? ring : slabs;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  dim3 grid(((p.M + 255) / 256) * (p.N / 352), p.groups);
+  const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI>), grid, dim3(256), lds, s, p);
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
+  DN_CHECK_LAUNCH("dn_conv_gemm (fat tile)");
+  return DN_OK;
+}
+
+template <typename E, int EPI>
 static int launch(const DnGemmParams& p, hipStream_t s) {
   if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
     if (p.norm_out) return launch_row<E, EPI>(p, s);
   }
+  // Tile variant: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests) force one, 0 = choose by shape.
+  static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
+  const int force = ((p.pad_ >> 16) & 15) ? ((p.pad_ >> 16) & 15) : env_tile;
+  if constexpr (EPI == DN_EPI_BIAS && std::is_same<E, BF16>::value) {
+    // the 256 x 352 one-wave-per-SIMD tile: bf16, N a multiple of 352 and at least ~half a chip of tiles (a workgroup owns a CU's whole LDS;
+    // measured +2.5 % per denoising step on half batches, +5 % on whole ones, against the 256 x 256 tile)
+    const long tiles_fat = (long)((p.M + 255) / 256) * (p.N / 352) * p.groups;
+    if (p.N % 352 == 0 && (force == 4 || (force == 0 && tiles_fat >= 100))) return launch_fat<E, EPI>(p, s);
+  }
   // 256 x 256 tiles when they still cover the chip (>= ~1.4 workgroups per CU or an exact fit), 256 x 128 tiles
-  // while those give every CU a workgroup, 128 x 128 tiles for small problems.  DN_GEMM_TILE forces a variant.
+  // while those give every CU a workgroup, 128 x 128 tiles for small problems.
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   const long mt256 = (p.M + 255) / 256;
   const long tiles_big = mt256 * ((np + 255) / 256) * p.groups;
   const long tiles_mid = mt256 * ((np + BN - 1) / BN) * p.groups;
-  static const int force = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
   if (force == 3 || (force == 0 && tiles_big >= 360)) return launch_big<E, EPI>(p, s);
   if (force == 2 || (force == 0 && tiles_mid >= 192)) return launch_tile<E, EPI, 256, 3>(p, s);
   return launch_tile<E, EPI, 128, 2>(p, s);

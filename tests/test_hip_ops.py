@@ -79,6 +79,34 @@ def test_causal_conv_gemm(ops, dtype, cin, cout, k, dil, B, T):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (128, 1056, 1, 1, 1, 515),
+                                                (64, 352, 1, 1, 2, 130), (1408, 1408, 3, 1, 4, 512)])
+def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil, B, T):
+    """The same causal conv through each forced tile variant (128x128, 256x128, 256x256, 256x352): ragged M,
+    N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term (pipeline prologue/drain edges)."""
+    ops_, packing, _lib = ops
+    code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
+    x = seeded((B, T, cin), 11)
+    w = seeded((cout, cin, k), 12, (1.0 / (cin * k)) ** 0.5)
+    b = seeded((cout,), 13, 0.1)
+    N = (cout + 31) // 32 * 32
+    assert N % 352 == 0
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), dtype)
+    W = packing._conv(w, code).to(DEV)
+    assert W.shape[1] >= N
+    out = torch.full((B * T, N), float("nan"), device=DEV)
+    bias = packing._vec(b, W.shape[1]).to(DEV)
+    terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
+    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=tile)
+    got = out.cpu().view(B, T, -1)
+    if dtype == "bf16":
+        assert maxerr(got, O.causal_conv1d(bf16r(x), bf16r(w), b, dil)) < 2e-4
+    else:
+        assert maxerr(got, O.causal_conv1d(x, w, b, dil)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wavenet_block_group_film_gate(ops, dtype):
     """Grouped dilated conv + FiLM + tanh*sigmoid + residual (reference latent_module.py:513-536)."""
     ops_, packing, _lib = ops
