@@ -23,6 +23,15 @@ inline int esize(int dtype) { return dtype == DN_BF16 ? 2 : 4; }
     if (rc__ != DN_OK) return rc__; \
   } while (0)
 
+// The residual-closing contractions can also emit the next block's RMSNorm (64 x 512 whole-row tile, dn_conv_gemm's
+// norm_out).  Measured on [32,512] x dim 512 it loses to 256 x 128 tiles + a standalone norm kernel (one workgroup
+// re-reads the whole weight for 64 rows): 6.85 vs 6.63 ms per denoising step.  Off unless DN_FUSE_NORM=1.
+inline bool fuse_norm_enabled(int Dp) {
+  const char* e = getenv("DN_FUSE_NORM");  // read per call: tests toggle it
+  const bool on = e && atoi(e) != 0;
+  return on && Dp <= 512;
+}
+
 DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
   DnGemmParams p;
   memset(&p, 0, sizeof(p));
@@ -154,7 +163,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
                     const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
   const int es = esize(dtype), M = B * T;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
-  const bool fuse = Dp <= 512 && !getenv("DN_NO_FUSE_NORM");  // (the switch exists for A/B timing only)
+  const bool fuse = fuse_norm_enabled(Dp);
   auto standalone_norm = [&](int l, int j) -> int {
     const NormSrc ns = norm_src(w, gb, l, j);
     return dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, ns.gamma, ns.gb, gb_ld, Dp, s);
@@ -359,13 +368,13 @@ int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const i
     DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
     fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
-    const bool fuse_norm = Dp <= 512 && !getenv("DN_NO_FUSE_NORM");
+    const bool fuse_norm = fuse_norm_enabled(Dp);
     if (fuse_norm)  // layer 0's attention norm rides on the contraction that opens the residual stream
       set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp, gb_ld);
     DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, gb, gb_ld, b.wv, fin, s));
   }
   const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, Dp <= 512 && !getenv("DN_NO_FUSE_NORM"), s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, fuse_norm_enabled(Dp), s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;

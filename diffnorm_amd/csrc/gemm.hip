@@ -1149,14 +1149,31 @@ static int launch(const DnGemmParams& p, hipStream_t s) {
     const long tiles_fat = (long)((p.M + 255) / 256) * (p.N / 352) * p.groups;
     if (p.N % 352 == 0 && (force == 4 || (force == 0 && tiles_fat >= 100))) return launch_fat<E, EPI>(p, s);
   }
-  // 256 x 256 tiles when they still cover the chip (>= ~1.4 workgroups per CU or an exact fit), 256 x 128 tiles
-  // while those give every CU a workgroup, 128 x 128 tiles for small problems.
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
-  const long mt256 = (p.M + 255) / 256;
+  const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
   const long tiles_big = mt256 * ((np + 255) / 256) * p.groups;
   const long tiles_mid = mt256 * ((np + BN - 1) / BN) * p.groups;
-  if (force == 3 || (force == 0 && tiles_big >= 360)) return launch_big<E, EPI>(p, s);
-  if (force == 2 || (force == 0 && tiles_mid >= 192)) return launch_tile<E, EPI, 256, 3>(p, s);
+  const long tiles_small = mt128 * ((np + BN - 1) / BN) * p.groups;
+  if (force == 3) return launch_big<E, EPI>(p, s);
+  if (force == 2) return launch_tile<E, EPI, 256, 3>(p, s);
+  if (force == 1) return launch_tile<E, EPI, 128, 2>(p, s);
+  // Choose by how evenly the tiles fill the 256 CUs: score = (throughput of the variant on a full chip, relative)
+  // x (rounds / ceil(rounds)), rounds = tiles / (CUs x workgroups that share a CU).  The 256 x 256 and 256 x 128
+  // rings own a CU's LDS (one workgroup per CU); two 128 x 128 workgroups share one and cover each other's
+  // prologue and epilogue, which is what the short-K contractions (K = 512: 8 K-tiles) are made of.
+  static const int heur = getenv("DN_GEMM_HEUR") ? atoi(getenv("DN_GEMM_HEUR")) : 1;
+  if (heur == 0) {  // previous rule, kept for A/B timing
+    if (tiles_big >= 360) return launch_big<E, EPI>(p, s);
+    if (tiles_mid >= 192) return launch_tile<E, EPI, 256, 3>(p, s);
+    return launch_tile<E, EPI, 128, 2>(p, s);
+  }
+  auto fill = [](long tiles, int per_cu) {
+    const double rounds = (double)tiles / (256.0 * per_cu);
+    return rounds / ceil(rounds);
+  };
+  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = 0.92 * fill(tiles_small, 2);
+  if (s_big >= s_mid && s_big >= s_small) return launch_big<E, EPI>(p, s);
+  if (s_mid > s_small) return launch_tile<E, EPI, 256, 3>(p, s);
   return launch_tile<E, EPI, 128, 2>(p, s);
 }
 

@@ -54,6 +54,30 @@ def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
         assert maxerr(got[mask], ref[mask]) < 0.3
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
+    """DN_FUSE_NORM=1 routes the residual-closing contractions through the whole-row tile that also emits the next
+    block's RMSNorm (off by default: slower at dim 512): same golden, and the same numbers as the default path."""
+    engine, _ = eng
+    g = golden("eps_tiny")
+    sd = O.make_eps_state_dict(TINY_EPS, "tiny")
+    e = engine.EpsEngine(sd, TINY_EPS, dtype=dtype, device=DEV)
+    x, t, lens = T_(g["x"]), T_(g["t"]), T_(g["lens"])
+    base = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
+    monkeypatch.setenv("DN_FUSE_NORM", "1")
+    got = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
+    monkeypatch.delenv("DN_FUSE_NORM")
+    mask = O.lengths_to_mask(lens, x.shape[1])
+    ref = T_(g["eps"])
+    if dtype == "f32":
+        assert maxerr(got[mask], ref[mask]) < tol
+        assert maxerr(got, base) < 1e-4
+    else:
+        assert maxerr(got[0][mask[0]], ref[0][mask[0]]) < tol
+        assert ((got - ref)[mask] ** 2).mean().item() < 1e-3
+        assert ((got - base)[mask] ** 2).mean().item() < 1e-3
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_eps_properties(eng, dtype):
     """Reference properties: valid frames are invariant to the content of right-padded frames,

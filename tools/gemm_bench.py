@@ -6,7 +6,7 @@ import torch
 from diffnorm_amd import _lib, ops, packing
 
 dev = torch.device("cuda:0")
-B, T = 32, 512
+B, T = int(os.environ.get("DN_BENCH_B", "32")), 512
 M = B * T
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 
