@@ -211,7 +211,7 @@ def main():
             "frame_steps_per_s": world * K * B * T / dt,
             "step_tflops": step_flops * K / dt / 1e12,
             "step_mfma_frac": step_flops * K / dt / 1e12 / peak,
-            "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel<{args.dtype}, BIAS> FFN causal conv k=3 "
+            "roofline": {"bound": "mfma", "kernel": f"{'conv_gemm_fat_kernel' if args.dtype == 'bf16' else 'conv_gemm_big_kernel'}<{args.dtype}, BIAS> FFN causal conv k=3 "
                                                     f"[{B * T} x 4095] x [4095 x 1365]",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "launches_timed": n_l.value,
