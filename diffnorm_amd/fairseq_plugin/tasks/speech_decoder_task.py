@@ -1,41 +1,15 @@
 """`--task speech_decoder` (reference fairseq/tasks/speech_decoder_task.py:33-259): unit dictionary, model /
 criterion construction and the train / valid step contract around the HIP-backed models.
 
-Dataset readers (npy feature manifests + unit TSVs) are scope row f1 and not built; `load_dataset` serves the
-synthetic (feat, unit) pairs the BASELINE configs use.  `train_step` runs the forward (the loss dict is real);
+`load_dataset` reads the reference's manifests (`diffnorm_amd.data`: `{feat_dir}/{split}.manifest.tsv` + `{data}/{split}.tsv`)
+when `--src-feat-dir/--tgt-feat-dir` are given, else serves the synthetic (feat, unit) pairs the BASELINE configs
+use.  `train_step` runs the forward (the loss dict is real);
 backward kernels are scope row f2, so it raises unless `ignore_grad` is set.
 """
 import torch
 
+from ...data import ReprToReprUnitDataset, UnitDictionary
 from ..registry import MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY, CRITERION_REGISTRY, FairseqTask, register_task
-
-
-class UnitDictionary:
-    """fairseq Dictionary for discrete units: 4 specials (<s>, <pad>, </s>, <unk>) + units "0".."N-1"
-    (reference fairseq/data/dictionary.py:20-40, speech_decoder_task.py:132-155) -> len = N + 4, unit u -> index u + 4."""
-
-    def __init__(self, n_units: int):
-        self.symbols = ["<s>", "<pad>", "</s>", "<unk>"] + [str(i) for i in range(n_units)]
-        self.indices = {s: i for i, s in enumerate(self.symbols)}
-        self.bos_index, self.pad_index, self.eos_index, self.unk_index = 0, 1, 2, 3
-
-    def __len__(self):
-        return len(self.symbols)
-
-    def pad(self):
-        return self.pad_index
-
-    def unk(self):
-        return self.unk_index
-
-    def eos(self):
-        return self.eos_index
-
-    def index(self, sym):
-        return self.indices.get(sym, self.unk_index)
-
-    def string(self, tensor):
-        return " ".join(self.symbols[int(i)] for i in tensor)
 
 
 class SyntheticReprUnitDataset(torch.utils.data.Dataset):
@@ -114,6 +88,12 @@ class _SpeechTaskBase(FairseqTask):
         return getattr(self.args, "max_source_positions", 6000), getattr(self.args, "max_target_positions", 1024)
 
     def load_dataset(self, split, epoch=1, combine=False, **kwargs):
+        src_dir, tgt_dir = getattr(self.args, "src_feat_dir", None), getattr(self.args, "tgt_feat_dir", None)
+        if src_dir and tgt_dir:  # reference speech_decoder_task.py:161-173
+            self.datasets[split] = ReprToReprUnitDataset.from_tsv(src_dir, tgt_dir, self.args.data, split,
+                                                                  is_train_split=split.startswith("train"),
+                                                                  tgt_dict=self.tgt_dict, shuffle=True)
+            return self.datasets[split]
         n = kwargs.get("n", 64)
         self.datasets[split] = SyntheticReprUnitDataset(n, kwargs.get("min_len", 64), kwargs.get("max_len", 512),
                                                         vocab=len(self.tgt_dict), seed=hash(split) % 1000)

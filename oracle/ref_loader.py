@@ -101,3 +101,46 @@ def load_reference():
     spec.loader.exec_module(gd)
     _CACHE["lm"], _CACHE["gd"] = lm, gd
     return lm, gd
+
+
+def load_reference_dataset():
+    """Returns the reference's fairseq/data/audio/repr_to_repr_unit_dataset.py module and its real Dictionary class
+    (SURVEY 8 f1).  The module's audio-pipeline imports (waveform/feature transforms, S2T dataset helpers) are not on
+    the path and are replaced by empty stand-in names; the dataset logic itself runs as it lies."""
+    if "ds" in _CACHE:
+        return _CACHE["ds"], _CACHE["dict"]
+    load_reference()
+    for name, rel in (("fairseq.file_io", "fairseq/file_io.py"), ("fairseq.tokenizer", "fairseq/tokenizer.py"),
+                      ("fairseq.file_chunker_utils", "fairseq/file_chunker_utils.py")):
+        _load(name, rel)
+    fd = _pkg("fairseq.data")
+    fd.data_utils = _load("fairseq.data.data_utils", "fairseq/data/data_utils.py")
+    fd.Dictionary = _load("fairseq.data.dictionary", "fairseq/data/dictionary.py").Dictionary
+    fd.FairseqDataset = _load("fairseq.data.fairseq_dataset", "fairseq/data/fairseq_dataset.py").FairseqDataset
+    fd.ConcatDataset = type("ConcatDataset", (), {})
+    _pkg("fairseq.data.audio")
+
+    class _NoTransform:
+        @classmethod
+        def from_config_dict(cls, cfg):
+            return None
+
+    def stub(modname, **names):
+        m = types.ModuleType(modname)
+        for k, v in names.items():
+            setattr(m, k, v)
+        sys.modules[modname] = m
+
+    blank = lambda n: type(n, (), {})
+    stub("fairseq.data.audio.audio_utils", get_features_or_waveform=None)
+    stub("fairseq.data.audio.data_cfg", S2SDataConfig=blank("S2SDataConfig"))
+    stub("fairseq.data.audio.speech_to_text_dataset", SpeechToTextDataset=blank("SpeechToTextDataset"),
+         SpeechToTextDatasetCreator=blank("SpeechToTextDatasetCreator"), TextTargetMultitaskData=blank("TextTargetMultitaskData"),
+         _collate_frames=None, _is_int_or_np_int=None)
+    stub("fairseq.data.audio.feature_transforms", CompositeAudioFeatureTransform=_NoTransform)
+    stub("fairseq.data.audio.waveform_transforms", CompositeAudioWaveformTransform=_NoTransform)
+    stub("fairseq.data.audio.dataset_transforms", CompositeAudioDatasetTransform=_NoTransform)
+    stub("fairseq.data.audio.speech_to_speech_dataset", SpeechToSpeechDataset=blank("SpeechToSpeechDataset"))
+    ds = _load("fairseq.data.audio.repr_to_repr_unit_dataset", "fairseq/data/audio/repr_to_repr_unit_dataset.py")
+    _CACHE["ds"], _CACHE["dict"] = ds, fd.Dictionary
+    return ds, fd.Dictionary
