@@ -143,10 +143,18 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
+    if world > 1:
+        # RCCL ("nccl") is the contract; DN_BENCH_BACKEND=gloo only rehearses the N > 1 control flow with several ranks
+        # sharing one GPU (RCCL refuses duplicate devices).  The data path has no collective either way.
+        backend = os.environ.get("DN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from diffnorm_amd import _lib, engine, ops, packing, scheduler, synthetic
 
@@ -181,7 +189,7 @@ def main():
         assert n == K
         assert torch.isfinite(x).all().item(), "state diverged"
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
@@ -209,7 +217,7 @@ def main():
                        "batch_per_gpu": B, "frames": T, "latent_dim": cfg.latent_dim, "timesteps": args.timesteps,
                        "hip_graph": not args.no_graph, "half_batch_streams": 1 if args.no_split else 2, "parallelism": f"batch-sharded x{world} (no collective)"},
             "frame_steps_per_s": world * K * B * T / dt,
-            "step_tflops": step_flops * K / dt / 1e12,
+            "step_tflops_per_gpu": step_flops * K / dt / 1e12,
             "step_mfma_frac": step_flops * K / dt / 1e12 / peak,
             "roofline": {"bound": "mfma", "kernel": f"{'conv_gemm_fat_kernel' if args.dtype == 'bf16' else 'conv_gemm_big_kernel'}<{args.dtype}, BIAS> FFN causal conv k=3 "
                                                     f"[{B * T} x 4095] x [4095 x 1365]",
