@@ -852,7 +852,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <typename E, int EPI>
+template <typename E, int EPI, bool TAPS_INNER>
 __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
   static_assert(std::is_same<E, BF16>::value, "the 256 x 352 tile is built for bf16 operands only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -881,20 +881,27 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   // ---- staging: 16-row x 64-byte pieces; wave w takes row pieces 4w..4w+3 and weight pieces w, w+4, .., (w+20 or 21).
   // Weight pieces differ by a uniform row offset: one per-lane 32-bit offset + a scalar base per piece (saddr form).
   // Row pieces keep per-lane 64-bit pointers (a lane whose frame precedes the sequence start reads the zero page).
+  //
+  // K-tile order.  General case: term-outer (all K-tiles of term 0, then term 1, ..).  When the terms are the taps of
+  // ONE causal conv (same activation tensor; launch_fat picks the TAPS_INNER instantiation) the order is tap-inner: K-tile n is tap
+  // n % n_terms of K-chunk n / n_terms, so the three taps read (nearly) the same activation rows back to back and the
+  // XCD's L2 serves two of the three reads; term-outer re-fetches the XCD's 5.8 MB activation panel through the
+  // fabric once per tap (measured 234 MB of fabric reads per FFN-conv launch = 3 x 46 MB + 8 XCDs x 11.9 MB of weights).
   const int srow = lane >> 2;
   const int schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
   const int ktiles_per_term = p.K / KT;
   const int nkt = p.n_terms * ktiles_per_term;
-  const char* a_ptr[4];
-  int a_inc[4];
+  constexpr bool taps_inner = TAPS_INNER;  // compile-time: a uniform branch in this K loop costs the lone wave ~20 cycles
+  const char* a_ptr[4];  // term-outer: this term's (shifted) row; tap-inner: the unshifted row
+  int a_inc[4];          // term-outer: 64 or 0 (zero page); tap-inner: the row's frame index m % T
   uint32_t w_voff = 0;
-  uint64_t w_base = 0;  // uniform: term weight base + tile's first row
+  uint64_t w_base = 0;   // uniform: term weight base + tile's first row (term-outer)
   int s_term = 0, s_kk = 0;
+  const char* const zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
     const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
-    const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int m = m0 + (wave * 4 + i) * 16 + srow;
@@ -906,6 +913,32 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     w_base = (uint64_t)(uintptr_t)tm.W + ((uint64_t)tm.w_gstride * g + (uint64_t)n0 * p.K) * ES;
     w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
   };
+  // tap-inner: the per-tap uniforms are affine in the tap index (launch_fat checks it: shift_t = shift_0 - t * step,
+  // W_t = W_0 + t * stride), so they are carried as running scalars -- no per-tap table (a table indexed by the
+  // run-time tap index would live in scratch, whose loads share vmcnt with the DMA)
+  int tap_shift = 0, tap_shift0 = 0, tap_sstep = 0;
+  uint32_t tap_delta = 0, tap_delta0 = 0, tap_dstep = 0;  // bytes between the unshifted row and the tap's row
+  uint64_t tap_wbase = 0, tap_wbase0 = 0;
+  int64_t tap_wstride = 0;
+  auto setup_taps = [&]() {
+    const DnGemmTerm& t0 = p.terms[0];
+    const DnGemmTerm& t1 = p.terms[1];
+    const int sh0 = t0.shift_by_group ? (t0.shift << g) : t0.shift, sh1 = t1.shift_by_group ? (t1.shift << g) : t1.shift;
+    tap_shift0 = sh0; tap_sstep = sh0 - sh1;
+    tap_delta0 = (uint32_t)sh0 * (uint32_t)(t0.lda * ES); tap_dstep = (uint32_t)tap_sstep * (uint32_t)(t0.lda * ES);
+    tap_wbase0 = (uint64_t)(uintptr_t)t0.W + ((uint64_t)t0.w_gstride * g + (uint64_t)n0 * p.K) * ES;
+    tap_wstride = (int64_t)((uintptr_t)t1.W - (uintptr_t)t0.W);
+    tap_shift = tap_shift0; tap_delta = tap_delta0; tap_wbase = tap_wbase0;
+    const char* A = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + schunk * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + (wave * 4 + i) * 16 + srow;
+      m = m < p.M ? m : p.M - 1;
+      a_ptr[i] = A + (int64_t)m * t0.lda * ES;
+      a_inc[i] = m % p.T;
+    }
+    w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
+  };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   const uint64_t piece_stride = (uint64_t)16 * p.K * ES;
   // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces
@@ -915,19 +948,35 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     if constexpr (i < 6) {
       int pc = wave + 4 * i;
       pc = pc < 22 ? pc : 21;  // waves 2, 3 repeat the last piece: every wave issues PER pieces
-      glds16_s(w_voff, w_base + pc * piece_stride, sbase + pc * 1024);
+      const uint64_t wb = taps_inner ? tap_wbase : w_base;
+      glds16_s(w_voff, wb + pc * piece_stride, sbase + pc * 1024);
     } else {
-      glds16(a_ptr[i - 6], sbase + W_BYTES + (wave * 4 + i - 6) * 1024);
+      constexpr int j = i - 6;
+      const char* src = a_ptr[j];
+      if constexpr (taps_inner) src = a_inc[j] >= tap_shift ? src - tap_delta : zero_src;  // branch-free
+      glds16(src, sbase + W_BYTES + (wave * 4 + j) * 1024);
     }
   };
   auto stage_advance = [&]() {
-    if (++s_kk == ktiles_per_term) {
-      s_kk = 0;
-      if (++s_term < p.n_terms) setup_term(s_term);
-    } else {
+    if constexpr (taps_inner) {  // branch-free: scalar selects, and a K-chunk increment that is 0 until the taps wrap
+      const bool wrap = s_term + 1 == p.n_terms;
+      s_term = wrap ? 0 : s_term + 1;
+      tap_shift = wrap ? tap_shift0 : tap_shift - tap_sstep;
+      tap_delta = wrap ? tap_delta0 : tap_delta - tap_dstep;
+      tap_wbase = wrap ? tap_wbase0 : tap_wbase + tap_wstride;
+      const int inc = wrap ? ROWB2 : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
-      w_voff += ROWB2;
+      for (int i = 0; i < 4; ++i) a_ptr[i] += inc;
+      w_voff += inc;
+    } else {
+      if (++s_kk == ktiles_per_term) {
+        s_kk = 0;
+        if (++s_term < p.n_terms) setup_term(s_term);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
+        w_voff += ROWB2;
+      }
     }
   };
   auto stage = [&](int slot) {
@@ -960,7 +1009,12 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   //        every wave reaches only after it has finished iteration kt-1.
   // (After the last K-tile the cross-tile requests read a stale slot; the values are never used.)
   u32x4 wa, wb, wr[3], cur[MT], nxt[MT];
-  auto ktile = [&](int kt, int slot) {
+  // A uniform branch costs this lone wave ~20 cycles (its instruction stream is the only thing feeding the MFMA pipe), so
+  // the K-tile body is straight-line: whether it stages (all K-tiles but the last three) and which vmcnt it waits for
+  // are compile-time; the main loop runs the staging form, the last (up to) three K-tiles run the draining forms.
+  auto ktile = [&](int slot, auto stage_c, auto sync_c) {
+    constexpr bool STAGE = decltype(stage_c)::value;
+    constexpr int SYNC = decltype(sync_c)::value;
     const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
     const uint32_t w_cur = w_rd + slot * STAGE_BYTES, w_nxt = w_rd + nslot * STAGE_BYTES, a_nxt = a_rd + nslot * STAGE_BYTES;
     lds_wait_all_but(std::integral_constant<int, 2>{});  // younger than nxt[7]: wa, wb
@@ -968,16 +1022,12 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     for (int mt = 0; mt < MT; ++mt) copy_after_wait(cur[mt], nxt[mt]);
     static_for<NT>([&](auto nt_c) {
       constexpr int nt = decltype(nt_c)::value;
-      if constexpr (nt == 1) {
-        if (kt + 2 < nkt) pipe_sync<PER>(); else pipe_sync<0>();
-      }
+      if constexpr (nt == 1) pipe_sync<SYNC>();
       // the DMA of tile kt+3 into the slot tile kt-1 lived in: one piece per n-tile (a piece costs the wave ~60+ issue
       // cycles during which its MFMA pipe drains; bunched pieces also queue behind each other in the address path)
-      if constexpr (nt >= 1) {
-        if (kt + 3 < nkt && !(DN_FAT_ABL & 1)) {
-          stage_piece(std::integral_constant<int, nt - 1>{}, slot == 0 ? STAGES - 1 : slot - 1);
-          if constexpr (nt == PER) stage_advance();
-        }
+      if constexpr (nt >= 1 && STAGE && !(DN_FAT_ABL & 1)) {
+        stage_piece(std::integral_constant<int, nt - 1>{}, slot == 0 ? STAGES - 1 : slot - 1);
+        if constexpr (nt == PER) stage_advance();
       }
       if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
       else if constexpr (nt + 2 == NT) lds_request<0>(wa, w_nxt);
@@ -1002,7 +1052,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
 #ifdef DN_FAT_STAMPS  // diagnostic build only (tools/fat_clock.py): in-kernel clock and K-loop cycles
   const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  setup_term(0);
+  if constexpr (taps_inner) setup_taps(); else setup_term(0);
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
@@ -1014,9 +1064,16 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   lds_request<0>(wa, w_rd);
   lds_request<1024>(wb, w_rd);
   {
-    int slot = 0, kt = 0;
-    auto next = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; return ++kt < nkt; };
-    do ktile(kt, slot); while (next());
+    using std::integral_constant;
+    int slot = 0;
+    auto next_slot = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; };
+    for (int kt = 0; kt + 3 < nkt; ++kt) {  // tiles kt+1, kt+2 in flight behind the one being waited for
+      ktile(slot, integral_constant<bool, true>{}, integral_constant<int, PER>{});
+      next_slot();
+    }
+    if (nkt >= 3) { ktile(slot, integral_constant<bool, false>{}, integral_constant<int, PER>{}); next_slot(); }
+    if (nkt >= 2) { ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{}); next_slot(); }
+    ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{});
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA results land before the epilogue reads them
 #ifdef DN_FAT_STAMPS
@@ -1116,20 +1173,35 @@ static int launch_row(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
+template <typename E, int EPI, bool TAPS_INNER>
+static void launch_fat_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER>), grid, dim3(256), lds, s, p);
+}
+
 template <typename E, int EPI>
 static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   constexpr int ring = 4 * (352 + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
   dim3 grid(((p.M + 255) / 256) * (p.N / 352), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
+  // taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression
+  static const bool allow_taps = !getenv("DN_FAT_TERM_OUTER");
+  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && allow_taps;
+  for (int i = 1; i < p.n_terms && taps; ++i) {
+    const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
+    taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&
+           a.shift_by_group == t0.shift_by_group && b.shift - a.shift == t0.shift - t1.shift && t0.shift >= t1.shift &&
+           (intptr_t)a.W - (intptr_t)b.W == (intptr_t)t1.W - (intptr_t)t0.W;
+  }
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI>), grid, dim3(256), lds, s, p);
+  if (taps) launch_fat_variant<E, EPI, true>(p, grid, lds, s);
+  else launch_fat_variant<E, EPI, false>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm (fat tile)");
   return DN_OK;
