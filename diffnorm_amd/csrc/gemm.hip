@@ -48,10 +48,33 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, uint64_t sbase, uint32_t
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbase), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32));
   const uint64_t base = ((uint64_t)hi << 32) | lo;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      // s_nop 3: with the two s_movs, 5+ wait states between a v_readfirstlane that produced `base` and the VMEM read of it
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(base), "s"(lds_addr)
       : "memory");
+}
+
+// The same DMA in two statements, for streams that place them in different MFMA gaps: M0 <- LDS address (one wait state
+// is needed before the DMA reads it; the instruction the caller puts in between provides it), then the load.  M0 is
+// declared clobbered instead of being saved and restored (nothing else in such a loop uses it).
+__device__ __forceinline__ void glds_set_m0(uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %0" ::"s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void glds_go(const void* src) {
+  asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src) : "memory");
+}
+// saddr form.  Hazard the compiler cannot see through inline asm: an SGPR written by a VALU instruction
+// (v_readfirstlane, which is how a uniform value computed in VGPRs reaches an "s" operand) needs 5 wait states before
+// a VMEM instruction reads it.  So the base is first copied by a SALU instruction -- in the M0 statement, one MFMA gap
+// ahead of the load -- and the load reads the copy (SALU-written SGPRs are interlocked).
+__device__ __forceinline__ uint64_t glds_set_m0_base(uint32_t lds_addr, uint64_t sbase) {
+  uint64_t copy;
+  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %2" : "=s"(copy) : "s"(lds_addr), "s"(sbase) : "memory");
+  return copy;
+}
+__device__ __forceinline__ void glds_go_s(uint32_t voff, uint64_t sbase_copy) {
+  asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase_copy) : "memory");
 }
 
 // wait until at most N of this wave's LDS-DMA pieces are outstanding, then workgroup barrier; one asm
@@ -883,7 +906,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   // Row pieces keep per-lane 64-bit pointers (a lane whose frame precedes the sequence start reads the zero page).
   //
   // K-tile order.  General case: term-outer (all K-tiles of term 0, then term 1, ..).  When the terms are the taps of
-  // ONE causal conv (same activation tensor; launch_fat picks the TAPS_INNER instantiation) the order is tap-inner: K-tile n is tap
+  // ONE causal conv (same activation tensor) the TAPS_INNER instantiation (opt-in, see launch_fat) runs tap-inner: K-tile n is tap
   // n % n_terms of K-chunk n / n_terms, so the three taps read (nearly) the same activation rows back to back and the
   // XCD's L2 serves two of the three reads; term-outer re-fetches the XCD's 5.8 MB activation panel through the
   // fabric once per tap (measured 234 MB of fabric reads per FFN-conv launch = 3 x 46 MB + 8 XCDs x 11.9 MB of weights).
@@ -941,21 +964,46 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   const uint64_t piece_stride = (uint64_t)16 * p.K * ES;
-  // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces
-  auto stage_piece = [&](auto i_c, int slot) {
+  // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces.  Two halves (M0 <- LDS address,
+  // then the load) so that the K loop can put them into different MFMA gaps; stage_piece = both, back to back.
+  auto piece_lds_addr = [&](auto i_c, int slot) -> uint32_t {
     constexpr int i = decltype(i_c)::value;
     const uint32_t sbase = lds_base + slot * STAGE_BYTES;
     if constexpr (i < 6) {
       int pc = wave + 4 * i;
       pc = pc < 22 ? pc : 21;  // waves 2, 3 repeat the last piece: every wave issues PER pieces
+      return sbase + pc * 1024;
+    } else {
+      return sbase + W_BYTES + (wave * 4 + (i - 6)) * 1024;
+    }
+  };
+  uint64_t piece_base = 0;  // SALU copy of the current weight piece's scalar base (see glds_set_m0_base)
+  auto piece_setup = [&](auto i_c, int slot) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (i < 6) {
+      int pc = wave + 4 * i;
+      pc = pc < 22 ? pc : 21;
       const uint64_t wb = taps_inner ? tap_wbase : w_base;
-      glds16_s(w_voff, wb + pc * piece_stride, sbase + pc * 1024);
+      piece_base = glds_set_m0_base(piece_lds_addr(i_c, slot), wb + pc * piece_stride);
+    } else {
+      glds_set_m0(piece_lds_addr(i_c, slot));
+    }
+  };
+  auto piece_go = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (i < 6) {
+      glds_go_s(w_voff, piece_base);
     } else {
       constexpr int j = i - 6;
       const char* src = a_ptr[j];
       if constexpr (taps_inner) src = a_inc[j] >= tap_shift ? src - tap_delta : zero_src;  // branch-free
-      glds16(src, sbase + W_BYTES + (wave * 4 + j) * 1024);
+      glds_go(src);
     }
+  };
+  auto stage_piece = [&](auto i_c, int slot) {
+    piece_setup(i_c, slot);
+    asm volatile("s_nop 0");
+    piece_go(i_c);
   };
   auto stage_advance = [&]() {
     if constexpr (taps_inner) {  // branch-free: scalar selects, and a K-chunk increment that is 0 until the taps wrap
@@ -1003,6 +1051,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   //   * the next K-tile's 8 activation fragments are requested one per n-tile under n-tiles 1..8 into `nxt` and
   //     copied to `cur` at the top of the next K-tile, two n-tiles after the last request.
   // Requests per n-tile, in order: [weight fragment nt+2] [nxt[nt-1] if 1 <= nt <= 8]; the counted waits below follow.
+  // Everything but the MFMAs is dealt out into the gaps between them (see the n-tile body).
   // The barrier sits before n-tile 1, the first point that touches tile kt+1:
   //   RAW: tile kt+1 is read only after every wave's counted vmcnt for it and that barrier.
   //   WAR: the DMA of tile kt+3 reuses the slot of tile kt-1 and is issued after the barrier of iteration kt, which
@@ -1023,29 +1072,44 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     static_for<NT>([&](auto nt_c) {
       constexpr int nt = decltype(nt_c)::value;
       if constexpr (nt == 1) pipe_sync<SYNC>();
-      // the DMA of tile kt+3 into the slot tile kt-1 lived in: one piece per n-tile (a piece costs the wave ~60+ issue
-      // cycles during which its MFMA pipe drains; bunched pieces also queue behind each other in the address path)
-      if constexpr (nt >= 1 && STAGE && !(DN_FAT_ABL & 1)) {
-        stage_piece(std::integral_constant<int, nt - 1>{}, slot == 0 ? STAGES - 1 : slot - 1);
-        if constexpr (nt == PER) stage_advance();
-      }
-      if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
-      else if constexpr (nt + 2 == NT) lds_request<0>(wa, w_nxt);
-      else lds_request<1024>(wb, w_nxt);
-      if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
-      // requests younger than this n-tile's weight fragment
-      constexpr int younger = 2 + (nt >= 3 ? 1 : 0) + (nt >= 2 && nt <= 9 ? 1 : 0) + (nt >= 1 && nt <= 8 ? 1 : 0);
       u32x4& w = [&]() -> u32x4& {
         if constexpr (nt == 0) return wa;
         else if constexpr (nt == 1) return wb;
         else return wr[(nt - 2) % 3];
       }();
+      // Requests of n-tile nt, in program order: [weight fragment nt+2] after MFMA 0, [nxt[nt-1] if 1 <= nt <= 8] after
+      // MFMA 1.  Younger than this n-tile's weight fragment (requested two n-tiles ago) are therefore nxt[nt-3] (if it
+      // exists), the next weight fragment and nxt[nt-2] (if it exists); across the K-tile boundary (nt = 0, 1) just the
+      // next weight fragment.
+      constexpr int younger = 1 + (nt >= 3 && nt <= 10 ? 1 : 0) + (nt >= 2 && nt <= 9 ? 1 : 0);
       lds_wait<younger>(w);
-#pragma unroll
-      for (int mt = 0; mt < ((DN_FAT_ABL & 2) ? 1 : MT); ++mt) {
-        if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
-        else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
-      }
+      // 8 MFMAs; after MFMA g the wave has ~8 issue cycles before the pipe can take the next one: one short instruction
+      // per gap is free, so the n-tile's other work is dealt out one piece per gap instead of being bunched in front
+      const int fill = slot == 0 ? STAGES - 1 : slot - 1;  // the slot tile kt-1 lived in receives tile kt+3
+      constexpr bool dma = nt >= 1 && STAGE && !(DN_FAT_ABL & 1);
+      auto mf = [&](auto mt_c) {
+        constexpr int mt = decltype(mt_c)::value;
+        if constexpr (!(DN_FAT_ABL & 2) || mt == 0) {
+          if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
+          else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
+        }
+      };
+      using std::integral_constant;
+      mf(integral_constant<int, 0>{});
+      if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
+      else if constexpr (nt + 2 == NT) lds_request<0>(wa, w_nxt);
+      else lds_request<1024>(wb, w_nxt);
+      mf(integral_constant<int, 1>{});
+      if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
+      mf(integral_constant<int, 2>{});
+      if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
+      mf(integral_constant<int, 3>{});
+      if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
+      mf(integral_constant<int, 4>{});
+      mf(integral_constant<int, 5>{});
+      if constexpr (dma && nt == PER) stage_advance();
+      mf(integral_constant<int, 6>{});
+      mf(integral_constant<int, 7>{});
     });
   };
 
@@ -1075,6 +1139,14 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     if (nkt >= 2) { ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{}); next_slot(); }
     ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{});
   }
+  // The last K-tile still issued its cross-tile requests (stale slot, values unused).  To the compiler those registers
+  // are dead the moment they are requested, so it would hand them to epilogue temporaries while the LDS data is still
+  // in flight -- and the late return would overwrite them.  Drain the LDS queue with every such register as an operand.
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(wa), "+v"(wb), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]),
+                 "+v"(nxt[6]), "+v"(nxt[7])
+               :
+               : "memory");
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA results land before the epilogue reads them
 #ifdef DN_FAT_STAMPS
   const uint64_t dbg_c2 = __builtin_readcyclecounter();
@@ -1190,9 +1262,12 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   constexpr int lds = ring > slabs ? ring : slabs;
   dim3 grid(((p.M + 255) / 256) * (p.N / 352), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
-  // taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression
-  static const bool allow_taps = !getenv("DN_FAT_TERM_OUTER");
-  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && allow_taps;
+  // Tap-inner K order (see the kernel): opt-in -- DN_FAT_TAPS_INNER=1 or bit 22 of pad_ -- because it changes the fp32
+  // summation order, and with it the last bits, relative to every other tile variant (which are all term-outer and
+  // therefore bit-identical to each other: shards of a batch that fall on different variants give identical units).
+  // Needs the taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression.
+  static const bool env_taps = getenv("DN_FAT_TAPS_INNER") && atoi(getenv("DN_FAT_TAPS_INNER")) != 0;
+  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && (env_taps || ((p.pad_ >> 22) & 1));
   for (int i = 1; i < p.n_terms && taps; ++i) {
     const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
     taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&

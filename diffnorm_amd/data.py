@@ -37,6 +37,8 @@ class UnitDictionary:
     def __init__(self, n_units: int = 1000):
         self.n_units = n_units
         self.nspecial = 4
+        # attribute spellings of fairseq's Dictionary (fairseq/data/dictionary.py:29-33)
+        self.bos_index, self.pad_index, self.eos_index, self.unk_index = self.BOS, self.PAD, self.EOS, self.UNK
 
     def __len__(self):
         return self.n_units + self.nspecial

@@ -31,7 +31,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               gb_half: int = 0, pos_table: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
               shift_by_group: bool = False, a_grouped: bool = True, norm_out: Optional[torch.Tensor] = None,
               norm_D: int = 0, norm_gamma: Optional[torch.Tensor] = None, norm_gb: Optional[torch.Tensor] = None,
-              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0):
+              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: bool = False):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
@@ -76,7 +76,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
         p.norm_gb = _lib.ptr(norm_gb)
         p.norm_gb_ld = 0 if (norm_gb is None or norm_gb_shared) else norm_gb.stride(0)
         p.norm_gb_half = norm_gb_half
-    p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16)  # ablation switches (tools/gemm_bench.py) | forced tile (tests)
+    p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16) | (int(taps_inner) << 22)  # ablation switches (tools/gemm_bench.py) | forced tile / K order (tests)
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out
 

@@ -79,12 +79,13 @@ def test_causal_conv_gemm(ops, dtype, cin, cout, k, dil, B, T):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (128, 1056, 1, 1, 1, 515),
                                                 (64, 352, 1, 1, 2, 130), (1408, 1408, 3, 1, 4, 512)])
 def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil, B, T):
-    """The same causal conv through each forced tile variant (128x128, 256x128, 256x256, 256x352): ragged M,
-    N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term (pipeline prologue/drain edges)."""
+    """The same causal conv through each forced tile variant (128x128, 256x128, 256x256, 256x352, and 256x352 with the
+    taps innermost in K = "tile 5"): ragged M, N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term
+    (pipeline prologue/drain edges), sequence starts inside a tile (T = 100, 130, 300)."""
     ops_, packing, _lib = ops
     code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
     x = seeded((B, T, cin), 11)
@@ -98,8 +99,15 @@ def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil
     out = torch.full((B * T, N), float("nan"), device=DEV)
     bias = packing._vec(b, W.shape[1]).to(DEV)
     terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
-    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=tile)
+    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=min(tile, 4), taps_inner=tile == 5)
     got = out.cpu().view(B, T, -1)
+    if tile > 1:  # every term-outer variant sums K in the same order: bit-identical outputs
+        ref_out = torch.empty_like(out)
+        ops_.conv_gemm(terms, ref_out, T, N, bias=bias, tile=1)
+        if tile < 5:
+            assert torch.equal(out, ref_out)
+        else:
+            assert maxerr(out.cpu(), ref_out.cpu()) < 1e-4
     if dtype == "bf16":
         assert maxerr(got, O.causal_conv1d(bf16r(x), bf16r(w), b, dil)) < 2e-4
     else:
