@@ -59,7 +59,7 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, uint64_t sbase, uint32_t
 // is needed before the DMA reads it; the instruction the caller puts in between provides it), then the load.  M0 is
 // declared clobbered instead of being saved and restored (nothing else in such a loop uses it).
 __device__ __forceinline__ void glds_set_m0(uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %0" ::"s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %0" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 __device__ __forceinline__ void glds_go(const void* src) {
   asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src) : "memory");
@@ -70,7 +70,11 @@ __device__ __forceinline__ void glds_go(const void* src) {
 // ahead of the load -- and the load reads the copy (SALU-written SGPRs are interlocked).
 __device__ __forceinline__ uint64_t glds_set_m0_base(uint32_t lds_addr, uint64_t sbase) {
   uint64_t copy;
-  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %2" : "=s"(copy) : "s"(lds_addr), "s"(sbase) : "memory");
+  // (wave-uniform values the compiler happens to hold in VGPRs reach the SALU moves through v_readfirstlane)
+  const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sbase), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32));
+  const uint64_t base = ((uint64_t)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %2" : "=&s"(copy) : "s"(la), "s"(base) : "memory");
   return copy;
 }
 __device__ __forceinline__ void glds_go_s(uint32_t voff, uint64_t sbase_copy) {
@@ -108,6 +112,73 @@ __device__ __forceinline__ float4 load4t(const void* base, int64_t off) {
 }
 
 // OUT_BF / RES_BF: storage types fixed at compile time; FULL: every row of the slab is inside M (no per-row guards).
+// 8 consecutive bf16 outputs per lane = one 16-byte store: bf16 output stores are issue-bound (a wave-instruction moves
+// 512 B as dwordx2 but 1 KiB as dwordx4), so halving their number halves the store tail of the epilogue.
+__device__ __forceinline__ void store8_bf16(void* base, int64_t off, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
+      make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
+// WIDE (bf16 output, rows 16-byte aligned, BIAS / SILU / GEGLU): a lane owns 8 output columns instead of 4.
+template <int EPI, bool FULL>
+__device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
+                                                   int ncols) {
+  const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
+  char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * 2;
+  if constexpr (EPI == DN_EPI_GEGLU) {
+    // value columns 0..31 and gate columns 32..63 of the slab -> 32 output columns: 4 lanes per row, 16 rows per pass
+    const int c8 = (lane & 3) * 8;
+    const int np = n_base + c8;        // packed row of the value
+    const int n = (n_base >> 1) + c8;  // output column
+    if (n >= p.N) return;
+    float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (bias) {
+      *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bias + np);
+      *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bias + np + 4);
+      *reinterpret_cast<float4*>(bg) = *reinterpret_cast<const float4*>(bias + np + 32);
+      *reinterpret_cast<float4*>(bg + 4) = *reinterpret_cast<const float4*>(bias + np + 36);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = j * 16 + (lane >> 2);
+      const int m = m_base + row;
+      if (!FULL && m >= p.M) continue;
+      float v[8], gt[8], o[8];
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
+      *reinterpret_cast<float4*>(gt) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8);
+      *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8 + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
+      store8_bf16(out, (int64_t)m * p.ldo + n, o);
+    }
+  } else {
+    const int c8 = (lane & 7) * 8;
+    const int n = n_base + c8;
+    if (n >= p.N || c8 >= ncols) return;
+    float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (bias) {
+      *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bias + n);
+      *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bias + n + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = j * 8 + (lane >> 3);
+      const int m = m_base + row;
+      if (!FULL && m >= p.M) continue;
+      float v[8];
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] += bv[i];
+        if constexpr (EPI == DN_EPI_SILU) v[i] = silu(v[i]);
+      }
+      store8_bf16(out, (int64_t)m * p.ldo + n, v);
+    }
+  }
+}
+
 template <int EPI, bool OUT_BF, bool RES_BF, bool FULL>
 __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
                                                    int ncols) {
@@ -234,6 +305,16 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
     else if (obf) DN_EP(true, false, false);
     else DN_EP(false, true, false);
   } else {
+    if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
+      // 16-byte stores need 8-column granularity and 16-byte aligned rows (uniform: kernel arguments)
+      const bool wide = !(p.pad_ & 16) && obf && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (ncols & 7) == 0 && (p.out_gstride & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+      if (wide) {
+        if (full) wave_epilogue_wide<EPI, true>(p, ep, m_base, n_base, g, lane, ncols);
+        else wave_epilogue_wide<EPI, false>(p, ep, m_base, n_base, g, lane, ncols);
+        return;
+      }
+    }
     if (obf) { if (full) DN_EP(true, false, true); else DN_EP(true, false, false); }
     else { if (full) DN_EP(false, false, true); else DN_EP(false, false, false); }
   }
@@ -839,7 +920,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
 #ifndef DN_FAT_ABL
 #define DN_FAT_ABL 0
 #endif
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned long u32x4;  // a 128-bit fragment as two 64-bit halves (4 VGPRs)
 
 template <bool IN_AGPR>
 __device__ __forceinline__ void mma_pinned_bf16(f32x4& acc, const u32x4& w, const u32x4& a) {
@@ -861,10 +942,8 @@ __device__ __forceinline__ void lds_wait_all_but(std::integral_constant<int, 2>)
 // register copy that stays behind the wait above it (a plain C++ copy could be scheduled ahead of the wait and read a
 // register whose LDS data is still in flight)
 __device__ __forceinline__ void copy_after_wait(u32x4& dst, const u32x4& src) {
-  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.x) : "v"(src.x));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.y) : "v"(src.y));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.z) : "v"(src.z));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(dst.w) : "v"(src.w));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(dst.x) : "v"(src.x));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(dst.y) : "v"(src.y));
 }
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -1049,7 +1128,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   //     (requested under n-tiles 9 and 10 of the previous K-tile), fragments 2..10 rotate through the ring wr[3]
   //     (9 = 3 x 3 uses, so the ring phase is the same in every K-tile and every register index is a constant);
   //   * the next K-tile's 8 activation fragments are requested one per n-tile under n-tiles 1..8 into `nxt` and
-  //     copied to `cur` at the top of the next K-tile, two n-tiles after the last request.
+  //     copied to `cur` in the gaps of the last n-tile, fragment mt right behind the last MFMA that reads cur[mt].
   // Requests per n-tile, in order: [weight fragment nt+2] [nxt[nt-1] if 1 <= nt <= 8]; the counted waits below follow.
   // Everything but the MFMAs is dealt out into the gaps between them (see the n-tile body).
   // The barrier sits before n-tile 1, the first point that touches tile kt+1:
@@ -1066,9 +1145,6 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     constexpr int SYNC = decltype(sync_c)::value;
     const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
     const uint32_t w_cur = w_rd + slot * STAGE_BYTES, w_nxt = w_rd + nslot * STAGE_BYTES, a_nxt = a_rd + nslot * STAGE_BYTES;
-    lds_wait_all_but(std::integral_constant<int, 2>{});  // younger than nxt[7]: wa, wb
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) copy_after_wait(cur[mt], nxt[mt]);
     static_for<NT>([&](auto nt_c) {
       constexpr int nt = decltype(nt_c)::value;
       if constexpr (nt == 1) pipe_sync<SYNC>();
@@ -1095,21 +1171,46 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
         }
       };
       using std::integral_constant;
-      mf(integral_constant<int, 0>{});
-      if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
-      else if constexpr (nt + 2 == NT) lds_request<0>(wa, w_nxt);
-      else lds_request<1024>(wb, w_nxt);
-      mf(integral_constant<int, 1>{});
-      if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
-      mf(integral_constant<int, 2>{});
-      if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
-      mf(integral_constant<int, 3>{});
-      if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
-      mf(integral_constant<int, 4>{});
-      mf(integral_constant<int, 5>{});
-      if constexpr (dma && nt == PER) stage_advance();
-      mf(integral_constant<int, 6>{});
-      mf(integral_constant<int, 7>{});
+      if constexpr (nt < NT - 1) {
+        mf(integral_constant<int, 0>{});
+        if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
+        else lds_request<0>(wa, w_nxt);
+        mf(integral_constant<int, 1>{});
+        if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
+        mf(integral_constant<int, 2>{});
+        if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
+        mf(integral_constant<int, 3>{});
+        if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
+        mf(integral_constant<int, 4>{});
+        mf(integral_constant<int, 5>{});
+        mf(integral_constant<int, 6>{});
+        mf(integral_constant<int, 7>{});
+      } else {
+        // last n-tile: once MFMA mt has issued (its operands are read at issue), cur[mt] is free and takes the next
+        // K-tile's fragment -- two v_mov_b64 per gap.  nxt[0..6] are older than this n-tile's weight fragment, which
+        // the wait above covered; nxt[7] needs its own wait (younger than it: wa, wb).
+        mf(integral_constant<int, 0>{});
+        lds_request<1024>(wb, w_nxt);
+        copy_after_wait(cur[0], nxt[0]);
+        mf(integral_constant<int, 1>{});
+        copy_after_wait(cur[1], nxt[1]);
+        mf(integral_constant<int, 2>{});
+        if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
+        copy_after_wait(cur[2], nxt[2]);
+        mf(integral_constant<int, 3>{});
+        if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
+        copy_after_wait(cur[3], nxt[3]);
+        mf(integral_constant<int, 4>{});
+        copy_after_wait(cur[4], nxt[4]);
+        mf(integral_constant<int, 5>{});
+        copy_after_wait(cur[5], nxt[5]);
+        if constexpr (dma) stage_advance();
+        mf(integral_constant<int, 6>{});
+        copy_after_wait(cur[6], nxt[6]);
+        mf(integral_constant<int, 7>{});
+        lds_wait_all_but(integral_constant<int, 2>{});
+        copy_after_wait(cur[7], nxt[7]);
+      }
     });
   };
 
@@ -1124,7 +1225,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
 #ifdef DN_FAT_STAMPS
   const uint64_t dbg_c1 = __builtin_readcyclecounter();
 #endif
-  static_for<MT>([&](auto mt_c) { lds_request<decltype(mt_c)::value * 1024>(nxt[decltype(mt_c)::value], a_rd); });
+  static_for<MT>([&](auto mt_c) { lds_request<decltype(mt_c)::value * 1024>(cur[decltype(mt_c)::value], a_rd); });
   lds_request<0>(wa, w_rd);
   lds_request<1024>(wb, w_rd);
   {
