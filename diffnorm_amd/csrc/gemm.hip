@@ -938,7 +938,27 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& r) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
 }
-__device__ __forceinline__ void lds_wait_all_but(std::integral_constant<int, 2>) { asm volatile("s_waitcnt lgkmcnt(2)"); }
+template <int N>
+__device__ __forceinline__ void lds_wait_all_but() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+
+// LDS-request bookkeeping of the one-wave-per-SIMD K-tile (NT n-tiles of 8 MFMAs).  Program order of the requests of
+// n-tile g: the weight fragment that will be used two n-tiles later, then -- for n-tiles BG .. BG + 8/NPG - 1 -- NPG of the
+// next K-tile's 8 activation fragments.  LDS returns in order, so a use must allow exactly the requests issued after
+// the one it needs to stay outstanding; these functions count them (two consecutive K-tiles laid end to end).
+template <int NT, int BG, int NPG>
+struct SoloSched {
+  static constexpr int per_group(int g) { return 1 + ((g >= BG && g < BG + 8 / NPG) ? NPG : 0); }
+  static constexpr int prefix(int g) { int n = 0; for (int h = 0; h < g; ++h) n += per_group(h); return n; }
+  static constexpr int R = prefix(NT);
+  // weight fragment nt of a K-tile is requested in n-tile nt-2 of the same K-tile, or (nt = 0, 1) in n-tile NT-2+nt of
+  // the previous one; it is waited for at the top of n-tile nt
+  static constexpr int younger_w(int nt) { return (R + prefix(nt)) - ((nt >= 2 ? R + prefix(nt - 2) : prefix(NT - 2 + nt)) + 1); }
+  // the last activation fragment is the last request of n-tile BG + 8/NPG - 1; the copies that need it sit in the last
+  // n-tile behind that n-tile's own weight request
+  static constexpr int younger_copy() { return (prefix(NT - 1) + 1) - ((prefix(BG + 8 / NPG - 1) + per_group(BG + 8 / NPG - 1) - 1) + 1); }
+};
+static_assert(SoloSched<11, 1, 1>::younger_w(0) == 1 && SoloSched<11, 1, 1>::younger_w(2) == 2 && SoloSched<11, 1, 1>::younger_w(5) == 3 &&
+              SoloSched<11, 1, 1>::younger_w(10) == 2 && SoloSched<11, 1, 1>::younger_copy() == 2, "schedule arithmetic");
 // register copy that stays behind the wait above it (a plain C++ copy could be scheduled ahead of the wait and read a
 // register whose LDS data is still in flight)
 __device__ __forceinline__ void copy_after_wait(u32x4& dst, const u32x4& src) {
@@ -954,23 +974,34 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <typename E, int EPI, bool TAPS_INNER>
+// NTW = n-tiles per wave: 11 -> the 256 x 352 tile (N a multiple of 352, BIAS epilogue), 8 -> a 256 x 256 tile for any N and
+// every epilogue (64 accumulator tiles, all in AGPRs).
+template <typename E, int EPI, bool TAPS_INNER, int NTW>
 __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
-  static_assert(std::is_same<E, BF16>::value, "the 256 x 352 tile is built for bf16 operands only");
+  static_assert(std::is_same<E, BF16>::value, "the one-wave-per-SIMD tiles are built for bf16 operands only");
+  static_assert(NTW == 11 || NTW == 8, "n-tiles per wave");
+  static_assert(NTW == 8 || EPI == DN_EPI_BIAS, "the 352-wide tile only carries the BIAS epilogue (its wave columns start at multiples of 176)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
-  constexpr int BMF = 256, BNF = 352, STAGES = 4;
-  constexpr int W_BYTES = BNF * ROWB2, A_BYTES = BMF * ROWB2, STAGE_BYTES = W_BYTES + A_BYTES;  // 22528 + 16384
-  constexpr int PER = 10;  // DMA pieces per wave per stage: 4 of the 16 row pieces, 6 of the 22 weight pieces (2 waves repeat one)
-  constexpr int NT = 11, MT = 8;
+  constexpr int BMF = 256, BNF = 32 * NTW, STAGES = 4;
+  constexpr int W_BYTES = BNF * ROWB2, A_BYTES = BMF * ROWB2, STAGE_BYTES = W_BYTES + A_BYTES;  // 352: 22528 + 16384
+  constexpr int NWP = BNF / 16, WPW = (NWP + 3) / 4;  // weight pieces per stage / per wave (352: 22 / 6, two waves repeat one)
+  constexpr int PER = WPW + 4;  // DMA pieces per wave per stage: WPW weight pieces, then 4 of the 16 row pieces
+  constexpr int NT = NTW, MT = 8;
+  constexpr int BG = NTW == 11 ? 1 : 0;   // n-tile whose top carries the barrier: the first one that touches K-tile kt+1
+  constexpr int NPG = NTW == 11 ? 1 : 2;  // next-K-tile activation fragments requested per n-tile (n-tiles BG .. BG + 8/NPG - 1)
+  using Sched = SoloSched<NT, BG, NPG>;
+  static_assert((NT - 2) % 3 == 0, "weight fragments 2..NT-1 must cycle the 3-deep ring a whole number of times per K-tile");
+  static_assert(BG + PER - 1 == NT - 1, "one DMA piece per n-tile from the barrier to the last n-tile");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int g = blockIdx.y;
-  const int n_tiles_n = p.N / BNF;
+  const int np_total = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);  // packed weight rows that carry output
+  const int n_tiles_n = (np_total + BNF - 1) / BNF;
   int logical;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -979,6 +1010,9 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   }
   const int m0 = (logical / n_tiles_n) * BMF;
   const int n0 = (logical % n_tiles_n) * BNF;
+  // the packed weight has rows up to the next multiple of 128: pieces of a ragged last tile beyond that re-read its
+  // last piece (their columns are never stored)
+  const int pc_max = min(NWP, ((np_total + 127) / 128 * 128 - n0) / 16) - 1;
 
   // ---- staging: 16-row x 64-byte pieces; wave w takes row pieces 4w..4w+3 and weight pieces w, w+4, .., (w+20 or 21).
   // Weight pieces differ by a uniform row offset: one per-lane 32-bit offset + a scalar base per piece (saddr form).
@@ -1048,20 +1082,20 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   auto piece_lds_addr = [&](auto i_c, int slot) -> uint32_t {
     constexpr int i = decltype(i_c)::value;
     const uint32_t sbase = lds_base + slot * STAGE_BYTES;
-    if constexpr (i < 6) {
+    if constexpr (i < WPW) {
       int pc = wave + 4 * i;
-      pc = pc < 22 ? pc : 21;  // waves 2, 3 repeat the last piece: every wave issues PER pieces
+      pc = pc < pc_max ? pc : pc_max;  // 352: waves 2, 3 repeat the last piece (every wave issues PER pieces); ragged N
       return sbase + pc * 1024;
     } else {
-      return sbase + W_BYTES + (wave * 4 + (i - 6)) * 1024;
+      return sbase + W_BYTES + (wave * 4 + (i - WPW)) * 1024;
     }
   };
   uint64_t piece_base = 0;  // SALU copy of the current weight piece's scalar base (see glds_set_m0_base)
   auto piece_setup = [&](auto i_c, int slot) {
     constexpr int i = decltype(i_c)::value;
-    if constexpr (i < 6) {
+    if constexpr (i < WPW) {
       int pc = wave + 4 * i;
-      pc = pc < 22 ? pc : 21;
+      pc = pc < pc_max ? pc : pc_max;
       const uint64_t wb = taps_inner ? tap_wbase : w_base;
       piece_base = glds_set_m0_base(piece_lds_addr(i_c, slot), wb + pc * piece_stride);
     } else {
@@ -1070,10 +1104,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   };
   auto piece_go = [&](auto i_c) {
     constexpr int i = decltype(i_c)::value;
-    if constexpr (i < 6) {
+    if constexpr (i < WPW) {
       glds_go_s(w_voff, piece_base);
     } else {
-      constexpr int j = i - 6;
+      constexpr int j = i - WPW;
       const char* src = a_ptr[j];
       if constexpr (taps_inner) src = a_inc[j] >= tap_shift ? src - tap_delta : zero_src;  // branch-free
       glds_go(src);
@@ -1119,7 +1153,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
 
   const int frow = lane & 15, fq = lane >> 4;
   const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
-  const uint32_t w_rd = lds_base + (wn * 176 + frow) * ROWB2 + coff;            // + slot * STAGE_BYTES + nt * 1024
+  const uint32_t w_rd = lds_base + (wn * (16 * NTW) + frow) * ROWB2 + coff;     // + slot * STAGE_BYTES + nt * 1024
   const uint32_t a_rd = lds_base + W_BYTES + (wm * 128 + frow) * ROWB2 + coff;  // + slot * STAGE_BYTES + mt * 1024
 
   // One K-tile = 11 n-tiles of 8 MFMAs.  With the LDS ~2/3 busy (76 KiB of fragment reads + 38 KiB of DMA writes per
@@ -1147,22 +1181,19 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     const uint32_t w_cur = w_rd + slot * STAGE_BYTES, w_nxt = w_rd + nslot * STAGE_BYTES, a_nxt = a_rd + nslot * STAGE_BYTES;
     static_for<NT>([&](auto nt_c) {
       constexpr int nt = decltype(nt_c)::value;
-      if constexpr (nt == 1) pipe_sync<SYNC>();
+      if constexpr (nt == BG) pipe_sync<SYNC>();
       u32x4& w = [&]() -> u32x4& {
         if constexpr (nt == 0) return wa;
         else if constexpr (nt == 1) return wb;
         else return wr[(nt - 2) % 3];
       }();
-      // Requests of n-tile nt, in program order: [weight fragment nt+2] after MFMA 0, [nxt[nt-1] if 1 <= nt <= 8] after
-      // MFMA 1.  Younger than this n-tile's weight fragment (requested two n-tiles ago) are therefore nxt[nt-3] (if it
-      // exists), the next weight fragment and nxt[nt-2] (if it exists); across the K-tile boundary (nt = 0, 1) just the
-      // next weight fragment.
-      constexpr int younger = 1 + (nt >= 3 && nt <= 10 ? 1 : 0) + (nt >= 2 && nt <= 9 ? 1 : 0);
-      lds_wait<younger>(w);
+      lds_wait<Sched::younger_w(nt)>(w);
       // 8 MFMAs; after MFMA g the wave has ~8 issue cycles before the pipe can take the next one: one short instruction
       // per gap is free, so the n-tile's other work is dealt out one piece per gap instead of being bunched in front
       const int fill = slot == 0 ? STAGES - 1 : slot - 1;  // the slot tile kt-1 lived in receives tile kt+3
-      constexpr bool dma = nt >= 1 && STAGE && !(DN_FAT_ABL & 1);
+      constexpr bool dma = nt >= BG && STAGE && !(DN_FAT_ABL & 1);
+      constexpr int a_first = (nt - BG) * NPG;  // first next-K-tile activation fragment requested in this n-tile
+      constexpr bool a_req = nt >= BG && a_first < MT;
       auto mf = [&](auto mt_c) {
         constexpr int mt = decltype(mt_c)::value;
         if constexpr (!(DN_FAT_ABL & 2) || mt == 0) {
@@ -1176,29 +1207,31 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
         if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
         else lds_request<0>(wa, w_nxt);
         mf(integral_constant<int, 1>{});
-        if constexpr (nt >= 1 && nt <= MT) lds_request<(nt - 1) * 1024>(nxt[nt - 1], a_nxt);
+        if constexpr (a_req) lds_request<a_first * 1024>(nxt[a_first], a_nxt);
         mf(integral_constant<int, 2>{});
-        if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
+        if constexpr (dma) piece_setup(integral_constant<int, nt - BG>{}, fill);
         mf(integral_constant<int, 3>{});
-        if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
+        if constexpr (dma) piece_go(integral_constant<int, nt - BG>{});
         mf(integral_constant<int, 4>{});
+        if constexpr (a_req && NPG == 2) lds_request<(a_first + 1) * 1024>(nxt[a_first + 1], a_nxt);
         mf(integral_constant<int, 5>{});
         mf(integral_constant<int, 6>{});
         mf(integral_constant<int, 7>{});
       } else {
         // last n-tile: once MFMA mt has issued (its operands are read at issue), cur[mt] is free and takes the next
-        // K-tile's fragment -- two v_mov_b64 per gap.  nxt[0..6] are older than this n-tile's weight fragment, which
-        // the wait above covered; nxt[7] needs its own wait (younger than it: wa, wb).
+        // K-tile's fragment -- two v_mov_b64 per gap.  All but the last-requested activation fragments are older than this
+        // n-tile's weight fragment, which the wait above covered; the last one gets its own counted wait.
+        static_assert(!a_req, "no activation request in the last n-tile");
         mf(integral_constant<int, 0>{});
         lds_request<1024>(wb, w_nxt);
         copy_after_wait(cur[0], nxt[0]);
         mf(integral_constant<int, 1>{});
         copy_after_wait(cur[1], nxt[1]);
         mf(integral_constant<int, 2>{});
-        if constexpr (dma) piece_setup(integral_constant<int, nt - 1>{}, fill);
+        if constexpr (dma) piece_setup(integral_constant<int, nt - BG>{}, fill);
         copy_after_wait(cur[2], nxt[2]);
         mf(integral_constant<int, 3>{});
-        if constexpr (dma) piece_go(integral_constant<int, nt - 1>{});
+        if constexpr (dma) piece_go(integral_constant<int, nt - BG>{});
         copy_after_wait(cur[3], nxt[3]);
         mf(integral_constant<int, 4>{});
         copy_after_wait(cur[4], nxt[4]);
@@ -1208,7 +1241,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
         mf(integral_constant<int, 6>{});
         copy_after_wait(cur[6], nxt[6]);
         mf(integral_constant<int, 7>{});
-        lds_wait_all_but(integral_constant<int, 2>{});
+        lds_wait_all_but<Sched::younger_copy()>();
         copy_after_wait(cur[7], nxt[7]);
       }
     });
@@ -1260,26 +1293,30 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   }
 #endif
 
-  // ---- epilogue: the 128 x 176 sub-tile as 2 x 3 slabs of 64 x 64 (the third carries 48 columns)
+  // ---- epilogue: the wave's 128 x (16 NTW) sub-tile as 2 x ceil(NTW / 4) slabs of 64 x 64 (352: the third carries 48 columns).
+  // The slab loop is a run-time loop around ONE copy of the epilogue code (inlined per slab, the FiLM epilogue alone made
+  // a 58k-instruction kernel); only the accumulator -> LDS copies, which need compile-time register indices, are per slab.
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
-  auto slab = [&](auto mh_c, auto nh_c) {
-    constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
-    constexpr int NTS = NH == 2 ? 3 : 4;  // n-tiles in this slab
+  constexpr int NHS = (NTW + 3) / 4;
+#pragma unroll 1
+  for (int sidx = 0; sidx < 2 * NHS; ++sidx) {
+    static_for<2 * NHS>([&](auto s_c) {
+      constexpr int MH = decltype(s_c)::value / NHS, NH = decltype(s_c)::value % NHS;
+      constexpr int NTS = NTW - 4 * NH < 4 ? NTW - 4 * NH : 4;  // n-tiles in this slab
+      if (sidx == MH * NHS + NH) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NTS; ++nt)
-        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[NH * 4 + nt][MH * 4 + mt];
+          for (int nt = 0; nt < NTS; ++nt)
+            *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[NH * 4 + nt][MH * 4 + mt];
+      }
+    });
+    const int mh = sidx / NHS, nh = sidx - mh * NHS;
+    const int nts = NTW - 4 * nh < 4 ? NTW - 4 * nh : 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + MH * 64, n0 + wn * 176 + NH * 64, g, lane, NTS * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-  slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next slab overwrites it
+  }
 }
 
 // In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
@@ -1346,22 +1383,25 @@ static int launch_row(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
-template <typename E, int EPI, bool TAPS_INNER>
+template <typename E, int EPI, bool TAPS_INNER, int NTW>
 static void launch_fat_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW>), grid, dim3(256), lds, s, p);
 }
 
-template <typename E, int EPI>
+// NTW = 11: the 256 x 352 tile (caller guarantees N % 352 == 0, BIAS epilogue); NTW = 8: the 256 x 256 one-wave-per-SIMD tile.
+template <typename E, int EPI, int NTW>
 static int launch_fat(const DnGemmParams& p, hipStream_t s) {
-  constexpr int ring = 4 * (352 + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
+  constexpr int BNF = 32 * NTW;
+  constexpr int ring = 4 * (BNF + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
-  dim3 grid(((p.M + 255) / 256) * (p.N / 352), p.groups);
+  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  dim3 grid(((p.M + 255) / 256) * ((np + BNF - 1) / BNF), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
   // Tap-inner K order (see the kernel): opt-in -- DN_FAT_TAPS_INNER=1 or bit 22 of pad_ -- because it changes the fp32
   // summation order, and with it the last bits, relative to every other tile variant (which are all term-outer and
@@ -1376,10 +1416,10 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
            (intptr_t)a.W - (intptr_t)b.W == (intptr_t)t1.W - (intptr_t)t0.W;
   }
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-  if (taps) launch_fat_variant<E, EPI, true>(p, grid, lds, s);
-  else launch_fat_variant<E, EPI, false>(p, grid, lds, s);
+  if (taps) launch_fat_variant<E, EPI, true, NTW>(p, grid, lds, s);
+  else launch_fat_variant<E, EPI, false, NTW>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
-  DN_CHECK_LAUNCH("dn_conv_gemm (fat tile)");
+  DN_CHECK_LAUNCH("dn_conv_gemm (one-wave-per-SIMD tile)");
   return DN_OK;
 }
 
@@ -1395,7 +1435,10 @@ static int launch(const DnGemmParams& p, hipStream_t s) {
     // the 256 x 352 one-wave-per-SIMD tile: bf16, N a multiple of 352 and at least ~half a chip of tiles (a workgroup owns a CU's whole LDS;
     // measured +2.5 % per denoising step on half batches, +5 % on whole ones, against the 256 x 256 tile)
     const long tiles_fat = (long)((p.M + 255) / 256) * (p.N / 352) * p.groups;
-    if (p.N % 352 == 0 && (force == 4 || (force == 0 && tiles_fat >= 100))) return launch_fat<E, EPI>(p, s);
+    if (p.N % 352 == 0 && (force == 4 || (force == 0 && tiles_fat >= 100))) return launch_fat<E, EPI, 11>(p, s);
+  }
+  if constexpr (std::is_same<E, BF16>::value) {
+    if (force == 6) return launch_fat<E, EPI, 8>(p, s);
   }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;

@@ -92,7 +92,8 @@ typedef struct {
   int32_t pad_;        /* profiling only.  bits 0..7: ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip
                           LDS reads inside the K loop, bit3 no s_setprio, bit4 4-column instead of 8-column bf16 stores), 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start; bits 16..19: force a tile variant (tests: 1 = 128x128,
-                          2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0), 0 = chosen from the shape; bit 22: let the
+                          2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0, 6 = 256x256 with one wave per SIMD [bf16]),
+                          0 = chosen from the shape; bit 22: let the
                           256x352 tile run the taps of a causal conv innermost in K (fewer fabric re-reads of the
                           activation panel; changes the fp32 summation order, so off unless asked for)          */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */

@@ -79,12 +79,12 @@ def test_causal_conv_gemm(ops, dtype, cin, cout, k, dil, B, T):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (128, 1056, 1, 1, 1, 515),
                                                 (64, 352, 1, 1, 2, 130), (1408, 1408, 3, 1, 4, 512)])
 def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil, B, T):
     """The same causal conv through each forced tile variant (128x128, 256x128, 256x256, 256x352, and 256x352 with the
-    taps innermost in K = "tile 5"): ragged M, N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term
+    taps innermost in K = "tile 5"; 6 = the 256x256 one-wave-per-SIMD tile, bf16 only): ragged M, N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term
     (pipeline prologue/drain edges), sequence starts inside a tile (T = 100, 130, 300)."""
     ops_, packing, _lib = ops
     code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
@@ -99,12 +99,12 @@ def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil
     out = torch.full((B * T, N), float("nan"), device=DEV)
     bias = packing._vec(b, W.shape[1]).to(DEV)
     terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
-    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=min(tile, 4), taps_inner=tile == 5)
+    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4 if tile == 5 else tile, taps_inner=tile == 5)
     got = out.cpu().view(B, T, -1)
     if tile > 1:  # every term-outer variant sums K in the same order: bit-identical outputs
         ref_out = torch.empty_like(out)
         ops_.conv_gemm(terms, ref_out, T, N, bias=bias, tile=1)
-        if tile < 5:
+        if tile != 5:
             assert torch.equal(out, ref_out)
         else:
             assert maxerr(out.cpu(), ref_out.cpu()) < 1e-4
@@ -114,9 +114,11 @@ def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil
         assert maxerr(got, O.causal_conv1d(x, w, b, dil)) < 1e-4
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 6])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_wavenet_block_group_film_gate(ops, dtype):
-    """Grouped dilated conv + FiLM + tanh*sigmoid + residual (reference latent_module.py:513-536)."""
+def test_wavenet_block_group_film_gate(ops, dtype, tile):
+    """Grouped dilated conv + FiLM + tanh*sigmoid + residual (reference latent_module.py:513-536), through the tile
+    variants that carry this epilogue (6 = one-wave-per-SIMD 256x256, bf16; f32 falls back to the shape's default)."""
     ops_, packing, _lib = ops
     code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
     B, T, D, L = 2, 48, 64, 3
@@ -144,20 +146,21 @@ def test_wavenet_block_group_film_gate(ops, dtype):
     resb = torch.stack([sd["res_conv.bias"] for sd in sds]).to(DEV)
     gb = torch.stack(gbs, dim=1).contiguous().to(DEV)  # [B, L, 2D]
     res = torch.empty(L, M, D, device=DEV, dtype=xa.dtype)
-    ops_.conv_gemm([(xa, resW, 0)], res, T, D, bias=resb, groups=L, a_grouped=False)
+    ops_.conv_gemm([(xa, resW, 0)], res, T, D, bias=resb, groups=L, a_grouped=False, tile=tile)
     out = torch.empty(L, M, D, device=DEV, dtype=xa.dtype)
     terms = [(xa, convW[:, j].contiguous(), 2 - j) for j in range(3)]
     # w_gstride must step whole per-block matrices: pass taps as separate contiguous [L,128,64] stacks
     ops_.conv_gemm(terms, out, T, D, bias=convb, epilogue=_lib.EPI_FILM_GATE, groups=L, res=res, gamma_beta=gb.view(B, -1),
-                   gb_half=D, shift_by_group=True, a_grouped=False)
+                   gb_half=D, shift_by_group=True, a_grouped=False, tile=tile)
     got = out.float().cpu().view(L, B, T, D)
     tol = 2e-2 if dtype == "bf16" else 1e-4  # bf16: res and out are stored bf16 (one rounding each)
     for i in range(L):
         assert maxerr(got[i], want[i]) < tol, i
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 6])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_geglu_and_resadd_and_posemb(ops, dtype):
+def test_geglu_and_resadd_and_posemb(ops, dtype, tile):
     """GEGLU-interleaved Linear (reference :881-903), residual epilogue (:692,704), pos-emb epilogue (:867-868)."""
     ops_, packing, _lib = ops
     code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
@@ -178,7 +181,7 @@ def test_geglu_and_resadd_and_posemb(ops, dtype):
     M = B * T
     xa = act(x.view(M, D), dtype)
     out = torch.full((M, ip), float("nan"), device=DEV)
-    ops_.conv_gemm([(xa, act(wp, dtype), 0)], out, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU)
+    ops_.conv_gemm([(xa, act(wp, dtype), 0)], out, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tile)
     got = out.cpu().view(B, T, ip)
     assert maxerr(got[..., :inner], want) < (2e-4 if dtype == "bf16" else 1e-4)
     assert got[..., inner:].abs().max().item() == 0.0
@@ -186,7 +189,7 @@ def test_geglu_and_resadd_and_posemb(ops, dtype):
     w2 = seeded((D, D), 4, D ** -0.5)
     xres = seeded((M, D), 5).to(DEV)
     want2 = xres.cpu() + torch.nn.functional.linear(rnd(x.view(M, D)), rnd(w2))
-    ops_.conv_gemm([(xa, packing._mat(w2, code).to(DEV), 0)], xres, T, D, epilogue=_lib.EPI_RESADD, res=xres)
+    ops_.conv_gemm([(xa, packing._mat(w2, code).to(DEV), 0)], xres, T, D, epilogue=_lib.EPI_RESADD, res=xres, tile=tile)
     assert maxerr(xres.cpu(), want2) < (2e-4 if dtype == "bf16" else 1e-4)
     # positional embedding epilogue
     lens = torch.tensor([33, 20])
@@ -195,7 +198,7 @@ def test_geglu_and_resadd_and_posemb(ops, dtype):
     tab = packing.sinusoidal_table(T + 1, D, D).to(DEV)
     out3 = torch.empty(M, D, device=DEV)
     ops_.conv_gemm([(xa, packing._mat(w2, code).to(DEV), 0)], out3, T, D, epilogue=_lib.EPI_POSEMB, pos_table=tab,
-                   lengths=lens.to(DEV).int())
+                   lengths=lens.to(DEV).int(), tile=tile)
     assert maxerr(out3.cpu().view(B, T, D), want3) < (2e-4 if dtype == "bf16" else 1e-4)
     assert maxerr(tab.cpu()[1:, :], O.sinusoidal_table(T + 1, D)[1:]) == 0.0
 
