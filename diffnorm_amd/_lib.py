@@ -38,7 +38,10 @@ class GemmParams(C.Structure):
                 ("pad_", C.c_int32), ("lengths", C.c_void_p),
                 ("norm_out", C.c_void_p), ("norm_ld", C.c_int32), ("norm_dtype", C.c_int32), ("norm_D", C.c_int32),
                 ("norm_gb_ld", C.c_int32), ("norm_gamma", C.c_void_p), ("norm_gb", C.c_void_p),
-                ("norm_gb_half", C.c_int32), ("pad2_", C.c_int32)]
+                ("norm_gb_half", C.c_int32), ("pad2_", C.c_int32),
+                ("norm_split", C.c_int32), ("norm_ssq_ld", C.c_int32), ("norm_ssq", C.c_void_p),
+                ("row_ssq", C.c_void_p), ("row_ssq_ld", C.c_int32), ("row_ssq_parts", C.c_int32),
+                ("row_D", C.c_float), ("row_bias_ld", C.c_int32), ("row_bias", C.c_void_p)]
 
 
 class AttnParams(C.Structure):

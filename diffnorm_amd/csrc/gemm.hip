@@ -112,6 +112,21 @@ __device__ __forceinline__ float4 load4t(const void* base, int64_t off) {
 }
 
 // OUT_BF / RES_BF: storage types fixed at compile time; FULL: every row of the slab is inside M (no per-row guards).
+// Split RMSNorm, consumer side (DnGemmParams.row_ssq): lane r of the wave turns the partial sums of squares of row
+// m_base + r into the row's factor sqrt(D) / max(|row|, 1e-12) and parks it in the slab's pad column 64, where the
+// epilogue's row loop picks it up (one LDS pipeline per wave, in order: no barrier needed).
+__device__ __forceinline__ void park_row_scales(const DnGemmParams& p, float* ep, int m_base, int lane) {
+  int m = m_base + lane;
+  m = m < p.M ? m : p.M - 1;
+  const float* q = p.row_ssq + (int64_t)m * p.row_ssq_ld;
+  float ss = 0.f;
+  for (int j = 0; j < p.row_ssq_parts; ++j) ss += q[j];
+  ep[lane * EP_LD + 64] = sqrtf(p.row_D) / fmaxf(sqrtf(ss), 1e-12f);
+}
+__device__ __forceinline__ const float* row_bias_of(const DnGemmParams& p, int m) {
+  return p.row_bias + (p.row_bias_ld ? (int64_t)(m / p.T) * p.row_bias_ld : 0);
+}
+
 // 8 consecutive bf16 outputs per lane = one 16-byte store: bf16 output stores are issue-bound (a wave-instruction moves
 // 512 B as dwordx2 but 1 KiB as dwordx4), so halving their number halves the store tail of the epilogue.
 __device__ __forceinline__ void store8_bf16(void* base, int64_t off, const float (&v)[8]) {
@@ -148,6 +163,19 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
       *reinterpret_cast<float4*>(gt) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8);
       *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8 + 4);
+      if (p.row_ssq) {  // split norm: scale the accumulators by the row's factor, add beta . W^T
+        const float sm = ep[row * EP_LD + 64];
+        float rv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.row_bias) {
+          const float* rb = row_bias_of(p, m);
+          *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(rb + np);
+          *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + np + 4);
+          *reinterpret_cast<float4*>(rg) = *reinterpret_cast<const float4*>(rb + np + 32);
+          *reinterpret_cast<float4*>(rg + 4) = *reinterpret_cast<const float4*>(rb + np + 36);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = fmaf(v[i], sm, rv[i]); gt[i] = fmaf(gt[i], sm, rg[i]); }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
       store8_bf16(out, (int64_t)m * p.ldo + n, o);
@@ -169,6 +197,17 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       float v[8];
       *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8);
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
+      if (p.row_ssq) {
+        const float sm = ep[row * EP_LD + 64];
+        float rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.row_bias) {
+          const float* rb = row_bias_of(p, m);
+          *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(rb + n);
+          *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + n + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sm, rv[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         v[i] += bv[i];
@@ -197,8 +236,19 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
       const int row = j * 8 + (lane >> 3);
       const int m = m_base + row;
       if (!FULL && m >= p.M) continue;
-      const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-      const float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
+      float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+      float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
+      if (p.row_ssq) {
+        const float sm = ep[row * EP_LD + 64];
+        float4 rv = make_float4(0, 0, 0, 0), rg = rv;
+        if (p.row_bias) {
+          const float* rb = row_bias_of(p, m);
+          rv = *reinterpret_cast<const float4*>(rb + np);
+          rg = *reinterpret_cast<const float4*>(rb + np + 32);
+        }
+        v = make_float4(fmaf(v.x, sm, rv.x), fmaf(v.y, sm, rv.y), fmaf(v.z, sm, rv.z), fmaf(v.w, sm, rv.w));
+        gt = make_float4(fmaf(gt.x, sm, rg.x), fmaf(gt.y, sm, rg.y), fmaf(gt.z, sm, rg.z), fmaf(gt.w, sm, rg.w));
+      }
       store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
                       gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
     }
@@ -270,7 +320,15 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         const int row = (jb + i) * 4 + (lane >> 4);
         const int m = m_base + row;
         if (!FULL && m >= p.M) continue;
-        const float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+        float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+        if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU) {
+          if (p.row_ssq) {  // split norm, consumer side
+            const float sm = ep[row * EP_LD + 64];
+            float4 rb4 = make_float4(0, 0, 0, 0);
+            if (p.row_bias) rb4 = *reinterpret_cast<const float4*>(row_bias_of(p, m) + n);
+            a4 = make_float4(fmaf(a4.x, sm, rb4.x), fmaf(a4.y, sm, rb4.y), fmaf(a4.z, sm, rb4.z), fmaf(a4.w, sm, rb4.w));
+          }
+        }
         float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
         if constexpr (EPI == DN_EPI_SILU) {
           v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
@@ -284,6 +342,21 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
           v0 += rv[i].x; v1 += rv[i].y; v2 += rv[i].z; v3 += rv[i].w;
         }
         store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, v0, v1, v2, v3);
+        if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
+          if (p.norm_split) {  // split norm, producer side: row * gamma for the consuming contraction + this slab's sum of squares
+            float4 ga = make_float4(1, 1, 1, 1);
+            if (p.norm_gb) ga = *reinterpret_cast<const float4*>(p.norm_gb + (p.norm_gb_ld ? (int64_t)(m / p.T) * p.norm_gb_ld : 0) + n);
+            else if (p.norm_gamma) ga = *reinterpret_cast<const float4*>(p.norm_gamma + n);
+            if (p.norm_dtype == DN_BF16) store4t<true>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
+            else store4t<false>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
+            float q = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;  // the row's 16 lanes are lanes (lane & ~15) .. +15
+            q += __shfl_xor(q, 1);
+            q += __shfl_xor(q, 2);
+            q += __shfl_xor(q, 4);
+            q += __shfl_xor(q, 8);
+            if ((lane & 15) == 0) p.norm_ssq[(int64_t)m * p.norm_ssq_ld + (n_base >> 6)] = q;
+          }
+        }
       }
     }
   }
@@ -296,6 +369,9 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
   const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
+  if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
+    if (p.row_ssq) park_row_scales(p, const_cast<float*>(ep), m_base, lane);
+  }
 #define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols)
   if constexpr (RESADD) {
     if (full) DN_EP(false, false, true); else DN_EP(false, false, false);
@@ -1426,7 +1502,7 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
 template <typename E, int EPI>
 static int launch(const DnGemmParams& p, hipStream_t s) {
   if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
-    if (p.norm_out) return launch_row<E, EPI>(p, s);
+    if (p.norm_out && !p.norm_split) return launch_row<E, EPI>(p, s);
   }
   // Tile variant: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests) force one, 0 = choose by shape.
   static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
@@ -1508,12 +1584,24 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   if (p.epilogue == DN_EPI_RESADD) DN_CHECK_ARG(p.out_dtype == DN_F32, "dn_conv_gemm: RESADD writes fp32");
   if (p.epilogue == DN_EPI_POSEMB) DN_CHECK_ARG(p.pos_table && p.lengths && p.pos_ld % 4 == 0, "dn_conv_gemm: POSEMB needs pos_table and lengths");
   if (p.epilogue == DN_EPI_FILM_GATE && p.gamma_beta) DN_CHECK_ARG(p.gb_half % 4 == 0 && p.gb_ld % 4 == 0, "dn_conv_gemm: gamma_beta strides must be multiples of 4");
-  if (p.norm_out) {
+  if (p.norm_split) {
+    DN_CHECK_ARG(p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB, "dn_conv_gemm: norm_split needs a RESADD or POSEMB epilogue");
+    DN_CHECK_ARG(p.norm_out && p.norm_ssq && p.N % 64 == 0 && p.norm_ld % 4 == 0 && p.norm_ld >= p.N && p.norm_ssq_ld * 64 >= p.N,
+                 "dn_conv_gemm: norm_split needs norm_out, norm_ssq and N a multiple of 64 (N=%d)", p.N);
+    DN_CHECK_ARG(p.norm_dtype == DN_F32 || p.norm_dtype == DN_BF16, "dn_conv_gemm: bad norm_dtype");
+    DN_CHECK_ARG(!p.norm_gb || p.norm_gb_ld % 4 == 0, "dn_conv_gemm: norm_gb stride must be a multiple of 4");
+  } else if (p.norm_out) {
     DN_CHECK_ARG(p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB, "dn_conv_gemm: norm_out needs a RESADD or POSEMB epilogue");
     DN_CHECK_ARG(p.N <= 512 && p.out_dtype == DN_F32, "dn_conv_gemm: the fused norm needs N <= 512 and an fp32 stream");
     DN_CHECK_ARG(p.norm_D > 0 && p.norm_D <= p.N && p.norm_D % 4 == 0 && p.norm_ld % 4 == 0 && p.norm_ld >= p.norm_D && p.norm_ld <= 512,
                  "dn_conv_gemm: bad norm_D=%d / norm_ld=%d", p.norm_D, p.norm_ld);
     DN_CHECK_ARG(!p.norm_gb || (p.norm_gb_ld % 4 == 0 && p.norm_gb_half % 4 == 0), "dn_conv_gemm: norm_gb strides must be multiples of 4");
+  }
+  if (p.row_ssq) {
+    DN_CHECK_ARG(p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU,
+                 "dn_conv_gemm: row_ssq (split norm) needs a BIAS, SILU or GEGLU epilogue");
+    DN_CHECK_ARG(p.row_ssq_parts >= 1 && p.row_ssq_ld >= p.row_ssq_parts && p.row_D > 0.f, "dn_conv_gemm: bad row_ssq_parts / row_ssq_ld / row_D");
+    DN_CHECK_ARG(p.row_bias_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p.row_bias) & 15) == 0, "dn_conv_gemm: row_bias must be 16-byte aligned, stride a multiple of 4");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return p.dtype == DN_BF16 ? dn::dispatch_epi<dn::BF16>(p, s) : dn::dispatch_epi<dn::F32>(p, s);

@@ -31,7 +31,9 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               gb_half: int = 0, pos_table: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
               shift_by_group: bool = False, a_grouped: bool = True, norm_out: Optional[torch.Tensor] = None,
               norm_D: int = 0, norm_gamma: Optional[torch.Tensor] = None, norm_gb: Optional[torch.Tensor] = None,
-              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: bool = False):
+              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: bool = False,
+              norm_ssq: Optional[torch.Tensor] = None, row_ssq: Optional[torch.Tensor] = None, row_D: int = 0,
+              row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
@@ -76,6 +78,16 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
         p.norm_gb = _lib.ptr(norm_gb)
         p.norm_gb_ld = 0 if (norm_gb is None or norm_gb_shared) else norm_gb.stride(0)
         p.norm_gb_half = norm_gb_half
+        if norm_ssq is not None:  # split norm, producer side: norm_out = row * gamma, norm_ssq = partial sums of squares
+            assert norm_ssq.dtype == torch.float32 and norm_ssq.shape[-1] * 64 >= N
+            p.norm_split, p.norm_ssq, p.norm_ssq_ld = 1, norm_ssq.data_ptr(), norm_ssq.shape[-1]
+    if row_ssq is not None:  # split norm, consumer side
+        assert row_ssq.dtype == torch.float32 and row_D > 0
+        p.row_ssq, p.row_ssq_ld, p.row_ssq_parts, p.row_D = row_ssq.data_ptr(), row_ssq.shape[-1], row_ssq.shape[-1], float(row_D)
+        if row_bias is not None:
+            assert row_bias.dtype == torch.float32
+            p.row_bias = row_bias.data_ptr()
+            p.row_bias_ld = 0 if row_bias_shared else row_bias.stride(0)
     p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16) | (int(taps_inner) << 22)  # ablation switches (tools/gemm_bench.py) | forced tile / K order (tests)
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out

@@ -105,6 +105,21 @@ typedef struct {
   const float* norm_gamma; /* learned gamma [norm_D] or NULL                                         */
   const float* norm_gb;    /* adaptive rows [Bc, norm_gb_ld]: gamma at col 0.., beta at norm_gb_half.. or NULL */
   int32_t norm_gb_half, pad2_;
+  /* Split RMSNorm: the norm of a row is divided between the contraction that produces the row and the one that consumes
+   * it, so no separate pass over the residual stream remains (x/|x| * sqrt(D) * g + b feeding a Linear W equals
+   * (sqrt(D)/|x|) * ((x*g) W^T) + b W^T).
+   * Producer (RESADD / POSEMB, N a multiple of 64, any tile): norm_split != 0 makes norm_out receive out_row * gamma
+   * (norm_gamma, or the gamma half of norm_gb per sample) WITHOUT the 1/|row| factor, and norm_ssq[m, n/64] the sum of
+   * squares of the 64 output columns of row m that one wave produced (no atomics: the consumer adds the partials).
+   * Consumer (BIAS / SILU / GEGLU): row_ssq != NULL makes out = acc * sqrt(row_D) / max(sqrt(sum_j row_ssq[m, j]), 1e-12)
+   * + bias + row_bias[b], with row_bias = beta W^T (+ the layer bias) precomputed by the caller, NULL when there is no beta. */
+  int32_t norm_split, norm_ssq_ld;
+  float* norm_ssq;         /* [M, norm_ssq_ld]                                                       */
+  const float* row_ssq;    /* [M, row_ssq_ld], row_ssq_parts partials per row                        */
+  int32_t row_ssq_ld, row_ssq_parts;
+  float row_D;             /* the norm's D (not padded)                                              */
+  int32_t row_bias_ld;     /* elements between batch rows of row_bias (0 = one row for the batch)    */
+  const float* row_bias;   /* [Bc, >= N (packed columns for GEGLU)] fp32 or NULL                     */
 } DnGemmParams;
 
 int dn_conv_gemm(const DnGemmParams* p, void* stream);

@@ -254,6 +254,87 @@ def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("mode", ["adaptive", "adaptive_shared", "learned"])
+@pytest.mark.parametrize("D,K,N2,B,T", [(512, 320, 384, 2, 100), (100, 64, 200, 3, 37)])
+def test_split_rmsnorm_producer_and_consumers(ops, dtype, tile, mode, D, K, N2, B, T):
+    """RMSNorm split across the contraction that produces a row and the ones that consume it (reference
+    latent_module.py:620-639 between :692/704 and :930-931/899): RESADD emits row*gamma and per-64-column sums of squares,
+    the BIAS and GEGLU consumers apply sqrt(D)/|row| to their accumulators and add beta.W^T; against the oracle's
+    rms_norm -> linear."""
+    ops_, packing, _lib = ops
+    code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
+    rnd = bf16r if dtype == "bf16" else (lambda z: z)
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    M, Dp = B * T, padk(D)
+    a = seeded((B, T, K), 1)
+    w = seeded((D, K), 2, K ** -0.5)
+    bias = seeded((D,), 3, 0.1)
+    x0 = seeded((M, D), 4, 2.0)
+    Bc = 1 if mode == "adaptive_shared" else B
+    gb = torch.zeros(Bc, 2 * Dp)
+    gb[:, :D] = seeded((Bc, D), 5, 0.5) + 1.0
+    gb[:, Dp:Dp + D] = seeded((Bc, D), 6, 0.3)
+    gamma = seeded((D,), 7, 0.2) + 1.0
+    x_new = x0.view(B, T, D) + torch.nn.functional.linear(rnd(a), rnd(w), bias)
+    if mode == "learned":
+        g_rows, b_rows = gamma.view(1, D).expand(B, D), torch.zeros(B, D)
+    else:
+        g_rows, b_rows = gb[:, :D].expand(B, D), gb[:, Dp:Dp + D].expand(B, D)
+    xn_ref = O.rms_norm(x_new) * g_rows.unsqueeze(1) + b_rows.unsqueeze(1)
+    # ---- producer
+    xd = pad_cols(x0, Dp).to(DEV)
+    xg = torch.full((M, Dp), float("nan"), device=DEV, dtype=adt)
+    ssq = torch.full((M, Dp // 64), float("nan"), device=DEV)
+    kw = dict(norm_out=xg, norm_D=D, norm_ssq=ssq)
+    if mode == "learned":
+        kw.update(norm_gamma=pad_cols(gamma, Dp).to(DEV))
+    else:
+        kw.update(norm_gb=gb.to(DEV), norm_gb_half=Dp, norm_gb_shared=mode == "adaptive_shared")
+    ops_.conv_gemm([(act(pad_cols(a, padk(K)).view(M, -1), dtype), packing._mat(w, code).to(DEV), 0)], xd, T, Dp,
+                   bias=packing._vec(bias, Dp).to(DEV), epilogue=_lib.EPI_RESADD, res=xd, tile=tile, **kw)
+    assert maxerr(xd.cpu().view(B, T, Dp)[..., :D], x_new) < (5e-4 if dtype == "bf16" else 1e-4)
+    assert maxerr(ssq.sum(1).cpu(), (x_new.view(M, D) ** 2).sum(1)) < 1e-3 * (x_new ** 2).sum(-1).max().item()
+    want_xg = x_new * g_rows.unsqueeze(1)
+    assert maxerr(xg.float().cpu()[:, :D].view(B, T, D), want_xg) < (2 ** -8 * want_xg.abs().max().item() if dtype == "bf16" else 1e-4)
+    assert xg.float().cpu()[:, D:].abs().max().item() == 0.0 if Dp > D else True
+    # ---- consumer 1: Linear + bias (the q/kv projection's shape of use)
+    w3 = seeded((N2, D), 8, D ** -0.5)
+    b3 = seeded((N2,), 9, 0.1)
+    want = torch.nn.functional.linear(rnd(xn_ref), rnd(w3), b3)
+    rb = torch.nn.functional.linear(b_rows[:Bc] if mode != "learned" else b_rows[:1], rnd(w3))  # beta . W^T  [Bc, N2]
+    N2p = padk(N2)
+    out = torch.full((M, N2p), float("nan"), device=DEV, dtype=adt)
+    ckw = dict(row_ssq=ssq, row_D=D)
+    if mode != "learned":
+        ckw.update(row_bias=pad_cols(rb, N2p).to(DEV), row_bias_shared=mode == "adaptive_shared")
+    ops_.conv_gemm([(xg, packing._mat(w3, code, ).to(DEV), 0)], out, T, N2p, bias=packing._vec(b3, packing.padn(N2)).to(DEV), tile=tile, **ckw)
+    tol = 4e-2 if dtype == "bf16" else 2e-4
+    assert maxerr(out.float().cpu()[:, :N2].view(B, T, N2), want) < tol * max(1.0, want.abs().max().item())
+    # ---- consumer 2: GEGLU projection
+    inner = 96
+    ip = padk(inner)
+    wg = seeded((2 * inner, D), 10, D ** -0.5)
+    bg = seeded((2 * inner,), 11, 0.2)
+    h = torch.nn.functional.linear(rnd(xn_ref), rnd(wg), bg)
+    val, gate = h.chunk(2, dim=-1)
+    want_g = torch.nn.functional.gelu(gate) * val
+    rows = packing._geglu_rows(inner)
+    keep = rows >= 0
+    wp, bp = torch.zeros(2 * ip, Dp), torch.zeros(2 * ip)
+    wp[keep, :D], bp[keep] = wg[rows[keep]], bg[rows[keep]]
+    rbg = torch.nn.functional.linear(pad_cols(b_rows[:Bc] if mode != "learned" else b_rows[:1], Dp), rnd(wp))  # packed column order
+    outg = torch.full((M, ip), float("nan"), device=DEV, dtype=adt)
+    gkw = dict(row_ssq=ssq, row_D=D)
+    if mode != "learned":
+        gkw.update(row_bias=rbg.contiguous().to(DEV), row_bias_shared=mode == "adaptive_shared")
+    ops_.conv_gemm([(xg, act(wp, dtype), 0)], outg, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tile, **gkw)
+    gotg = outg.float().cpu().view(B, T, ip)
+    assert maxerr(gotg[..., :inner], want_g) < tol * max(1.0, want_g.abs().max().item())
+    assert gotg[..., inner:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("heads,dh,B,T,lens", [(8, 64, 2, 200, [200, 77]), (8, 96, 1, 130, [101]), (4, 16, 3, 40, [40, 1, 23]),
                                                (2, 32, 2, 64, [64, 0])])
 def test_attention(ops, dtype, heads, dh, B, T, lens):
