@@ -61,7 +61,9 @@ struct DnEps {
   const void *cond_W, *init_W, *final_W;
   dn::WavenetW wn;
   dn::TransformerW tf;
-  int n_cond;  // columns of the conditioning table: 2*padk(dim) per conditioned module
+  int n_cond;  // conditioning columns of a row: 2*padk(dim) per conditioned module
+  int n_row;   // row stride of the conditioning table: n_cond, then (split RMSNorm) the depth x (3 hd + 2 padk(inner))
+               // columns of beta . W^T for the adaptive norms' consumers
   // hipGraph cache for dn_ddim_loop
   void* graph_exec;
   int graph_B, graph_T;
@@ -71,6 +73,9 @@ struct DnEps {
   const float* graph_coef;
   int graph_flags;
   void *side_stream, *ev_fork, *ev_join;  // DN_LOOP_SPLIT2: second half-batch stream and its fork/join events
+  // DN_LOOP_KEEP_TABLE: the conditioning table built by the previous dn_ddim_loop call on this workspace
+  void* table_ws;
+  int table_B, table_T, table_split, table_rows;
 };
 constexpr int kEpsTensors = 7 + dn::kWavenetTensors + dn::kTransformerTensors + 3;
 

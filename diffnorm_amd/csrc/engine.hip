@@ -32,6 +32,15 @@ inline bool fuse_norm_enabled(int Dp) {
   return on && Dp <= 512;
 }
 
+// Split RMSNorm (DnGemmParams.norm_split / row_ssq): every RMSNorm of the transformer is divided between the residual-
+// closing contraction that produces its input and the projection that consumes its output, so the 2*depth+1 norm passes
+// over the residual stream disappear (measured: -6 % per denoising step at [32,512] x dim 512).  DN_NO_SPLIT_NORM=1 runs
+// the standalone norm kernel instead (A/B timing, and the reference point of the parity tests).
+inline bool split_norm_enabled(int Dp) {
+  const char* e = getenv("DN_NO_SPLIT_NORM");  // read per call: tests toggle it
+  return !(e && atoi(e) != 0) && Dp % 64 == 0 && !fuse_norm_enabled(Dp);
+}
+
 DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
   DnGemmParams p;
   memset(&p, 0, sizeof(p));
@@ -127,7 +136,10 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
 }
 
 // ------------------------------------------------------------------------------------------ transformer
-struct TfBufs { void *xn, *qkv, *ao, *gg, *fc; };
+struct TfBufs { void *xn, *qkv, *ao, *gg, *fc; float* ssq; };
+// row stride of the sums-of-squares buffer: one float per 64 columns, padded to >= 8 and a multiple of 4 so a consumer
+// can fetch a row's partials with two 16-byte loads at kernel start
+inline int ssq_ld(int Dp) { const int n = Dp / 64; return n <= 8 ? 8 : (n + 3) / 4 * 4; }
 
 TfBufs plan_tf(const TransformerW& w, int M, int es, Arena& ar) {
   const int hd = w.heads * w.dim_head;
@@ -137,7 +149,21 @@ TfBufs plan_tf(const TransformerW& w, int M, int es, Arena& ar) {
   b.ao = ar.take((size_t)M * hd * es);
   b.gg = ar.take((size_t)M * padk(w.inner) * es);
   b.fc = ar.take((size_t)M * padk(w.inner) * es);
+  b.ssq = (float*)ar.take((size_t)M * ssq_ld(padk(w.dim)) * 4);  // split RMSNorm: per-64-column sums of squares
   return b;
+}
+
+// Producer half of a split RMSNorm on a RESADD / POSEMB contraction: row * gamma -> xn, per-slab sums of squares -> ssq.
+void set_split_norm(DnGemmParams& p, const TfBufs& tb, int Dp, int D, int dtype, const float* gamma, const float* gb, int gb_ld) {
+  p.norm_out = tb.xn; p.norm_ld = Dp; p.norm_dtype = dtype; p.norm_D = D;
+  p.norm_gamma = gamma; p.norm_gb = gb; p.norm_gb_ld = gb_ld; p.norm_gb_half = Dp;
+  p.norm_split = 1; p.norm_ssq = tb.ssq; p.norm_ssq_ld = ssq_ld(Dp);
+}
+// Consumer half: scale the accumulators by sqrt(D)/|row| and add beta . W^T (rb: the consumer's columns of the row-bias
+// block, NULL when the norm has no beta).
+void set_row_scale(DnGemmParams& p, const TfBufs& tb, int Dp, int D, const float* rb, int rb_ld) {
+  p.row_ssq = tb.ssq; p.row_ssq_ld = ssq_ld(Dp); p.row_ssq_parts = Dp / 64; p.row_D = (float)D;
+  p.row_bias = rb; p.row_bias_ld = rb_ld;
 }
 
 // Fills the fused-RMSNorm fields of a RESADD / POSEMB contraction (see DnGemmParams.norm_out).
@@ -159,21 +185,27 @@ NormSrc norm_src(const TransformerW& w, const float* gb, int l, int j) {
 // xres fp32 [M, padk(dim)] is updated in place; `pred` receives to_pred's output.  When the model width fits the
 // whole-row tile (padk(dim) <= 512) every RMSNorm is fused into the contraction that produces its input: the caller
 // supplies the first one (`xn_ready`: tb.xn already holds layer 0's attention norm) or it runs standalone once.
+// `rb` (split RMSNorm with adaptive norms only): fp32 rows [Bc, gb_ld] of beta . W^T, layer l at columns
+// l * (3 hd + 2 padk(inner)): first the q/kv projection's, then the GEGLU projection's (packed column order).
 int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T, const int32_t* lengths, const float* gb, int gb_ld,
-                    const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
+                    const float* rb, const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
   const int es = esize(dtype), M = B * T;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
   const bool fuse = fuse_norm_enabled(Dp);
+  const bool split = split_norm_enabled(Dp);
+  const int rb_layer = 3 * hd + 2 * ip;
+  bool scaled = split && xn_ready;  // tb.xn holds row*gamma + tb.ssq its sums of squares (else: the finished norm)
   auto standalone_norm = [&](int l, int j) -> int {
     const NormSrc ns = norm_src(w, gb, l, j);
     return dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, ns.gamma, ns.gb, gb_ld, Dp, s);
   };
-  if (!(fuse && xn_ready)) DN_TRY(standalone_norm(0, 0));
+  if (!((fuse || split) && xn_ready)) DN_TRY(standalone_norm(0, 0));
   for (int l = 0; l < w.depth; ++l) {
     {  // to_q ; to_kv in one contraction (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
       p.out = tb.qkv; p.ldo = 3 * hd;
+      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {
@@ -189,18 +221,19 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
       p.terms[0].A = tb.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      if (fuse) {
-        const NormSrc ns = norm_src(w, gb, l, 1);
-        set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
-      }
+      const NormSrc ns = norm_src(w, gb, l, 1);
+      if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
-    if (!fuse) DN_TRY(standalone_norm(l, 1));
+    if (!fuse && !split) DN_TRY(standalone_norm(l, 1));
+    scaled = split;
     {  // Linear(D -> 2*inner) + GEGLU (:899,881-884)
       DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
       p.bias = w.ffin_b + (size_t)l * 2 * ip;
       p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
+      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {  // CausalConv1d(inner, inner, 3) (:894)
@@ -219,19 +252,19 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       p.terms[0].A = tb.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
       p.bias = w.ffout_b + (size_t)l * Dp;
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      if (fuse) {
-        const NormSrc ns = norm_src(w, gb, l + 1, 0);
-        set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
-      }
+      const NormSrc ns = norm_src(w, gb, l + 1, 0);
+      if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
-    if (!fuse) DN_TRY(standalone_norm(l + 1, 0));
+    if (!fuse && !split) DN_TRY(standalone_norm(l + 1, 0));
   }
   // to_pred = RMSNorm(gamma) + Linear(D, D, no bias) (:676-679); its norm came out of the last contraction above
   DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
   p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = w.pred_W;
   p.out = pred; p.ldo = pred_ld; p.out_dtype = pred_dtype;
   if (pred_ld < Dp) p.N = pred_ld;  // dense fp32 destination narrower than the padded width
+  if (split) set_row_scale(p, tb, Dp, D, nullptr, 0);  // learned gamma, no beta
   return dn_conv_gemm(&p, s);
 }
 
@@ -260,7 +293,7 @@ int check_dims(const char* who, int dtype, int dim, int heads, int dim_head, int
 // ------------------------------------------------------------------------------------------ eps plan
 struct EpsBufs {
   float *cond, *gb, *xres;
-  void *xin, *h0, *tp;
+  void *xin, *h0, *tp, *gbh;  // gbh: the conditioning rows in the arithmetic dtype (A operand of the beta . W^T contraction)
   WaveBufs wv;
   TfBufs tf;
 };
@@ -270,7 +303,8 @@ EpsBufs plan_eps(const DnEps* m, int B, int T, int Bt, Arena& ar) {
   const int C = m->cfg.dim * m->cfg.cond_mult, Dp = padk(m->cfg.dim), zp = padk(m->cfg.latent);
   EpsBufs b;
   b.cond = (float*)ar.take((size_t)Bt * C * 4);
-  b.gb = (float*)ar.take((size_t)Bt * m->n_cond * 4);
+  b.gb = (float*)ar.take((size_t)Bt * m->n_row * 4);
+  b.gbh = es == 4 ? nullptr : ar.take((size_t)Bt * m->n_cond * es);
   b.xin = ar.take((size_t)M * zp * es);
   b.h0 = ar.take((size_t)M * Dp * es);
   b.wv = plan_wave(m->wn, M, es, ar);
@@ -313,6 +347,7 @@ extern "C" int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights,
   m->tf.g1 = m->tf.g2 = nullptr;  // time-conditioned norms carry no learned gamma (:662-663)
   m->final_W = t[0]; m->final_b = (const float*)t[1]; m->pos_table = (const float*)t[2];
   m->n_cond = (cfg->wn_stacks * cfg->wn_layers + 2 * cfg->depth) * 2 * padk(cfg->dim);
+  m->n_row = m->n_cond + cfg->depth * (3 * cfg->heads * cfg->dim_head + 2 * padk(m->tf.inner));
   *out = m;
   return DN_OK;
 }
@@ -342,13 +377,36 @@ namespace {
 // Conditioning table: rows of [gamma ; beta] for the S*L FiLM blocks and the 2*depth adaptive norms,
 // one row per entry of `times`.  Always fp32 (exact-f32 MFMA, fp32 weights): the raw integer timestep
 // drives activations of O(100), so this tiny contraction is kept out of the bf16 budget.
-int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, float* gb, hipStream_t s) {
-  const int D = m->cfg.dim, C = D * m->cfg.cond_mult;
+int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, float* gb, void* gbh, hipStream_t s) {
+  const int D = m->cfg.dim, C = D * m->cfg.cond_mult, Dp = padk(D), dtype = m->cfg.dtype, es = esize(dtype);
   DN_TRY(dn_time_cond(times, n, m->w_freq, D / 2, m->tc_W, m->tc_b, C, cond, nullptr, DN_F32, C, s));
   DnGemmParams p = gemm_base(DN_F32, n, m->n_cond, C, 1);  // (:507,517) and (:624,637), all at once
   p.terms[0].A = cond; p.terms[0].lda = C; p.terms[0].W = m->cond_W;
-  p.bias = m->cond_b; p.out = gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
-  return dn_conv_gemm(&p, s);
+  p.bias = m->cond_b; p.out = gb; p.ldo = m->n_row; p.out_dtype = DN_F32;
+  DN_TRY(dn_conv_gemm(&p, s));
+  if (!split_norm_enabled(Dp)) return DN_OK;
+  // Split RMSNorm: the beta of an adaptive norm reaches its consumer as beta . W^T, which depends on t only -- two grouped
+  // contractions (one group per layer) append it to the row: [q/kv columns | GEGLU columns (packed order)] per layer.
+  const TransformerW& w = m->tf;
+  const int hd = w.heads * w.dim_head, ip = padk(w.inner), rb_layer = 3 * hd + 2 * ip;
+  const size_t tf_off = (size_t)m->cfg.wn_stacks * m->cfg.wn_layers * 2 * Dp;  // first transformer norm's [gamma ; beta]
+  const void* A = gb;
+  int lda = m->n_row;
+  if (es != 4) {  // operands in the arithmetic dtype
+    DN_TRY(dn_convert_rows(gb, DN_F32, m->n_row, gbh, dtype, m->n_cond, n, m->n_cond, s));
+    A = gbh; lda = m->n_cond;
+  }
+  for (int j = 0; j < 2; ++j) {  // j = 0: attention norm -> q/kv projection; j = 1: feed-forward norm -> GEGLU projection
+    const int N = j == 0 ? 3 * hd : 2 * ip;
+    DnGemmParams q = gemm_base(dtype, n, N, Dp, 1);
+    q.groups = w.depth;
+    q.terms[0].A = eoff(A, tf_off + (size_t)j * 2 * Dp + Dp, es); q.terms[0].lda = lda; q.terms[0].a_gstride = 4 * Dp;
+    q.terms[0].W = j == 0 ? w.qkv_W : w.ffin_W;
+    q.terms[0].w_gstride = j == 0 ? (int64_t)padn(3 * hd) * Dp : (int64_t)2 * ip * Dp;
+    q.out = gb + m->n_cond + (j == 0 ? 0 : 3 * hd); q.ldo = m->n_row; q.out_dtype = DN_F32; q.out_gstride = rb_layer;
+    DN_TRY(dn_conv_gemm(&q, s));
+  }
+  return DN_OK;
 }
 
 // Model.forward after the conditioning (latent_module.py:861-876); gb_ld == 0 -> one row for the batch.
@@ -368,13 +426,15 @@ int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const i
     DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
     fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
-    const bool fuse_norm = fuse_norm_enabled(Dp);
-    if (fuse_norm)  // layer 0's attention norm rides on the contraction that opens the residual stream
-      set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp, gb_ld);
+    // layer 0's attention norm rides on the contraction that opens the residual stream
+    const float* gb0 = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
+    if (fuse_norm_enabled(Dp)) set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb0, gb_ld);
+    else if (split_norm_enabled(Dp)) set_split_norm(fin, b.tf, Dp, D, dtype, nullptr, gb0, gb_ld);
     DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, gb, gb_ld, b.wv, fin, s));
   }
   const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, b.tf, b.tp, Dp, dtype, fuse_norm_enabled(Dp), s));
+  const bool xn_ready = fuse_norm_enabled(Dp) || split_norm_enabled(Dp);
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, gb + m->n_cond, b.tf, b.tp, Dp, dtype, xn_ready, s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
@@ -409,13 +469,14 @@ extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const 
     dn_set_error("dn_eps_forward: workspace %zu < required %zu", workspace_bytes, ar.off);
     return DN_EWORKSPACE;
   }
-  DN_TRY(eps_cond_rows(m, t, Bt, b.cond, b.gb, s));
-  return eps_core(m, x, b.gb, shared_t ? 0 : m->n_cond, lengths, B, T, eps_out, b, s);
+  DN_TRY(eps_cond_rows(m, t, Bt, b.cond, b.gb, b.gbh, s));
+  return eps_core(m, x, b.gb, shared_t ? 0 : m->n_row, lengths, B, T, eps_out, b, s);
 }
 
 static size_t ddim_extra_bytes(const DnEps* m, int B, int T, int start_step) {
   const size_t C = (size_t)m->cfg.dim * m->cfg.cond_mult;
-  return (size_t)B * T * m->cfg.latent * 4 + (size_t)start_step * (m->n_cond + C) * 4 + (size_t)(B + start_step) * 4 + 4096;
+  return (size_t)B * T * m->cfg.latent * 4 + (size_t)start_step * (m->n_row + C) * 4 + (size_t)start_step * m->n_cond * 2 +
+         (size_t)(B + start_step) * 4 + 4096;
 }
 
 extern "C" size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t start_step) {
@@ -463,19 +524,25 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   float* eps = (float*)ar.take((size_t)M * z * 4);
   int32_t* tvec = (int32_t*)ar.take((size_t)B * 4);
   int32_t* counter = (int32_t*)ar.take(64);
-  float* table = (float*)ar.take((size_t)start_step * m->n_cond * 4);  // conditioning rows for t = 0..start_step-1
+  float* table = (float*)ar.take((size_t)start_step * m->n_row * 4);  // conditioning rows for t = 0..start_step-1
   float* cond_all = (float*)ar.take((size_t)start_step * C * 4);
+  void* table_h = esize(m->cfg.dtype) == 4 ? nullptr : ar.take((size_t)start_step * m->n_cond * 2);
   int32_t* tall = (int32_t*)ar.take((size_t)start_step * 4);
   const int last = start_step == 1 ? 0 : 1;  // the loop breaks after the t == 1 update (:1444-1445)
   int n_eval = start_step - last;             // t = start_step-1 ... last
   if (max_evals > 0 && max_evals < n_eval) n_eval = max_evals;  // partial chain (benchmarks, chunked sampling)
   // The 56 conditioning vectors depend only on t: build them for the whole chain once (fp32), so the
   // 117 M conditioning weights are not re-streamed at every step.
-  hipLaunchKernelGGL(iota_kernel, dim3((start_step + 255) / 256), dim3(256), 0, s, tall, start_step);
-  DN_TRY(eps_cond_rows(m, tall, start_step, cond_all, table, s));
+  const bool keep = (flags & DN_LOOP_KEEP_TABLE) && m->table_ws == workspace && m->table_B == B && m->table_T == T &&
+                    m->table_split == (int)split && m->table_rows >= start_step;
+  if (!keep) {
+    hipLaunchKernelGGL(iota_kernel, dim3((start_step + 255) / 256), dim3(256), 0, s, tall, start_step);
+    DN_TRY(eps_cond_rows(m, tall, start_step, cond_all, table, table_h, s));
+    m->table_ws = workspace; m->table_B = B; m->table_T = T; m->table_split = (int)split; m->table_rows = start_step;
+  }
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
-    hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_cond, counter, bufs.gb);
+    hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_row, counter, bufs.gb);
     if (split) {  // fork: the second half runs on the side stream behind the shared conditioning row
       const size_t off = (size_t)B0 * T * z;
       if (hipEventRecord((hipEvent_t)m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)m->ev_fork, 0) != hipSuccess) {
@@ -502,7 +569,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   if (!s) use_graph = 0;  // the null stream cannot be captured
   if (use_graph && n_eval > 2) {
     const bool cached = m->graph_exec && m->graph_B == B && m->graph_T == T && m->graph_ws == workspace && m->graph_x == x &&
-                        m->graph_len == lengths && m->graph_coef == coef && m->graph_flags == flags;
+                        m->graph_len == lengths && m->graph_coef == coef && m->graph_flags == (flags & ~DN_LOOP_KEEP_TABLE);
     if (!cached) {
       DN_TRY(one_step());  // eager first step: also settles the per-kernel attributes outside capture
       done = 1;
@@ -530,7 +597,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
         return DN_ELAUNCH;
       }
       m->graph_exec = exec; m->graph_B = B; m->graph_T = T; m->graph_ws = workspace; m->graph_x = x;
-      m->graph_len = lengths; m->graph_coef = coef; m->graph_flags = flags;
+      m->graph_len = lengths; m->graph_coef = coef; m->graph_flags = flags & ~DN_LOOP_KEEP_TABLE;
     }
     for (; done < n_eval; ++done) {
       hipError_t e = hipGraphLaunch((hipGraphExec_t)m->graph_exec, s);
@@ -692,7 +759,7 @@ extern "C" int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengt
   }
   float* rec = dense_recon ? recon : b.recon;
   const int rec_ld = dense_recon ? D : Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, b.tf, rec, rec_ld, DN_F32, false, s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, nullptr, b.tf, rec, rec_ld, DN_F32, false, s));
   if (recon && !dense_recon) DN_TRY(dn_convert_rows(rec, DN_F32, Dp, recon, DN_F32, D, M, D, s));
   if (!want_lm) return DN_OK;
   DN_TRY(dn_convert_rows(rec, DN_F32, rec_ld, b.pred_act, dtype, Dp, M, D, s));

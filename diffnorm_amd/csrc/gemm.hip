@@ -120,8 +120,41 @@ __device__ __forceinline__ void park_row_scales(const DnGemmParams& p, float* ep
   m = m < p.M ? m : p.M - 1;
   const float* q = p.row_ssq + (int64_t)m * p.row_ssq_ld;
   float ss = 0.f;
-  for (int j = 0; j < p.row_ssq_parts; ++j) ss += q[j];
+  for (int j = 0; j < p.row_ssq_parts; ++j) ss += q[j];  // same order as row_scale_finish
   ep[lane * EP_LD + 64] = sqrtf(p.row_D) / fmaxf(sqrtf(ss), 1e-12f);
+}
+// The same factor with its loads taken out of the epilogue: a kernel requests the (up to 8) partials of "its" row
+// (lane r <-> row m_base + r of the wave's slab) before it starts staging, and finishes the arithmetic after the staging
+// prologue's first counted vmcnt -- VMEM loads return in order and these are older than every DMA piece, so they have
+// landed by then without a wait of their own.  Inline asm, because the compiler cannot see the DMA pieces and would
+// drain vmcnt(0) (the whole staging prologue) in front of the first use of an ordinary load.
+struct RowSsqReq { f32x4 a, b; bool on; };
+template <int EPI>
+__device__ __forceinline__ RowSsqReq row_scale_request(const DnGemmParams& p, int m_base, int lane) {
+  RowSsqReq r;
+  r.a = r.b = f32x4{0.f, 0.f, 0.f, 0.f};
+  r.on = false;
+  if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
+    r.on = p.row_ssq != nullptr && p.row_ssq_parts <= 8 && (p.row_ssq_ld & 3) == 0 && p.row_ssq_ld >= 8;
+    if (r.on) {
+      int m = m_base + lane;
+      m = m < p.M ? m : p.M - 1;
+      const float* q = p.row_ssq + (int64_t)m * p.row_ssq_ld;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
+    }
+  }
+  return r;
+}
+// call after a counted vmcnt that covers the request; < 0: not requested (the epilogue loads the partials itself)
+__device__ __forceinline__ float row_scale_finish(const DnGemmParams& p, RowSsqReq r) {
+  if (!r.on) return -1.f;
+  asm volatile("" : "+v"(r.a), "+v"(r.b));  // ordered behind the preceding (volatile) vmcnt statement
+  const float v[8] = {r.a[0], r.a[1], r.a[2], r.a[3], r.b[0], r.b[1], r.b[2], r.b[3]};
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ss += j < p.row_ssq_parts ? v[j] : 0.f;
+  return sqrtf(p.row_D) / fmaxf(sqrtf(ss), 1e-12f);
 }
 __device__ __forceinline__ const float* row_bias_of(const DnGemmParams& p, int m) {
   return p.row_bias + (p.row_bias_ld ? (int64_t)(m / p.T) * p.row_bias_ld : 0);
@@ -153,6 +186,16 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(bg) = *reinterpret_cast<const float4*>(bias + np + 32);
       *reinterpret_cast<float4*>(bg + 4) = *reinterpret_cast<const float4*>(bias + np + 36);
     }
+    // beta . W^T: per sample -> fetched per row; one row for the batch -> fetched once.  Either way it enters as
+    // fma(acc, scale, rb) + bias, so shared_t and per-sample t give bit-identical results.
+    const bool rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;
+    float rsv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rsg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.row_ssq && p.row_bias && !rb_rows) {
+      *reinterpret_cast<float4*>(rsv) = *reinterpret_cast<const float4*>(p.row_bias + np);
+      *reinterpret_cast<float4*>(rsv + 4) = *reinterpret_cast<const float4*>(p.row_bias + np + 4);
+      *reinterpret_cast<float4*>(rsg) = *reinterpret_cast<const float4*>(p.row_bias + np + 32);
+      *reinterpret_cast<float4*>(rsg + 4) = *reinterpret_cast<const float4*>(p.row_bias + np + 36);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = j * 16 + (lane >> 2);
@@ -165,8 +208,10 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8 + 4);
       if (p.row_ssq) {  // split norm: scale the accumulators by the row's factor, add beta . W^T
         const float sm = ep[row * EP_LD + 64];
-        float rv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.row_bias) {
+        float rv[8], rg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { rv[i] = rsv[i]; rg[i] = rsg[i]; }
+        if (rb_rows) {
           const float* rb = row_bias_of(p, m);
           *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(rb + np);
           *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + np + 4);
@@ -189,6 +234,12 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bias + n);
       *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bias + n + 4);
     }
+    const bool rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;
+    float rsv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.row_ssq && p.row_bias && !rb_rows) {
+      *reinterpret_cast<float4*>(rsv) = *reinterpret_cast<const float4*>(p.row_bias + n);
+      *reinterpret_cast<float4*>(rsv + 4) = *reinterpret_cast<const float4*>(p.row_bias + n + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = j * 8 + (lane >> 3);
@@ -199,8 +250,10 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
       if (p.row_ssq) {
         const float sm = ep[row * EP_LD + 64];
-        float rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.row_bias) {
+        float rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rv[i] = rsv[i];
+        if (rb_rows) {
           const float* rb = row_bias_of(p, m);
           *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(rb + n);
           *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + n + 4);
@@ -231,6 +284,12 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
     if (n >= p.N) return;
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
     const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
+    const bool rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;  // per-sample beta . W^T: fetched per row
+    float4 rsv = make_float4(0, 0, 0, 0), rsg = rsv;                      // one row for the batch: fetched once
+    if (p.row_ssq && p.row_bias && !rb_rows) {
+      rsv = *reinterpret_cast<const float4*>(p.row_bias + np);
+      rsg = *reinterpret_cast<const float4*>(p.row_bias + np + 32);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = j * 8 + (lane >> 3);
@@ -240,8 +299,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
       float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
       if (p.row_ssq) {
         const float sm = ep[row * EP_LD + 64];
-        float4 rv = make_float4(0, 0, 0, 0), rg = rv;
-        if (p.row_bias) {
+        float4 rv = rsv, rg = rsg;
+        if (rb_rows) {
           const float* rb = row_bias_of(p, m);
           rv = *reinterpret_cast<const float4*>(rb + np);
           rg = *reinterpret_cast<const float4*>(rb + np + 32);
@@ -257,6 +316,12 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
     const int n = n_base + c4;
     if (n >= p.N || c4 >= ncols) return;  // ncols < 64: only the slab's first columns carry this wave's outputs
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+    bool rb_rows = false;
+    float4 rsv = make_float4(0, 0, 0, 0);
+    if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU) {
+      rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;
+      if (p.row_ssq && p.row_bias && !rb_rows) rsv = *reinterpret_cast<const float4*>(p.row_bias + n);
+    }
     // The side inputs of a row (residual, FiLM gamma/beta, positional row) are global loads; issued inside the
     // per-row loop each would sit behind the previous row's store (the compiler must assume `out` aliases them) and
     // expose a full memory round trip per row.  So the rows go in batches of RB: all loads of a batch first, then
@@ -274,6 +339,13 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
     const float* gbb = nullptr;
     if constexpr (EPI == DN_EPI_FILM_GATE) gbb = p.gamma_beta ? p.gamma_beta + p.gb_gstride * g + n : nullptr;
     const bool gb_shared = p.gb_ld == 0;
+    float4 split_gamma = make_float4(1, 1, 1, 1);  // split norm: the gamma row when one row serves the whole batch
+    if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
+      if (p.norm_split) {
+        if (p.norm_gb && !p.norm_gb_ld) split_gamma = *reinterpret_cast<const float4*>(p.norm_gb + n);
+        else if (!p.norm_gb && p.norm_gamma) split_gamma = *reinterpret_cast<const float4*>(p.norm_gamma + n);
+      }
+    }
     float4 gas = make_float4(1, 1, 1, 1), bes = make_float4(0, 0, 0, 0);
     if constexpr (EPI == DN_EPI_FILM_GATE)
       if (gbb && gb_shared) {  // one conditioning row for the whole batch (sampling): load it once per lane
@@ -324,8 +396,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU) {
           if (p.row_ssq) {  // split norm, consumer side
             const float sm = ep[row * EP_LD + 64];
-            float4 rb4 = make_float4(0, 0, 0, 0);
-            if (p.row_bias) rb4 = *reinterpret_cast<const float4*>(row_bias_of(p, m) + n);
+            float4 rb4 = rsv;
+            if (rb_rows) rb4 = *reinterpret_cast<const float4*>(row_bias_of(p, m) + n);
             a4 = make_float4(fmaf(a4.x, sm, rb4.x), fmaf(a4.y, sm, rb4.y), fmaf(a4.z, sm, rb4.z), fmaf(a4.w, sm, rb4.w));
           }
         }
@@ -344,9 +416,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, v0, v1, v2, v3);
         if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           if (p.norm_split) {  // split norm, producer side: row * gamma for the consuming contraction + this slab's sum of squares
-            float4 ga = make_float4(1, 1, 1, 1);
-            if (p.norm_gb) ga = *reinterpret_cast<const float4*>(p.norm_gb + (p.norm_gb_ld ? (int64_t)(m / p.T) * p.norm_gb_ld : 0) + n);
-            else if (p.norm_gamma) ga = *reinterpret_cast<const float4*>(p.norm_gamma + n);
+            float4 ga = split_gamma;
+            if (p.norm_gb && p.norm_gb_ld) ga = *reinterpret_cast<const float4*>(p.norm_gb + (int64_t)(m / p.T) * p.norm_gb_ld + n);
             if (p.norm_dtype == DN_BF16) store4t<true>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             else store4t<false>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             float q = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;  // the row's 16 lanes are lanes (lane & ~15) .. +15
@@ -364,13 +435,16 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
 
 template <int EPI>
 __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
-                                              int ncols = 64) {
+                                              int ncols = 64, float row_scale = -1.f) {
   const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
   const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
   if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
-    if (p.row_ssq) park_row_scales(p, const_cast<float*>(ep), m_base, lane);
+    if (p.row_ssq) {
+      if (row_scale >= 0.f) const_cast<float*>(ep)[lane * EP_LD + 64] = row_scale;  // requested at kernel start
+      else park_row_scales(p, const_cast<float*>(ep), m_base, lane);
+    }
   }
 #define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols)
   if constexpr (RESADD) {
@@ -518,6 +592,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
         for (int mt = 0; mt < 4; ++mt) mma_kstep<E>(acc[nt][mt], wf[ks][nt], af[ks][mt]);
   };
 
+  const RowSsqReq rs_req = row_scale_request<EPI>(p, m0 + wm * 64, lane);
   setup_term(0);
   if constexpr (STAGES == 3) {
     // Staggered two-group schedule (8 waves = group 0: waves 0-3, group 1: waves 4-7; waves w and w+4
@@ -588,7 +663,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
       *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[nt][mt];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in-order: writes precede the reads below
 
-  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane);
+  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale_finish(p, rs_req));
 }
 
 // ------------------------------------------------------------------------------------------ 256 x 256 tile
@@ -712,12 +787,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   //   RAW: tile k+1 must be in LDS before segment 2k+2: every wave retires its pieces of tile k+1 with a counted
   //        vmcnt ahead of the barrier that ends odd segment 2k+1 (tiles k+2, k+3 may stay in flight: 2*PER_STAGE).
   //   WAR: tile k+3 overwrites the slot of tile k-1, last read in segment 2k-1; it is issued in segments >= 2k.
+  const RowSsqReq rs_req = row_scale_request<EPI>(p, m0 + wm * 64, lane);
   setup_term(0);
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
   if (nkt > 2) pipe_sync<2 * PER_STAGE>(); else if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();  // tile 0 landed
+  const float row_scale = row_scale_finish(p, rs_req);
   __builtin_amdgcn_sched_barrier(0);
   if (late) pipe_sync<63>();  // the stagger
   int slot = 0, fill = STAGES - 1;
@@ -760,7 +837,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
       for (int nt = 0; nt < 4; ++nt)
         *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[H * 4 + nt][mt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane);
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane, 64, row_scale);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
   };
   half(std::integral_constant<int, 0>{});
@@ -1326,11 +1403,13 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
 #ifdef DN_FAT_STAMPS  // diagnostic build only (tools/fat_clock.py): in-kernel clock and K-loop cycles
   const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  const RowSsqReq rs_req0 = row_scale_request<EPI>(p, m0 + wm * 128, lane), rs_req1 = row_scale_request<EPI>(p, m0 + wm * 128 + 64, lane);
   if constexpr (taps_inner) setup_taps(); else setup_term(0);
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
   if (nkt > 2) pipe_sync<2 * PER>(); else if (nkt > 1) pipe_sync<PER>(); else pipe_sync<0>();
+  const float row_scale0 = row_scale_finish(p, rs_req0), row_scale1 = row_scale_finish(p, rs_req1);
 #ifdef DN_FAT_STAMPS
   const uint64_t dbg_c1 = __builtin_readcyclecounter();
 #endif
@@ -1390,7 +1469,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     const int mh = sidx / NHS, nh = sidx - mh * NHS;
     const int nts = NTW - 4 * nh < 4 ? NTW - 4 * nh : 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16);
+    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16, mh ? row_scale1 : row_scale0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next slab overwrites it
   }
 }

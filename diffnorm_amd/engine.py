@@ -97,9 +97,11 @@ class EpsEngine(_Engine):
         return out
 
     def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
-                  use_graph: bool = True, max_evals: int = 0, split: bool = True) -> int:
+                  use_graph: bool = True, max_evals: int = 0, split: bool = True, keep_table: bool = False) -> int:
         """In-place DDIM eta=0 chain on x [B,T,z] fp32 (reference latent_module.py:1411-1445).
-        coef: fp32 [timesteps,4] from `scheduler.ddim_coef_table`.  Returns the number of model evaluations."""
+        coef: fp32 [timesteps,4] from `scheduler.ddim_coef_table`.  Returns the number of model evaluations.
+        `max_evals` stops early; the caller continues with start_step - max_evals and may pass `keep_table=True` when
+        nothing else used this engine in between (the conditioning table of the first call is then reused)."""
         B, T, z = x.shape
         assert x.is_contiguous() and x.dtype == torch.float32 and x.device == self.device
         assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.device == self.device
@@ -110,7 +112,7 @@ class EpsEngine(_Engine):
         with torch.cuda.device(self.device):
             return _lib.check(self.lib.dn_ddim_loop(self.handle, x.data_ptr(), l32.data_ptr(), B, T, start_step,
                                                     max_evals, coef.data_ptr(), coef.shape[0],
-                                                    (1 if use_graph else 0) | (2 if split else 0), wp, wn,
+                                                    (1 if use_graph else 0) | (2 if split else 0) | (4 if keep_table else 0), wp, wn,
                                                     _lib.current_stream()), "dn_ddim_loop")
 
 

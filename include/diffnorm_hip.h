@@ -258,7 +258,10 @@ int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengths, int32_t
  * start_step - max_evals).  flags: DN_LOOP_* bits.  Workspace:
  * dn_ddim_workspace_bytes.  Returns the number of model evaluations (>= 0) or a negative error.                 */
 enum { DN_LOOP_GRAPH = 1,  /* capture one step into a hipGraph and replay it */
-       DN_LOOP_SPLIT2 = 2  /* run the two half-batches as parallel branches (side stream / forked graph) */ };
+       DN_LOOP_SPLIT2 = 2, /* run the two half-batches as parallel branches (side stream / forked graph) */
+       DN_LOOP_KEEP_TABLE = 4 /* continuing a chain (after a max_evals stop): the caller guarantees that nothing wrote the
+                                 workspace since the previous dn_ddim_loop call with the same B, T and split; the
+                                 conditioning table built then (rows t < its start_step) is reused instead of rebuilt */ };
 size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t start_step);
 int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step,
                  int32_t max_evals, const float* coef, int32_t timesteps, int32_t flags, void* workspace,

@@ -3,6 +3,8 @@
 Budgets (north_star): 1e-3 in f32 mode, 1e-2 in bf16 mode, on O(1) activations; the golden vectors
 are outputs of the real reference (tests/golden, oracle/gen_golden.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -159,6 +161,18 @@ def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
             got_units = torch.cat([u[i, : int(lens[i])] for i in range(B)]).cpu().numpy()
             agree = (got_units == g[f"s{start}_units"]).mean()
             assert agree >= (0.99 if dtype == "f32" else 0.9), agree
+        if start == 50:  # the same chain in two calls (max_evals, then continue on the kept conditioning table): bit-identical
+            xc = x.clone()
+            assert ee.ddim_loop(xc, lens.to(DEV).int(), start, coef, max_evals=7) == 7
+            assert ee.ddim_loop(xc, lens.to(DEV).int(), start - 7, coef, keep_table=True) == start - 8
+            assert torch.equal(xc, xs)
+            xe = x.clone()  # and with the split RMSNorm off (standalone norm kernel): same chain within the budget
+            os.environ["DN_NO_SPLIT_NORM"] = "1"
+            try:
+                ee.ddim_loop(xe, lens.to(DEV).int(), start, coef, use_graph=False)
+            finally:
+                del os.environ["DN_NO_SPLIT_NORM"]
+            assert maxerr(xe, xs) < tol * 5
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
