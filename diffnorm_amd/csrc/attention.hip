@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 #pragma unroll
   for (int i = 0; i < DT; ++i) acc_o[i][0] = acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+  // bf16: the softmax denominators ride on the matrix pipe -- one extra output tile whose V^T fragment is all ones makes
+  // acc_l[qt][r] = sum_k P[k][query] (the same bf16-rounded P the numerator uses), replacing 32 v_add + 2 cross-lane
+  // reductions per key tile by 4 MFMAs on a pipe that has slack here (the loop is VALU-bound on the exponentials).
+  f32x4 acc_l[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const uint4 ones_frag = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 
   int len = p.lengths ? p.lengths[b] : T;
   len = len < T ? len : T;
@@ -87,43 +92,52 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     sc = 0.f;
   }
 
-  // K/V tiles are double-buffered in LDS and register-staged one tile ahead: the global loads of tile j+1 are
-  // issued before tile j is consumed and written to the other buffer after it, so HBM/L2 latency hides under
-  // the MFMAs and softmax of tile j; one barrier per tile.
+  // K/V tiles are double-buffered in LDS and register-staged TWO tiles ahead (two register sets): a key tile's work
+  // (~1.5k cycles per wave) is shorter than a loaded L2/HBM round trip, so with one tile of lead every iteration ended
+  // waiting for its successor's loads.  Tile t travels in register set t % 2: requested at the top of iteration t-2,
+  // written to LDS buffer t % 2 at the end of iteration t-1 (that buffer was last read in iteration t-2; one barrier
+  // per tile).  The loop is unrolled over two tiles so the set index is a compile-time constant.
   constexpr int NPT = (KV_TILE * NCH + 255) / 256;  // 16-byte chunks per thread per tensor per tile
-  uint4 kreg[NPT], vreg[NPT];
-  auto issue_loads = [&](int kv0) {
+  uint4 kreg[2][NPT], vreg[2][NPT];
+  auto issue_loads = [&](auto set_c, int kv0) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / NCH, ch = idx - row * NCH;
       const int key = kv0 + row;
-      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
+      kreg[S][i] = vreg[S][i] = make_uint4(0, 0, 0, 0);
       if (idx < KV_TILE * NCH && key < T && ch * 16 < dhb) {
-        kreg[i] = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
-        vreg[i] = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
+        kreg[S][i] = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
+        vreg[S][i] = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
       }
     }
   };
-  auto write_tile = [&](int buf) {
+  auto write_tile = [&](auto set_c, int buf) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / NCH, ch = idx - row * NCH;
       if (idx < KV_TILE * NCH) {
         const int off = buf * TILE_LDS + lds_off<E>(row, ch * 16);
-        *reinterpret_cast<uint4*>(k_lds + off) = kreg[i];
-        *reinterpret_cast<uint4*>(v_lds + off) = vreg[i];
+        *reinterpret_cast<uint4*>(k_lds + off) = kreg[S][i];
+        *reinterpret_cast<uint4*>(v_lds + off) = vreg[S][i];
       }
     }
   };
-  issue_loads(0);
-  write_tile(0);
+  using SET0 = std::integral_constant<int, 0>;
+  using SET1 = std::integral_constant<int, 1>;
+  issue_loads(SET0{}, 0);
+  if (KV_TILE < len) issue_loads(SET1{}, KV_TILE);
+  write_tile(SET0{}, 0);
   __syncthreads();
-  int buf = 0;
-  for (int kv0 = 0; kv0 < len; kv0 += KV_TILE) {
+  // one key tile: `cur_c` = its register-set parity (= its LDS buffer)
+  auto key_tile = [&](auto cur_c, int kv0) {
+    constexpr int buf = decltype(cur_c)::value;
+    using NXT = std::integral_constant<int, 1 - buf>;
     const bool more = kv0 + KV_TILE < len;
-    if (more) issue_loads(kv0 + KV_TILE);
+    if (kv0 + 2 * KV_TILE < len) issue_loads(cur_c, kv0 + 2 * KV_TILE);  // this tile's set is free: it went to LDS last iteration
     const char* kt_lds = k_lds + buf * TILE_LDS;
     const char* vt_lds = v_lds + buf * TILE_LDS;
 
@@ -171,13 +185,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           for (int r = 0; r < 4; ++r) {
             const float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
             acc_s[kt][qt][r] = pv;
-            rs += pv;
+            if constexpr (ES != 2) rs += pv;
           }
-        rs = quad_xor_sum(rs);
-        l_run[qt] = l_run[qt] * alpha + rs;
-        m_run[qt] = m_new;
+        if constexpr (ES != 2) {
+          rs = quad_xor_sum(rs);
+          l_run[qt] = l_run[qt] * alpha + rs;
+        }
+        // once the running maxima have settled (typically after the first key tiles) alpha is exactly 1 in every lane:
+        // skip the rescale of the output tile then (wave-uniform test)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
+          for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
+          if constexpr (ES == 2) acc_l[qt] *= alpha;
+        }
+        m_run[qt] = m_new;
       }
     };
     if (kv0 + KV_TILE > len)
@@ -213,6 +234,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           mma_kstep<E>(acc_o[dt][0], vf, pf[0]);
           mma_kstep<E>(acc_o[dt][1], vf, pf[1]);
         }
+        mma_kstep<E>(acc_l[0], ones_frag, pf[0]);
+        mma_kstep<E>(acc_l[1], ones_frag, pf[1]);
       }
     } else {
 #pragma unroll
@@ -228,9 +251,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           }
         }
     }
-    if (more) write_tile(buf ^ 1);  // the other buffer was last read one barrier ago
+    if (more) write_tile(NXT{}, 1 - buf);  // the other buffer was last read one barrier ago
     __syncthreads();
-    buf ^= 1;
+  };
+  for (int kv0 = 0; kv0 < len; kv0 += 2 * KV_TILE) {
+    key_tile(SET0{}, kv0);
+    if (kv0 + KV_TILE < len) key_tile(SET1{}, kv0 + KV_TILE);
   }
 
   // ---- O = acc / l ; lane holds dims dt*16 + 4*fg + 0..3 of query qt*16 + fr
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   for (int qt = 0; qt < 2; ++qt) {
     const int q = q0 + qt * 16 + fr;
     if (q >= T) continue;
-    const float inv = 1.0f / l_run[qt];
+    const float inv = 1.0f / (ES == 2 ? acc_l[qt][0] : l_run[qt]);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int d = dt * 16 + fg * 4;
