@@ -156,6 +156,27 @@ __device__ __forceinline__ float row_scale_finish(const DnGemmParams& p, RowSsqR
   for (int j = 0; j < 8; ++j) ss += j < p.row_ssq_parts ? v[j] : 0.f;
   return sqrtf(p.row_D) / fmaxf(sqrtf(ss), 1e-12f);
 }
+// sum over the 16 lanes of a DPP row (lanes 16 j .. 16 j + 15), result in every lane: xor-1 and xor-2 butterflies inside a
+// quad, then the mirrored half-row and the mirrored row -- four VALU adds, no LDS crossbar latency
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float q) {
+  q += dpp_mov<0xB1>(q);   // quad_perm [1,0,3,2]
+  q += dpp_mov<0x4E>(q);   // quad_perm [2,3,0,1]
+  q += dpp_mov<0x141>(q);  // row_half_mirror
+  q += dpp_mov<0x140>(q);  // row_mirror
+  return q;
+}
+// The four row factors a lane needs when it copies its accumulators to the transpose slab (rows 16 mt + (lane & 15)),
+// from the per-lane factors (lane r <-> row r) of row_scale_finish.  < 0 in, 1.0 out (nothing pre-scaled).
+constexpr float ROW_PRESCALED = -2.f;
+__device__ __forceinline__ f32x4 scaled(const f32x4& a, float sc) { return f32x4{a[0] * sc, a[1] * sc, a[2] * sc, a[3] * sc}; }
+__device__ __forceinline__ void slab_row_scales(float row_scale, int lane, float (&sc)[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) sc[mt] = row_scale >= 0.f ? __shfl(row_scale, mt * 16 + (lane & 15)) : 1.f;
+}
 __device__ __forceinline__ const float* row_bias_of(const DnGemmParams& p, int m) {
   return p.row_bias + (p.row_bias_ld ? (int64_t)(m / p.T) * p.row_bias_ld : 0);
 }
@@ -170,7 +191,7 @@ __device__ __forceinline__ void store8_bf16(void* base, int64_t off, const float
 // WIDE (bf16 output, rows 16-byte aligned, BIAS / SILU / GEGLU): a lane owns 8 output columns instead of 4.
 template <int EPI, bool FULL>
 __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
-                                                   int ncols) {
+                                                   int ncols, bool prescaled) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * 2;
   if constexpr (EPI == DN_EPI_GEGLU) {
@@ -206,8 +227,8 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
       *reinterpret_cast<float4*>(gt) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8);
       *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8 + 4);
-      if (p.row_ssq) {  // split norm: scale the accumulators by the row's factor, add beta . W^T
-        const float sm = ep[row * EP_LD + 64];
+      if (p.row_ssq) {  // split norm: scale the accumulators by the row's factor (unless the slab copy did), add beta . W^T
+        const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
         float rv[8], rg[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { rv[i] = rsv[i]; rg[i] = rsg[i]; }
@@ -219,7 +240,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
           *reinterpret_cast<float4*>(rg + 4) = *reinterpret_cast<const float4*>(rb + np + 36);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = fmaf(v[i], sm, rv[i]); gt[i] = fmaf(gt[i], sm, rg[i]); }
+        for (int i = 0; i < 8; ++i) { v[i] = __fadd_rn(__fmul_rn(v[i], sm), rv[i]); gt[i] = __fadd_rn(__fmul_rn(gt[i], sm), rg[i]); }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
@@ -249,7 +270,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8);
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
       if (p.row_ssq) {
-        const float sm = ep[row * EP_LD + 64];
+        const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
         float rv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rv[i] = rsv[i];
@@ -259,7 +280,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
           *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + n + 4);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sm, rv[i]);
+        for (int i = 0; i < 8; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], sm), rv[i]);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -273,7 +294,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
 
 template <int EPI, bool OUT_BF, bool RES_BF, bool FULL>
 __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
-                                                   int ncols) {
+                                                   int ncols, bool prescaled) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (OUT_BF ? 2 : 4);
   if constexpr (EPI == DN_EPI_GEGLU) {
@@ -298,15 +319,17 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
       float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
       float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
       if (p.row_ssq) {
-        const float sm = ep[row * EP_LD + 64];
+        const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
         float4 rv = rsv, rg = rsg;
         if (rb_rows) {
           const float* rb = row_bias_of(p, m);
           rv = *reinterpret_cast<const float4*>(rb + np);
           rg = *reinterpret_cast<const float4*>(rb + np + 32);
         }
-        v = make_float4(fmaf(v.x, sm, rv.x), fmaf(v.y, sm, rv.y), fmaf(v.z, sm, rv.z), fmaf(v.w, sm, rv.w));
-        gt = make_float4(fmaf(gt.x, sm, rg.x), fmaf(gt.y, sm, rg.y), fmaf(gt.z, sm, rg.z), fmaf(gt.w, sm, rg.w));
+        v = make_float4(__fadd_rn(__fmul_rn(v.x, sm), rv.x), __fadd_rn(__fmul_rn(v.y, sm), rv.y), __fadd_rn(__fmul_rn(v.z, sm), rv.z),
+                        __fadd_rn(__fmul_rn(v.w, sm), rv.w));
+        gt = make_float4(__fadd_rn(__fmul_rn(gt.x, sm), rg.x), __fadd_rn(__fmul_rn(gt.y, sm), rg.y), __fadd_rn(__fmul_rn(gt.z, sm), rg.z),
+                         __fadd_rn(__fmul_rn(gt.w, sm), rg.w));
       }
       store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
                       gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
@@ -395,10 +418,11 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         float4 a4 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
         if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU) {
           if (p.row_ssq) {  // split norm, consumer side
-            const float sm = ep[row * EP_LD + 64];
+            const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
             float4 rb4 = rsv;
             if (rb_rows) rb4 = *reinterpret_cast<const float4*>(row_bias_of(p, m) + n);
-            a4 = make_float4(fmaf(a4.x, sm, rb4.x), fmaf(a4.y, sm, rb4.y), fmaf(a4.z, sm, rb4.z), fmaf(a4.w, sm, rb4.w));
+            a4 = make_float4(__fadd_rn(__fmul_rn(a4.x, sm), rb4.x), __fadd_rn(__fmul_rn(a4.y, sm), rb4.y),
+                             __fadd_rn(__fmul_rn(a4.z, sm), rb4.z), __fadd_rn(__fmul_rn(a4.w, sm), rb4.w));
           }
         }
         float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
@@ -421,10 +445,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
             if (p.norm_dtype == DN_BF16) store4t<true>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             else store4t<false>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             float q = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;  // the row's 16 lanes are lanes (lane & ~15) .. +15
-            q += __shfl_xor(q, 1);
-            q += __shfl_xor(q, 2);
-            q += __shfl_xor(q, 4);
-            q += __shfl_xor(q, 8);
+            q = row16_sum(q);
             if ((lane & 15) == 0) p.norm_ssq[(int64_t)m * p.norm_ssq_ld + (n_base >> 6)] = q;
           }
         }
@@ -440,13 +461,14 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
   const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
+  const bool prescaled = row_scale == ROW_PRESCALED;  // the slab already holds acc * sqrt(D)/|row|
   if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
-    if (p.row_ssq) {
+    if (p.row_ssq && row_scale != ROW_PRESCALED) {
       if (row_scale >= 0.f) const_cast<float*>(ep)[lane * EP_LD + 64] = row_scale;  // requested at kernel start
       else park_row_scales(p, const_cast<float*>(ep), m_base, lane);
     }
   }
-#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols)
+#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols, prescaled)
   if constexpr (RESADD) {
     if (full) DN_EP(false, false, true); else DN_EP(false, false, false);
   } else if constexpr (EPI == DN_EPI_FILM_GATE) {
@@ -460,8 +482,8 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
       const bool wide = !(p.pad_ & 16) && obf && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (ncols & 7) == 0 && (p.out_gstride & 7) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
       if (wide) {
-        if (full) wave_epilogue_wide<EPI, true>(p, ep, m_base, n_base, g, lane, ncols);
-        else wave_epilogue_wide<EPI, false>(p, ep, m_base, n_base, g, lane, ncols);
+        if (full) wave_epilogue_wide<EPI, true>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
+        else wave_epilogue_wide<EPI, false>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
         return;
       }
     }
@@ -656,14 +678,17 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   // 64 columns of one row, so bias / FiLM / residual loads and the output stores are whole 128-256 B row segments.
   if constexpr (STAGES != 3) __syncthreads();  // the 2-stage loop ends without a barrier: ring reads must be over
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+  const float row_scale = row_scale_finish(p, rs_req);
+  float sc4[4];  // split RMSNorm, consumer side: the row factor is applied while the accumulators go to the slab
+  slab_row_scales(row_scale, lane, sc4);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[nt][mt];
+      *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = scaled(acc[nt][mt], sc4[mt]);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in-order: writes precede the reads below
 
-  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale_finish(p, rs_req));
+  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
 }
 
 // ------------------------------------------------------------------------------------------ 256 x 256 tile
@@ -829,15 +854,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
   // the two halves are spelled out with compile-time accumulator indices: a rolled loop would index `acc` at run time
   // and push the whole accumulator file to scratch
+  float sc4[4];
+  slab_row_scales(row_scale, lane, sc4);
   auto half = [&](auto hc) {
     constexpr int H = decltype(hc)::value;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[H * 4 + nt][mt];
+        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = scaled(acc[H * 4 + nt][mt], sc4[mt]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane, 64, row_scale);
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
   };
   half(std::integral_constant<int, 0>{});
@@ -1403,13 +1430,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
 #ifdef DN_FAT_STAMPS  // diagnostic build only (tools/fat_clock.py): in-kernel clock and K-loop cycles
   const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const RowSsqReq rs_req0 = row_scale_request<EPI>(p, m0 + wm * 128, lane), rs_req1 = row_scale_request<EPI>(p, m0 + wm * 128 + 64, lane);
   if constexpr (taps_inner) setup_taps(); else setup_term(0);
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
   if (nkt > 2) pipe_sync<2 * PER>(); else if (nkt > 1) pipe_sync<PER>(); else pipe_sync<0>();
-  const float row_scale0 = row_scale_finish(p, rs_req0), row_scale1 = row_scale_finish(p, rs_req1);
 #ifdef DN_FAT_STAMPS
   const uint64_t dbg_c1 = __builtin_readcyclecounter();
 #endif
@@ -1453,6 +1478,8 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   // a 58k-instruction kernel); only the accumulator -> LDS copies, which need compile-time register indices, are per slab.
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
   constexpr int NHS = (NTW + 3) / 4;
+  // (a split-RMSNorm consumer on this tile fetches its row factors in the epilogue: the accumulator file leaves no room
+  //  to carry them across the K loop)
 #pragma unroll 1
   for (int sidx = 0; sidx < 2 * NHS; ++sidx) {
     static_for<2 * NHS>([&](auto s_c) {
@@ -1469,7 +1496,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     const int mh = sidx / NHS, nh = sidx - mh * NHS;
     const int nts = NTW - 4 * nh < 4 ? NTW - 4 * nh : 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16, mh ? row_scale1 : row_scale0);
+    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16, -1.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next slab overwrites it
   }
 }

@@ -102,3 +102,18 @@ def test_engines_refuse_to_run_without_a_gpu():
         engine._require_cuda("cuda:0")
     with pytest.raises(_lib.DiffNormHipError):
         engine._require_cuda("cpu")
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    """Resource check of the compiled kernels (no GPU needed: hipcc cross-compiles): no VGPR/SGPR spills and no scratch in
+    gemm.hip / attention.hip -- a spill inside a hand-scheduled K loop is both a slowdown and a hazard (scratch loads share
+    vmcnt with the counted DMA waits)."""
+    import importlib.util
+    import shutil
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("check_resources", os.path.join(ROOT, "tools", "check_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(["gemm.hip", "attention.hip"]) == []
