@@ -17,6 +17,13 @@
 
 #include "common.h"
 
+// Ablation switches of the two-waves-per-SIMD K loops (tools/gemm_bench.py): compile-time, because a run-time test inside
+// the loop costs the wave that feeds the MFMA pipe a branch per test.  Build with EXTRA=-DDN_GEMM_ABL=<bits>:
+// bit0 skip DMA, bit1 skip MFMA, bit2 skip LDS fragment reads, bit3 no s_setprio.
+#ifndef DN_GEMM_ABL
+#define DN_GEMM_ABL 0
+#endif
+
 namespace dn {
 
 __device__ uint4 g_zero_page[8];  // 128 bytes of zeros (static storage is zero-initialised)
@@ -632,31 +639,31 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
     if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();  // tile 0 landed
     __builtin_amdgcn_sched_barrier(0);
     if (late) pipe_sync<63>();  // the stagger: group 1 sits out segment 0 (vmcnt(63) = no wait)
-    int slot = 0, fill = 2;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // The K loop is specialised on the wave's group and has no per-iteration conditions (a uniform branch in the wave
+    // that is feeding the MFMA pipe idles the pipe): tiles that still stage (kt + 2 < nkt) run in the main loop, the last
+    // two drain.
+    auto ktile = [&](auto late_c, auto stage_c, int slot, int fill) {
+      constexpr bool LATE = decltype(late_c)::value, STAGE = decltype(stage_c)::value;
       // ---- L segment
-      if (!(p.pad_ & 4)) load_frags(slot);  // LDS reads first: they drain while the TA chews the DMA addresses
-      if (kt + 2 < nkt && !(p.pad_ & 1)) stage(fill);
-      if (late) {  // this is an odd segment for group 1
-        if (kt + 2 < nkt) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
-      } else {
-        pipe_sync<63>();
-      }
+      if constexpr (!(DN_GEMM_ABL & 4)) load_frags(slot);  // LDS reads first: they drain while the TA chews the DMA addresses
+      if constexpr (STAGE && !(DN_GEMM_ABL & 1)) stage(fill);
+      if constexpr (LATE) pipe_sync<STAGE ? PER_STAGE : 0>(); else pipe_sync<63>();  // an odd segment for group 1
       __builtin_amdgcn_sched_barrier(0);
       // ---- C segment
-      if (!(p.pad_ & 8)) __builtin_amdgcn_s_setprio(1);
-      if (!(p.pad_ & 2)) mma_all();
+      if constexpr (!(DN_GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
+      if constexpr (!(DN_GEMM_ABL & 2)) mma_all();
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (late) {
-        pipe_sync<63>();
-      } else {  // odd segment for group 0
-        if (kt + 2 < nkt) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
-      }
+      if constexpr (LATE) pipe_sync<63>(); else pipe_sync<STAGE ? PER_STAGE : 0>();  // odd segment for group 0
       __builtin_amdgcn_sched_barrier(0);
-      slot = slot == 2 ? 0 : slot + 1;
-      fill = fill == 2 ? 0 : fill + 1;
-    }
+    };
+    auto run = [&](auto late_c) {
+      int slot = 0, fill = 2, kt = 0;
+      auto adv = [&]() { slot = slot == 2 ? 0 : slot + 1; fill = fill == 2 ? 0 : fill + 1; };
+      for (; kt + 2 < nkt; ++kt) { ktile(late_c, std::true_type{}, slot, fill); adv(); }
+      for (; kt < nkt; ++kt) { ktile(late_c, std::false_type{}, slot, fill); adv(); }
+    };
+    if (late) run(std::true_type{}); else run(std::false_type{});
     if (!late) pipe_sync<63>();  // group 0 matches group 1's extra barrier
   } else {
     // Two-stage loop for the 4-wave tile (two workgroups per CU overlap each other): one barrier per K-tile.
@@ -822,32 +829,35 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   const float row_scale = row_scale_finish(p, rs_req);
   __builtin_amdgcn_sched_barrier(0);
   if (late) pipe_sync<63>();  // the stagger
-  int slot = 0, fill = STAGES - 1;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int ahead = nkt - 1 - kt;  // tiles after kt
+  // The K loop is specialised on the wave's group, on whether the tile still stages (kt + 3 < nkt) and on the vmcnt its
+  // counted barrier waits for: no per-iteration conditions (a uniform branch in the wave that is feeding the MFMA pipe
+  // idles the pipe).
+  auto ktile = [&](auto late_c, auto stage_c, auto sync_c, int slot, int fill) {
+    constexpr bool LATE = decltype(late_c)::value, STAGE = decltype(stage_c)::value;
+    constexpr int SYNC = decltype(sync_c)::value;
     // ---- L segment
-    if (!(p.pad_ & 4)) load_frags(slot);
-    if (kt + STAGES - 1 < nkt && !(p.pad_ & 1)) stage(fill);
-    if (late) {
-      if (ahead >= 3) pipe_sync<2 * PER_STAGE>(); else if (ahead == 2) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
-    } else {
-      pipe_sync<63>();
-    }
+    if constexpr (!(DN_GEMM_ABL & 4)) load_frags(slot);
+    if constexpr (STAGE && !(DN_GEMM_ABL & 1)) stage(fill);
+    if constexpr (LATE) pipe_sync<SYNC>(); else pipe_sync<63>();
     __builtin_amdgcn_sched_barrier(0);
     // ---- C segment
-    if (!(p.pad_ & 8)) __builtin_amdgcn_s_setprio(1);
-    if (!(p.pad_ & 2)) mma_all();
+    if constexpr (!(DN_GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(DN_GEMM_ABL & 2)) mma_all();
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (late) {
-      pipe_sync<63>();
-    } else {
-      if (ahead >= 3) pipe_sync<2 * PER_STAGE>(); else if (ahead == 2) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
-    }
+    if constexpr (LATE) pipe_sync<63>(); else pipe_sync<SYNC>();
     __builtin_amdgcn_sched_barrier(0);
-    slot = slot == STAGES - 1 ? 0 : slot + 1;
-    fill = fill == STAGES - 1 ? 0 : fill + 1;
-  }
+  };
+  auto run = [&](auto late_c) {
+    using std::integral_constant;
+    int slot = 0, fill = STAGES - 1, kt = 0;
+    auto adv = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; fill = fill == STAGES - 1 ? 0 : fill + 1; };
+    for (; kt + 3 < nkt; ++kt) { ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER_STAGE>{}, slot, fill); adv(); }
+    if (nkt >= 3) { ktile(late_c, std::false_type{}, integral_constant<int, PER_STAGE>{}, slot, fill); adv(); }  // two tiles follow
+    if (nkt >= 2) { ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill); adv(); }
+    ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill);
+  };
+  if (late) run(std::true_type{}); else run(std::false_type{});
   if (!late) pipe_sync<63>();
 
   // ---- epilogue: two 64 x 64 halves of the wave's 64 (m) x 128 (n) tile through its LDS slab

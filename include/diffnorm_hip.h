@@ -89,8 +89,8 @@ typedef struct {
   int64_t gb_gstride;
   const float* pos_table; /* POSEMB: fp32 [T+1, pos_ld] sinusoidal table, row 0 = zeros             */
   int32_t pos_ld;
-  int32_t pad_;        /* profiling only.  bits 0..7: ablation switches (bit0 skip DMA, bit1 skip MFMA, bit2 skip
-                          LDS reads inside the K loop, bit3 no s_setprio, bit4 4-column instead of 8-column bf16 stores), 0 in every product call; bits 8..15: launch tag
+  int32_t pad_;        /* profiling / tests only.  bit4: 4-column instead of 8-column bf16 stores (the K-loop ablations that
+                          used bits 0..3 are compile-time now: -DDN_GEMM_ABL); 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start; bits 16..19: force a tile variant (tests: 1 = 128x128,
                           2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0, 6 = 256x256 with one wave per SIMD [bf16]),
                           0 = chosen from the shape; bit 22: let the
