@@ -115,6 +115,11 @@ def load():
         raise DiffNormHipError(
             f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
             "Build it with `make -C diffnorm_amd/csrc` or `__graft_entry__.build()`.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and every device pointer this library receives
+    # comes from torch, so torch's copy must be the one that is loaded (and initialised) first -- loading this library
+    # first binds it to the system copy, which then has no device context ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
