@@ -202,27 +202,29 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * 2;
   if constexpr (EPI == DN_EPI_GEGLU) {
-    // value columns 0..31 and gate columns 32..63 of the slab -> 32 output columns: 4 lanes per row, 16 rows per pass
+    // packed columns come in 16-column tiles [8 value | 8 gate]: a slab of 64 carries 32 output columns; 4 lanes per row
+    // (one tile = 8 outputs each), 16 rows per pass
     const int c8 = (lane & 3) * 8;
-    const int np = n_base + c8;        // packed row of the value
+    const int sv = (lane & 3) * 16;    // slab column of this lane's value octet; its gate octet follows at + 8
+    const int np = n_base + sv;        // packed row of the value octet (bias / row_bias index)
     const int n = (n_base >> 1) + c8;  // output column
-    if (n >= p.N) return;
+    if (n >= p.N || sv >= ncols) return;
     float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (bias) {
       *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bias + np);
       *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bias + np + 4);
-      *reinterpret_cast<float4*>(bg) = *reinterpret_cast<const float4*>(bias + np + 32);
-      *reinterpret_cast<float4*>(bg + 4) = *reinterpret_cast<const float4*>(bias + np + 36);
+      *reinterpret_cast<float4*>(bg) = *reinterpret_cast<const float4*>(bias + np + 8);
+      *reinterpret_cast<float4*>(bg + 4) = *reinterpret_cast<const float4*>(bias + np + 12);
     }
     // beta . W^T: per sample -> fetched per row; one row for the batch -> fetched once.  Either way it enters as
-    // fma(acc, scale, rb) + bias, so shared_t and per-sample t give bit-identical results.
+    // acc * scale + rb + bias in the same order, so shared_t and per-sample t give bit-identical results.
     const bool rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;
     float rsv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rsg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.row_ssq && p.row_bias && !rb_rows) {
       *reinterpret_cast<float4*>(rsv) = *reinterpret_cast<const float4*>(p.row_bias + np);
       *reinterpret_cast<float4*>(rsv + 4) = *reinterpret_cast<const float4*>(p.row_bias + np + 4);
-      *reinterpret_cast<float4*>(rsg) = *reinterpret_cast<const float4*>(p.row_bias + np + 32);
-      *reinterpret_cast<float4*>(rsg + 4) = *reinterpret_cast<const float4*>(p.row_bias + np + 36);
+      *reinterpret_cast<float4*>(rsg) = *reinterpret_cast<const float4*>(p.row_bias + np + 8);
+      *reinterpret_cast<float4*>(rsg + 4) = *reinterpret_cast<const float4*>(p.row_bias + np + 12);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -230,10 +232,10 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       const int m = m_base + row;
       if (!FULL && m >= p.M) continue;
       float v[8], gt[8], o[8];
-      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8);
-      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 + 4);
-      *reinterpret_cast<float4*>(gt) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8);
-      *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c8 + 4);
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv + 4);
+      *reinterpret_cast<float4*>(gt) = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv + 8);
+      *reinterpret_cast<float4*>(gt + 4) = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv + 12);
       if (p.row_ssq) {  // split norm: scale the accumulators by the row's factor (unless the slab copy did), add beta . W^T
         const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
         float rv[8], rg[8];
@@ -243,8 +245,8 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
           const float* rb = row_bias_of(p, m);
           *reinterpret_cast<float4*>(rv) = *reinterpret_cast<const float4*>(rb + np);
           *reinterpret_cast<float4*>(rv + 4) = *reinterpret_cast<const float4*>(rb + np + 4);
-          *reinterpret_cast<float4*>(rg) = *reinterpret_cast<const float4*>(rb + np + 32);
-          *reinterpret_cast<float4*>(rg + 4) = *reinterpret_cast<const float4*>(rb + np + 36);
+          *reinterpret_cast<float4*>(rg) = *reinterpret_cast<const float4*>(rb + np + 8);
+          *reinterpret_cast<float4*>(rg + 4) = *reinterpret_cast<const float4*>(rb + np + 12);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { v[i] = __fadd_rn(__fmul_rn(v[i], sm), rv[i]); gt[i] = __fadd_rn(__fmul_rn(gt[i], sm), rg[i]); }
@@ -305,33 +307,35 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (OUT_BF ? 2 : 4);
   if constexpr (EPI == DN_EPI_GEGLU) {
-    // value columns 0..31 and gate columns 32..63 of the slab -> 32 output columns: 8 lanes per row, 8 rows per pass
+    // packed columns come in 16-column tiles [8 value | 8 gate]: a slab of 64 carries 32 output columns; 8 lanes per row
+    // (half a tile = 4 outputs each), 8 rows per pass
     const int c4 = (lane & 7) * 4;
-    const int np = n_base + c4;              // packed row of the value
-    const int n = (n_base >> 1) + c4;        // output column
-    if (n >= p.N) return;
+    const int sv = (c4 >> 3) * 16 + (c4 & 7);  // slab column of this lane's 4 values; their gates follow at + 8
+    const int np = n_base + sv;                // packed row of the first value (bias / row_bias index)
+    const int n = (n_base >> 1) + c4;          // output column
+    if (n >= p.N || sv >= ncols) return;
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + np) : make_float4(0, 0, 0, 0);
-    const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 32) : make_float4(0, 0, 0, 0);
+    const float4 bg = bias ? *reinterpret_cast<const float4*>(bias + np + 8) : make_float4(0, 0, 0, 0);
     const bool rb_rows = p.row_ssq && p.row_bias && p.row_bias_ld != 0;  // per-sample beta . W^T: fetched per row
     float4 rsv = make_float4(0, 0, 0, 0), rsg = rsv;                      // one row for the batch: fetched once
     if (p.row_ssq && p.row_bias && !rb_rows) {
       rsv = *reinterpret_cast<const float4*>(p.row_bias + np);
-      rsg = *reinterpret_cast<const float4*>(p.row_bias + np + 32);
+      rsg = *reinterpret_cast<const float4*>(p.row_bias + np + 8);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = j * 8 + (lane >> 3);
       const int m = m_base + row;
       if (!FULL && m >= p.M) continue;
-      float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-      float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + 32 + c4);
+      float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv);
+      float4 gt = *reinterpret_cast<const float4*>(ep + row * EP_LD + sv + 8);
       if (p.row_ssq) {
         const float sm = prescaled ? 1.f : ep[row * EP_LD + 64];
         float4 rv = rsv, rg = rsg;
         if (rb_rows) {
           const float* rb = row_bias_of(p, m);
           rv = *reinterpret_cast<const float4*>(rb + np);
-          rg = *reinterpret_cast<const float4*>(rb + np + 32);
+          rg = *reinterpret_cast<const float4*>(rb + np + 8);
         }
         v = make_float4(__fadd_rn(__fmul_rn(v.x, sm), rv.x), __fadd_rn(__fmul_rn(v.y, sm), rv.y), __fadd_rn(__fmul_rn(v.z, sm), rv.z),
                         __fadd_rn(__fmul_rn(v.w, sm), rv.w));
@@ -1170,7 +1174,9 @@ template <typename E, int EPI, bool TAPS_INNER, int NTW>
 __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
   static_assert(std::is_same<E, BF16>::value, "the one-wave-per-SIMD tiles are built for bf16 operands only");
   static_assert(NTW == 11 || NTW == 8, "n-tiles per wave");
-  static_assert(NTW == 8 || EPI == DN_EPI_BIAS, "the 352-wide tile only carries the BIAS epilogue (its wave columns start at multiples of 176)");
+  static_assert(NTW == 8 || EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU,
+                "the 352-wide tile carries the BIAS and GEGLU epilogues (its waves start at multiples of 176 columns: fine for "
+                "GEGLU's self-contained 16-column tiles, not for the others' assumptions)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
@@ -1623,11 +1629,15 @@ static int launch(const DnGemmParams& p, hipStream_t s) {
   // Tile variant: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests) force one, 0 = choose by shape.
   static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
   const int force = ((p.pad_ >> 16) & 15) ? ((p.pad_ >> 16) & 15) : env_tile;
-  if constexpr (EPI == DN_EPI_BIAS && std::is_same<E, BF16>::value) {
-    // the 256 x 352 one-wave-per-SIMD tile: bf16, N a multiple of 352 and at least ~half a chip of tiles (a workgroup owns a CU's whole LDS;
-    // measured +2.5 % per denoising step on half batches, +5 % on whole ones, against the 256 x 256 tile)
-    const long tiles_fat = (long)((p.M + 255) / 256) * (p.N / 352) * p.groups;
-    if (p.N % 352 == 0 && (force == 4 || (force == 0 && tiles_fat >= 100))) return launch_fat<E, EPI, 11>(p, s);
+  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && std::is_same<E, BF16>::value) {
+    // the 256 x 352 one-wave-per-SIMD tile: bf16, packed columns a multiple of 352 and at least ~half a chip of tiles (a
+    // workgroup owns a CU's whole LDS; measured +2.5 % per denoising step on half batches, +5 % on whole ones, against the
+    // 256 x 256 tile on the FFN conv)
+    const int npk = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+    const long tiles_fat = (long)((p.M + 255) / 256) * (npk / 352) * p.groups;
+    // chosen by itself only for the long-K BIAS contractions; on the GEGLU projection (K = 512: 16 K-tiles) it measured
+    // level with the 256 x 256 tile (67.6 vs 66.1 us), so there it runs only when forced
+    if (npk % 352 == 0 && (force == 4 || (force == 0 && EPI == DN_EPI_BIAS && tiles_fat >= 100))) return launch_fat<E, EPI, 11>(p, s);
   }
   if constexpr (std::is_same<E, BF16>::value) {
     if (force == 6) return launch_fat<E, EPI, 8>(p, s);

@@ -7,8 +7,8 @@ weights [out,in]).  Output: the ordered tensor tables `dn_eps_create` / `dn_vae_
 * every weight becomes [rows padded to 128][K padded to 64] with K contiguous, in the arithmetic
   dtype (bf16 or fp32); pads are zeros, so padded channels stay exactly zero through the network;
 * a k-tap causal conv becomes k matrices, tap j multiplying the frame t-(k-1-j)*dilation;
-* Linear(D, 2*inner) of the GEGLU is interleaved in blocks of 64 rows = [32 value rows ; 32 gate rows]
-  so one wave holds value and gate of the same column (epilogue DN_EPI_GEGLU);
+* Linear(D, 2*inner) of the GEGLU is interleaved per 16-row MFMA tile = [8 value rows ; 8 gate rows of the same output
+  columns], so every tile is self-contained and one wave holds value and gate of a column (epilogue DN_EPI_GEGLU);
 * the 2*S*L FiLM and 2*depth adaptive-RMSNorm projections are stacked into one [n_cond, C] matrix,
   each as [gamma(Dp) ; beta(Dp)];
 * biases, norm gammas, the Fourier frequencies and the sinusoidal table stay fp32.
@@ -94,8 +94,10 @@ def _geglu_rows(inner: int) -> torch.Tensor:
     """Source row in Linear(D,2*inner).weight for every packed row (or -1 for a zero row)."""
     ip = padk(inner)
     p = torch.arange(2 * ip)
-    col = (p // 64) * 32 + (p % 32)
-    is_gate = (p % 64) >= 32
+    # every 16-row MFMA tile is self-contained: 8 value rows then the 8 gate rows of the same output columns, so a kernel
+    # may cut the packed matrix at any multiple of 16 rows (the 256 x 352 tile gives a wave 176 of them)
+    col = (p // 16) * 8 + (p % 8)
+    is_gate = (p % 16) >= 8
     src = torch.where(is_gate, col + inner, col)
     return torch.where(col < inner, src, torch.full_like(src, -1))
 

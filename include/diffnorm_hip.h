@@ -40,7 +40,8 @@ enum {
 enum {
   DN_EPI_BIAS = 0,      /* out = acc + bias                                               (nn.Linear / CausalConv1d) */
   DN_EPI_SILU = 1,      /* out = silu(acc + bias)                                          latent_module.py:741-745 */
-  DN_EPI_GEGLU = 2,     /* out[:, j] = gelu_erf(gate_j) * value_j, GEGLU-interleaved packing latent_module.py:881-884 */
+  DN_EPI_GEGLU = 2,     /* out[:, j] = gelu_erf(gate_j) * value_j (latent_module.py:881-884); W rows packed per 16-row tile:
+                           packed row 16 t + i = value row 8 t + i (i < 8) or gate row 8 t + i - 8 (i >= 8)        */
   DN_EPI_FILM_GATE = 3, /* h=(acc+bias)[*gamma+beta]; out = tanh(h)*sigmoid(h) + res      latent_module.py:525-530 */
   DN_EPI_RESADD = 4,    /* out = res + acc + bias  (fp32 residual stream)                  latent_module.py:692,704 */
   DN_EPI_POSEMB = 5     /* out = acc + bias + pe[pos(b,t)]                                 latent_module.py:867-868 */

@@ -253,6 +253,37 @@ def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
     assert maxerr(xn.float().cpu().view(B, T, Dp)[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
 
 
+@pytest.mark.parametrize("tile", [0, 3, 4])
+def test_geglu_on_the_352_wide_tile(ops, tile):
+    """GEGLU projection whose packed width (2 x padk(inner) = 1408) is a multiple of 352: the one-wave-per-SIMD tile cuts the
+    packed matrix at multiples of 176 columns, which the [8 value | 8 gate] packing allows; bit-identical to the 256x256 tile."""
+    ops_, packing, _lib = ops
+    B, T, D, inner = 3, 100, 128, 700
+    ip = padk(inner)
+    assert (2 * ip) % 352 == 0
+    x = seeded((B, T, D), 1)
+    w = seeded((2 * inner, D), 2, D ** -0.5)
+    b = seeded((2 * inner,), 3, 0.2)
+    h = torch.nn.functional.linear(bf16r(x), bf16r(w), b)
+    val, gate = h.chunk(2, dim=-1)
+    want = torch.nn.functional.gelu(gate) * val
+    rows = packing._geglu_rows(inner)
+    keep = rows >= 0
+    wp, bp = torch.zeros(2 * ip, D), torch.zeros(2 * ip)
+    wp[keep], bp[keep] = w[rows[keep]], b[rows[keep]]
+    M = B * T
+    xa = act(x.view(M, D), "bf16")
+    outs = {}
+    for tl in (1, tile):
+        out = torch.full((M, ip), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops_.conv_gemm([(xa, act(wp, "bf16"), 0)], out, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tl)
+        outs[tl] = out
+    got = outs[tile].float().cpu().view(B, T, ip)
+    assert maxerr(got[..., :inner], want) < 2 ** -8 * max(1.0, want.abs().max().item())
+    assert got[..., inner:].abs().max().item() == 0.0
+    assert torch.equal(outs[tile], outs[1])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tile", [0, 1, 3])
 @pytest.mark.parametrize("mode", ["adaptive", "adaptive_shared", "learned"])
