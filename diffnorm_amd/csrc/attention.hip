@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
       }
     }
   };
+  // Per-lane LDS offsets of the fragment reads, hoisted out of the key loop: a tile row's swizzle key (row & 7, or & 15 for
+  // f32) depends on the lane only (tile rows advance in multiples of 16), so every read below is one of these bases plus a
+  // compile-time constant that folds into the ds_read offset field -- no address arithmetic per tile (the loop is
+  // issue-bound on VALU/LDS instructions, not on the matrix pipe).
+  int k_base[KS_D];  // row fr, 16-byte chunk ks*4 + fg
+#pragma unroll
+  for (int ks = 0; ks < KS_D; ++ks) k_base[ks] = lds_off<E>(fr, ks * 64 + fg * 16);
+  int v_base[DT];    // bf16: row fg*4 + (fr >> 2), 8-byte piece dt*4 + (fr & 3)
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) v_base[dt] = lds_off<E>(fg * 4 + (fr >> 2), ES == 2 ? dt * 32 + (fr & 3) * 8 : 0);
   using SET0 = std::integral_constant<int, 0>;
   using SET1 = std::integral_constant<int, 1>;
   issue_loads(SET0{}, 0);
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(kt_lds + lds_off<E>(kt * 16 + fr, ks * 64 + fg * 16));
+        const uint4 kf = *reinterpret_cast<const uint4*>(kt_lds + k_base[ks] + kt * 16 * ROWB);
         mma_kstep<E>(acc_s[kt][0], kf, qf[0][ks]);
         mma_kstep<E>(acc_s[kt][1], kf, qf[1][ks]);
       }
@@ -225,9 +235,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
         for (int dt = 0; dt < DT; ++dt) {
           const int byte = dt * 32 + (fr & 3) * 8;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt_lds + lds_off<E>(krow0, byte)));
+              (__attribute__((address_space(3))) s16x4*)(vt_lds + v_base[dt] + (2 * kk) * 16 * ROWB));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt_lds + lds_off<E>(krow1, byte)));
+              (__attribute__((address_space(3))) s16x4*)(vt_lds + v_base[dt] + (2 * kk + 1) * 16 * ROWB));
           uint4 vf;
           const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
           vf.x = lo2.x; vf.y = lo2.y; vf.z = hi2.x; vf.w = hi2.y;
