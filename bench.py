@@ -8,6 +8,10 @@ bf16 MFMA arithmetic, synthetic N(0,1) latents and random-init weights of the re
 With N > 1 every rank runs its own [32,512] batch (utterances are independent: weak scaling, no
 data-path collective); value = N*K steps / max-over-ranks time.
 
+Sequence per rank: an untimed 3-step set-up call (builds the chain's conditioning table for all remaining timesteps and
+captures the step graph), W untimed warm-up steps, barrier, EXACTLY K timed steps of the same chain, barrier.  The
+once-per-chain table build is reported separately ("chain_setup_ms", ~4 ms against a 998-step chain of ~5.7 s).
+
 Extra objects: "roofline" (dominant kernel = the FFN causal-conv contraction, timed live with HIP
 events) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1).
 """
@@ -165,7 +169,7 @@ def main():
     sched = scheduler.DDPMScheduler(args.timesteps)
     coef = sched.ddim_coef_table(dev)
     start = args.timesteps - 1  # "full 1000-step" chain: t = 998 ... 1 (last bullet)
-    assert W + K + 7 <= start - 1, "steps + warmup exceed the chain length"
+    assert W + K + 10 <= start - 1, "steps + warmup exceed the chain length"
     x = ops.randn((B, T, cfg.latent_dim), seed=1234 + rank, device=dev)  # x_T ~ N(0, I): the build's Philox
     lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
 
@@ -177,20 +181,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    SETUP = 3  # untimed: builds the chain's conditioning table and captures the step graph (the analogue of loading / compiling)
     with torch.cuda.stream(stream):
+        assert eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=SETUP, split=not args.no_split) == SETUP
+        pos = start - SETUP
         if W > 0:
-            n = eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=W, split=not args.no_split)
+            n = eng.ddim_loop(x, lengths, pos, coef, use_graph=not args.no_graph, max_evals=W, split=not args.no_split, keep_table=True)
             assert n == W
+            pos -= W
         barrier()
         t0 = time.perf_counter()
-        # the timed K steps continue the chain the warm-up started: its conditioning table (built once per chain, for
-        # all 998 steps) is kept, as it would be for the rest of a real chain
-        n = eng.ddim_loop(x, lengths, start - W, coef, use_graph=not args.no_graph, max_evals=K, split=not args.no_split,
-                          keep_table=W > 0)
+        # the timed K steps continue the same chain: its conditioning table (built once per chain, for all 998 steps) is
+        # kept, as it would be for the rest of a real chain
+        n = eng.ddim_loop(x, lengths, pos, coef, use_graph=not args.no_graph, max_evals=K, split=not args.no_split, keep_table=True)
         barrier()
         dt = time.perf_counter() - t0
         assert n == K
         assert torch.isfinite(x).all().item(), "state diverged"
+        pos -= K
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -204,7 +212,7 @@ def main():
         with torch.cuda.stream(stream):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            eng.ddim_loop(x, lengths, start - W - K, coef, use_graph=not args.no_graph, max_evals=2, split=not args.no_split)
+            eng.ddim_loop(x, lengths, pos, coef, use_graph=not args.no_graph, max_evals=2, split=not args.no_split)
             torch.cuda.synchronize()
             chain_setup_ms = max(0.0, (time.perf_counter() - t1) * 1e3 - 2 * dt / K * 1e3)
         with torch.cuda.stream(stream):
@@ -213,7 +221,7 @@ def main():
             import ctypes
             lib = _lib.load()
             _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV, 12 * 5), "dn_profile_start")
-            eng.ddim_loop(x, lengths, start - W - K - 2, coef, use_graph=False, max_evals=5, split=False)
+            eng.ddim_loop(x, lengths, pos - 2, coef, use_graph=False, max_evals=5, split=False)
             avg_ms, n_l = ctypes.c_float(), ctypes.c_int32()
             _lib.check(lib.dn_profile_stop(ctypes.byref(avg_ms), ctypes.byref(n_l)), "dn_profile_stop")
             ksec = avg_ms.value * 1e-3
