@@ -253,6 +253,36 @@ def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
     assert maxerr(xn.float().cpu().view(B, T, Dp)[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
 
 
+def test_random_shapes_every_variant_bit_identical(ops):
+    """40 seeded random causal-conv problems (ragged M, T that puts sequence starts anywhere in a tile, 1..4 taps, dilations
+    beyond T, K of 1..5 K-tiles, N of any multiple of 32 incl. multiples of 352): every term-outer tile variant returns the
+    same bits as the 128x128 tile, and that one matches the oracle."""
+    ops_, packing, _lib = ops
+    rng = np.random.RandomState(1234)
+    for case in range(40):
+        k = int(rng.randint(1, 5))
+        cin = int(rng.choice([32, 64, 96, 160, 320]))
+        cout = int(rng.choice([32, 64, 96, 160, 352, 416, 704]))
+        B, T = int(rng.randint(1, 5)), int(rng.randint(1, 400))
+        dil = int(rng.choice([1, 1, 2, 7, 64, 500]))
+        x = seeded((B, T, cin), 100 + case)
+        w = seeded((cout, cin, k), 200 + case, (1.0 / (cin * k)) ** 0.5)
+        b = seeded((cout,), 300 + case, 0.1)
+        xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+        W = packing._conv(w, _lib.DN_BF16).to(DEV)
+        bias = packing._vec(b, W.shape[1]).to(DEV)
+        terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
+        outs = {}
+        for tile in (1, 2, 3, 6) + ((4,) if cout % 352 == 0 else ()):
+            out = torch.full((B * T, cout), float("nan"), device=DEV)
+            ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=tile)
+            outs[tile] = out
+        ref = O.causal_conv1d(bf16r(x), bf16r(w), b, dil)
+        assert maxerr(outs[1].cpu().view(B, T, -1), ref) < 3e-4, (case, k, cin, cout, B, T, dil)
+        for tile, o in outs.items():
+            assert torch.equal(o, outs[1]), (case, tile, k, cin, cout, B, T, dil)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4])
 def test_geglu_on_the_352_wide_tile(ops, tile):
     """GEGLU projection whose packed width (2 x padk(inner) = 1408) is a multiple of 352: the one-wave-per-SIMD tile cuts the
