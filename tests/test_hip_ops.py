@@ -253,6 +253,26 @@ def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
     assert maxerr(xn.float().cpu().view(B, T, Dp)[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
 
 
+@pytest.mark.parametrize("tile", [1, 3, 4, 6])
+def test_grouped_bias_gemm_every_variant(ops, tile):
+    """Groups (the per-block 1x1 convs of a WaveNet stack share one launch): 3 independent [M,128]x[128,352] problems with
+    their own weights, biases and outputs, shared activations; every variant incl. the one-wave-per-SIMD tiles."""
+    ops_, packing, _lib = ops
+    B, T, cin, cout, L = 2, 150, 128, 352, 3
+    x = seeded((B, T, cin), 1)
+    ws = [seeded((cout, cin), 10 + i, cin ** -0.5) for i in range(L)]
+    bs = [seeded((cout,), 20 + i, 0.1) for i in range(L)]
+    M = B * T
+    xa = act(x.view(M, cin), "bf16")
+    W = torch.stack([packing._mat(w, _lib.DN_BF16) for w in ws]).to(DEV)  # [L, 384, 128]
+    bias = torch.stack([packing._vec(b, W.shape[1]) for b in bs]).to(DEV)
+    out = torch.full((L, M, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops_.conv_gemm([(xa, W, 0)], out, T, cout, bias=bias, groups=L, a_grouped=False, tile=tile)
+    for i in range(L):
+        want = torch.nn.functional.linear(bf16r(x), bf16r(ws[i]), bs[i]).view(M, cout)
+        assert maxerr(out[i].float().cpu(), want) < 2 ** -8 * max(1.0, want.abs().max().item()), i
+
+
 def test_random_shapes_every_variant_bit_identical(ops):
     """40 seeded random causal-conv problems (ragged M, T that puts sequence starts anywhere in a tile, 1..4 taps, dilations
     beyond T, K of 1..5 K-tiles, N of any multiple of 32 incl. multiples of 352): every term-outer tile variant returns the
