@@ -1139,9 +1139,15 @@ __device__ __forceinline__ void lds_wait_all_but() { asm volatile("s_waitcnt lgk
 // n-tile g: the weight fragment that will be used two n-tiles later, then -- for n-tiles BG .. BG + 8/NPG - 1 -- NPG of the
 // next K-tile's 8 activation fragments.  LDS returns in order, so a use must allow exactly the requests issued after
 // the one it needs to stay outstanding; these functions count them (two consecutive K-tiles laid end to end).
-template <int NT, int BG, int NPG>
+// An accumulator tile from its AGPRs to LDS (DS instructions take AGPR data operands on gfx90a and later).
+template <int OFF>
+__device__ __forceinline__ void acc_to_lds(uint32_t lds_addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(lds_addr), "a"(v), "n"(OFF) : "memory");
+}
+
+template <int NT, int BG, int NPG, int MT = 8>
 struct SoloSched {
-  static constexpr int per_group(int g) { return 1 + ((g >= BG && g < BG + 8 / NPG) ? NPG : 0); }
+  static constexpr int per_group(int g) { return 1 + ((g >= BG && g < BG + MT / NPG) ? NPG : 0); }
   static constexpr int prefix(int g) { int n = 0; for (int h = 0; h < g; ++h) n += per_group(h); return n; }
   static constexpr int R = prefix(NT);
   // weight fragment nt of a K-tile is requested in n-tile nt-2 of the same K-tile, or (nt = 0, 1) in n-tile NT-2+nt of
@@ -1149,7 +1155,7 @@ struct SoloSched {
   static constexpr int younger_w(int nt) { return (R + prefix(nt)) - ((nt >= 2 ? R + prefix(nt - 2) : prefix(NT - 2 + nt)) + 1); }
   // the last activation fragment is the last request of n-tile BG + 8/NPG - 1; the copies that need it sit in the last
   // n-tile behind that n-tile's own weight request
-  static constexpr int younger_copy() { return (prefix(NT - 1) + 1) - ((prefix(BG + 8 / NPG - 1) + per_group(BG + 8 / NPG - 1) - 1) + 1); }
+  static constexpr int younger_copy() { return (prefix(NT - 1) + 1) - ((prefix(BG + MT / NPG - 1) + per_group(BG + MT / NPG - 1) - 1) + 1); }
 };
 static_assert(SoloSched<11, 1, 1>::younger_w(0) == 1 && SoloSched<11, 1, 1>::younger_w(2) == 2 && SoloSched<11, 1, 1>::younger_w(5) == 3 &&
               SoloSched<11, 1, 1>::younger_w(10) == 2 && SoloSched<11, 1, 1>::younger_copy() == 2, "schedule arithmetic");
@@ -1170,10 +1176,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // NTW = n-tiles per wave: 11 -> the 256 x 352 tile (N a multiple of 352, BIAS epilogue), 8 -> a 256 x 256 tile for any N and
 // every epilogue (64 accumulator tiles, all in AGPRs).
-template <typename E, int EPI, bool TAPS_INNER, int NTW>
-__global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
-  static_assert(std::is_same<E, BF16>::value, "the one-wave-per-SIMD tiles are built for bf16 operands only");
+// WAVES = 8 (NTW = 8 only) runs the same instruction stream with TWO waves per SIMD, each on a 64 x 128 sub-tile: the partner's
+// MFMAs cover a wave's DMA-issue stalls without the segment barriers of the staggered two-group kernels.
+template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
+  static_assert(std::is_same<E, BF16>::value, "the hand-scheduled tiles are built for bf16 operands only");
   static_assert(NTW == 11 || NTW == 8, "n-tiles per wave");
+  static_assert(WAVES == 4 || (WAVES == 8 && NTW == 8), "4 waves (one per SIMD) or, on the 256 x 256 tile, 8");
   static_assert(NTW == 8 || EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU,
                 "the 352-wide tile carries the BIAS and GEGLU epilogues (its waves start at multiples of 176 columns: fine for "
                 "GEGLU's self-contained 16-column tiles, not for the others' assumptions)");
@@ -1182,14 +1191,16 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   constexpr int KT = ROWB2 / ES;
   constexpr int BMF = 256, BNF = 32 * NTW, STAGES = 4;
   constexpr int W_BYTES = BNF * ROWB2, A_BYTES = BMF * ROWB2, STAGE_BYTES = W_BYTES + A_BYTES;  // 352: 22528 + 16384
-  constexpr int NWP = BNF / 16, WPW = (NWP + 3) / 4;  // weight pieces per stage / per wave (352: 22 / 6, two waves repeat one)
-  constexpr int PER = WPW + 4;  // DMA pieces per wave per stage: WPW weight pieces, then 4 of the 16 row pieces
-  constexpr int NT = NTW, MT = 8;
+  constexpr int NWP = BNF / 16, WPW = (NWP + WAVES - 1) / WAVES;  // weight pieces per stage / per wave (352: 22 / 6, two waves repeat one)
+  constexpr int APW = 16 / WAVES;   // row pieces (16 rows each) per wave
+  constexpr int PER = WPW + APW;    // DMA pieces per wave per stage: WPW weight pieces, then APW of the 16 row pieces
+  constexpr int NT = NTW, MT = 32 / WAVES;  // a wave's sub-tile: 16 MT rows (128 or 64) x 16 NT columns
+  constexpr int RPW = 16 * MT;
   constexpr int BG = NTW == 11 ? 1 : 0;   // n-tile whose top carries the barrier: the first one that touches K-tile kt+1
-  constexpr int NPG = NTW == 11 ? 1 : 2;  // next-K-tile activation fragments requested per n-tile (n-tiles BG .. BG + 8/NPG - 1)
-  using Sched = SoloSched<NT, BG, NPG>;
+  constexpr int NPG = (NTW == 11 || WAVES == 8) ? 1 : 2;  // next-K-tile activation fragments requested per n-tile (n-tiles BG .. BG + MT/NPG - 1)
+  using Sched = SoloSched<NT, BG, NPG, MT>;
   static_assert((NT - 2) % 3 == 0, "weight fragments 2..NT-1 must cycle the 3-deep ring a whole number of times per K-tile");
-  static_assert(BG + PER - 1 == NT - 1, "one DMA piece per n-tile from the barrier to the last n-tile");
+  static_assert(BG + PER - 1 <= NT - 1 && BG + MT / NPG - 1 <= NT - 3, "DMA pieces and activation requests fit the n-tiles");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1224,8 +1235,8 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   const int ktiles_per_term = p.K / KT;
   const int nkt = p.n_terms * ktiles_per_term;
   constexpr bool taps_inner = TAPS_INNER;  // compile-time: a uniform branch in this K loop costs the lone wave ~20 cycles
-  const char* a_ptr[4];  // term-outer: this term's (shifted) row; tap-inner: the unshifted row
-  int a_inc[4];          // term-outer: 64 or 0 (zero page); tap-inner: the row's frame index m % T
+  const char* a_ptr[APW];  // term-outer: this term's (shifted) row; tap-inner: the unshifted row
+  int a_inc[APW];          // term-outer: 64 or 0 (zero page); tap-inner: the row's frame index m % T
   uint32_t w_voff = 0;
   uint64_t w_base = 0;   // uniform: term weight base + tile's first row (term-outer)
   int s_term = 0, s_kk = 0;
@@ -1235,8 +1246,8 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + (wave * 4 + i) * 16 + srow;
+    for (int i = 0; i < APW; ++i) {
+      int m = m0 + (wave * APW + i) * 16 + srow;
       m = m < p.M ? m : p.M - 1;
       const bool valid = (m % p.T) >= shift;
       a_ptr[i] = valid ? A + (int64_t)(m - shift) * tm.lda * ES : zero_src;
@@ -1263,8 +1274,8 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     tap_shift = tap_shift0; tap_delta = tap_delta0; tap_wbase = tap_wbase0;
     const char* A = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + schunk * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + (wave * 4 + i) * 16 + srow;
+    for (int i = 0; i < APW; ++i) {
+      int m = m0 + (wave * APW + i) * 16 + srow;
       m = m < p.M ? m : p.M - 1;
       a_ptr[i] = A + (int64_t)m * t0.lda * ES;
       a_inc[i] = m % p.T;
@@ -1279,18 +1290,18 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
     constexpr int i = decltype(i_c)::value;
     const uint32_t sbase = lds_base + slot * STAGE_BYTES;
     if constexpr (i < WPW) {
-      int pc = wave + 4 * i;
+      int pc = wave + WAVES * i;
       pc = pc < pc_max ? pc : pc_max;  // 352: waves 2, 3 repeat the last piece (every wave issues PER pieces); ragged N
       return sbase + pc * 1024;
     } else {
-      return sbase + W_BYTES + (wave * 4 + (i - WPW)) * 1024;
+      return sbase + W_BYTES + (wave * APW + (i - WPW)) * 1024;
     }
   };
   uint64_t piece_base = 0;  // SALU copy of the current weight piece's scalar base (see glds_set_m0_base)
   auto piece_setup = [&](auto i_c, int slot) {
     constexpr int i = decltype(i_c)::value;
     if constexpr (i < WPW) {
-      int pc = wave + 4 * i;
+      int pc = wave + WAVES * i;
       pc = pc < pc_max ? pc : pc_max;
       const uint64_t wb = taps_inner ? tap_wbase : w_base;
       piece_base = glds_set_m0_base(piece_lds_addr(i_c, slot), wb + pc * piece_stride);
@@ -1323,7 +1334,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
       tap_wbase = wrap ? tap_wbase0 : tap_wbase + tap_wstride;
       const int inc = wrap ? ROWB2 : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a_ptr[i] += inc;
+      for (int i = 0; i < APW; ++i) a_ptr[i] += inc;
       w_voff += inc;
     } else {
       if (++s_kk == ktiles_per_term) {
@@ -1331,7 +1342,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
         if (++s_term < p.n_terms) setup_term(s_term);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
+        for (int i = 0; i < APW; ++i) a_ptr[i] += a_inc[i];
         w_voff += ROWB2;
       }
     }
@@ -1350,7 +1361,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   const int frow = lane & 15, fq = lane >> 4;
   const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
   const uint32_t w_rd = lds_base + (wn * (16 * NTW) + frow) * ROWB2 + coff;     // + slot * STAGE_BYTES + nt * 1024
-  const uint32_t a_rd = lds_base + W_BYTES + (wm * 128 + frow) * ROWB2 + coff;  // + slot * STAGE_BYTES + mt * 1024
+  const uint32_t a_rd = lds_base + W_BYTES + (wm * RPW + frow) * ROWB2 + coff;  // + slot * STAGE_BYTES + mt * 1024
 
   // One K-tile = 11 n-tiles of 8 MFMAs.  With the LDS ~2/3 busy (76 KiB of fragment reads + 38 KiB of DMA writes per
   // K-tile) its latency is several hundred cycles, so every fragment is requested long before its first use:
@@ -1387,59 +1398,45 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
       // 8 MFMAs; after MFMA g the wave has ~8 issue cycles before the pipe can take the next one: one short instruction
       // per gap is free, so the n-tile's other work is dealt out one piece per gap instead of being bunched in front
       const int fill = slot == 0 ? STAGES - 1 : slot - 1;  // the slot tile kt-1 lived in receives tile kt+3
-      constexpr bool dma = nt >= BG && STAGE && !(DN_FAT_ABL & 1);
+      constexpr bool dma = nt >= BG && nt - BG < PER && STAGE && !(DN_FAT_ABL & 1);
+      constexpr bool dma_last = dma && nt - BG == PER - 1;  // the stage's last piece: advance the staging cursors behind it
       constexpr int a_first = (nt - BG) * NPG;  // first next-K-tile activation fragment requested in this n-tile
       constexpr bool a_req = nt >= BG && a_first < MT;
-      auto mf = [&](auto mt_c) {
+      static_assert(nt < NT - 1 || !a_req, "no activation request in the last n-tile");
+      using std::integral_constant;
+      static_for<MT>([&](auto mt_c) {
         constexpr int mt = decltype(mt_c)::value;
         if constexpr (!(DN_FAT_ABL & 2) || mt == 0) {
           if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
           else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
         }
-      };
-      using std::integral_constant;
-      if constexpr (nt < NT - 1) {
-        mf(integral_constant<int, 0>{});
-        if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
-        else lds_request<0>(wa, w_nxt);
-        mf(integral_constant<int, 1>{});
-        if constexpr (a_req) lds_request<a_first * 1024>(nxt[a_first], a_nxt);
-        mf(integral_constant<int, 2>{});
-        if constexpr (dma) piece_setup(integral_constant<int, nt - BG>{}, fill);
-        mf(integral_constant<int, 3>{});
-        if constexpr (dma) piece_go(integral_constant<int, nt - BG>{});
-        mf(integral_constant<int, 4>{});
-        if constexpr (a_req && NPG == 2) lds_request<(a_first + 1) * 1024>(nxt[a_first + 1], a_nxt);
-        mf(integral_constant<int, 5>{});
-        mf(integral_constant<int, 6>{});
-        mf(integral_constant<int, 7>{});
-      } else {
-        // last n-tile: once MFMA mt has issued (its operands are read at issue), cur[mt] is free and takes the next
-        // K-tile's fragment -- two v_mov_b64 per gap.  All but the last-requested activation fragments are older than this
-        // n-tile's weight fragment, which the wait above covered; the last one gets its own counted wait.
-        static_assert(!a_req, "no activation request in the last n-tile");
-        mf(integral_constant<int, 0>{});
-        lds_request<1024>(wb, w_nxt);
-        copy_after_wait(cur[0], nxt[0]);
-        mf(integral_constant<int, 1>{});
-        copy_after_wait(cur[1], nxt[1]);
-        mf(integral_constant<int, 2>{});
-        if constexpr (dma) piece_setup(integral_constant<int, nt - BG>{}, fill);
-        copy_after_wait(cur[2], nxt[2]);
-        mf(integral_constant<int, 3>{});
-        if constexpr (dma) piece_go(integral_constant<int, nt - BG>{});
-        copy_after_wait(cur[3], nxt[3]);
-        mf(integral_constant<int, 4>{});
-        copy_after_wait(cur[4], nxt[4]);
-        mf(integral_constant<int, 5>{});
-        copy_after_wait(cur[5], nxt[5]);
-        if constexpr (dma) stage_advance();
-        mf(integral_constant<int, 6>{});
-        copy_after_wait(cur[6], nxt[6]);
-        mf(integral_constant<int, 7>{});
-        lds_wait_all_but<Sched::younger_copy()>();
-        copy_after_wait(cur[7], nxt[7]);
-      }
+        // the gap behind MFMA mt
+        if constexpr (nt < NT - 1) {
+          if constexpr (mt == 0) {
+            if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
+            else lds_request<0>(wa, w_nxt);
+          }
+          if constexpr (mt == 1 && a_req) lds_request<a_first * 1024>(nxt[a_first], a_nxt);
+          if constexpr (dma) {  // (nested: the piece index is only valid where dma holds)
+            if constexpr (mt == 2) piece_setup(integral_constant<int, nt - BG>{}, fill);
+            if constexpr (mt == 3) piece_go(integral_constant<int, nt - BG>{});
+            if constexpr (mt == 3 && dma_last) stage_advance();
+          }
+          if constexpr (mt == 4 && a_req && NPG == 2) lds_request<(a_first + 1) * 1024>(nxt[a_first + 1], a_nxt);
+        } else {
+          // last n-tile: once MFMA mt has issued (its operands are read at issue), cur[mt] is free and takes the next
+          // K-tile's fragment -- two v_mov_b64 per gap.  All but the last-requested activation fragments are older than this
+          // n-tile's weight fragment, which the wait above covered; the last one gets its own counted wait.
+          if constexpr (mt == 0) lds_request<1024>(wb, w_nxt);
+          if constexpr (dma) {
+            if constexpr (mt == 2) piece_setup(integral_constant<int, nt - BG>{}, fill);
+            if constexpr (mt == 3) piece_go(integral_constant<int, nt - BG>{});
+          }
+          if constexpr (mt == MT - 1) lds_wait_all_but<Sched::younger_copy()>();
+          copy_after_wait(cur[mt], nxt[mt]);
+          if constexpr (mt == 5 && dma_last) stage_advance();
+        }
+      });
     });
   };
 
@@ -1472,11 +1469,15 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   // The last K-tile still issued its cross-tile requests (stale slot, values unused).  To the compiler those registers
   // are dead the moment they are requested, so it would hand them to epilogue temporaries while the LDS data is still
   // in flight -- and the late return would overwrite them.  Drain the LDS queue with every such register as an operand.
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(wa), "+v"(wb), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]),
-                 "+v"(nxt[6]), "+v"(nxt[7])
-               :
-               : "memory");
+  if constexpr (MT == 8) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wa), "+v"(wb), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[MT - 4]), "+v"(nxt[MT - 3]),
+                   "+v"(nxt[MT - 2]), "+v"(nxt[MT - 1])
+                 :
+                 : "memory");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa), "+v"(wb), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+  }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA results land before the epilogue reads them
 #ifdef DN_FAT_STAMPS
   const uint64_t dbg_c2 = __builtin_readcyclecounter();
@@ -1489,30 +1490,41 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_fat_kernel(const DnGemmParam
   }
 #endif
 
-  // ---- epilogue: the wave's 128 x (16 NTW) sub-tile as 2 x ceil(NTW / 4) slabs of 64 x 64 (352: the third carries 48 columns).
+  // ---- epilogue: the wave's (16 MT) x (16 NTW) sub-tile as MT/4 x ceil(NTW / 4) slabs of 64 x 64 (352: the third carries 48 columns).
   // The slab loop is a run-time loop around ONE copy of the epilogue code (inlined per slab, the FiLM epilogue alone made
   // a 58k-instruction kernel); only the accumulator -> LDS copies, which need compile-time register indices, are per slab.
   float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
-  constexpr int NHS = (NTW + 3) / 4;
+  const uint32_t ep_lds = lds_base + (wave * (64 * EP_LD) + frow * EP_LD + fq * 4) * 4;  // this lane's accumulator-fragment slot
+  constexpr int NHS = (NTW + 3) / 4, MHS = MT / 4;
   // (a split-RMSNorm consumer on this tile fetches its row factors in the epilogue: the accumulator file leaves no room
   //  to carry them across the K loop)
 #pragma unroll 1
-  for (int sidx = 0; sidx < 2 * NHS; ++sidx) {
-    static_for<2 * NHS>([&](auto s_c) {
+  for (int sidx = 0; sidx < MHS * NHS; ++sidx) {
+    static_for<MHS * NHS>([&](auto s_c) {
       constexpr int MH = decltype(s_c)::value / NHS, NH = decltype(s_c)::value % NHS;
       constexpr int NTS = NTW - 4 * NH < 4 ? NTW - 4 * NH : 4;  // n-tiles in this slab
       if (sidx == MH * NHS + NH) {
+        if constexpr (WAVES == 8) {  // straight from the AGPRs: no v_accvgpr_read, no VGPR pressure (128 VGPRs here)
+          static_for<4 * NTS>([&](auto i_c) {
+            constexpr int mt = decltype(i_c)::value / NTS, nt = decltype(i_c)::value % NTS;
+            acc_to_lds<(mt * 16 * EP_LD + nt * 16) * 4>(ep_lds, acc[NH * 4 + nt][MH * 4 + mt]);
+          });
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+          for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTS; ++nt)
-            *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[NH * 4 + nt][MH * 4 + mt];
+            for (int nt = 0; nt < NTS; ++nt)
+              *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[NH * 4 + nt][MH * 4 + mt];
+        }
       }
     });
     const int mh = sidx / NHS, nh = sidx - mh * NHS;
     const int nts = NTW - 4 * nh < 4 ? NTW - 4 * nh : 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI>(p, ep, m0 + wm * 128 + mh * 64, n0 + wn * (16 * NTW) + nh * 64, g, lane, nts * 16, -1.f);
+    int m_slab = m0 + wm * RPW + mh * 64, n_slab = n0 + wn * (16 * NTW) + nh * 64;
+    if constexpr (WAVES == 8)  // opaque: keeps the per-row address arithmetic inside the loop (hoisted, it overflows the 128 VGPRs)
+      asm volatile("" : "+s"(m_slab), "+s"(n_slab));
+    wave_epilogue<EPI>(p, ep, m_slab, n_slab, g, lane, nts * 16, -1.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next slab overwrites it
   }
 }
@@ -1581,22 +1593,23 @@ static int launch_row(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
-template <typename E, int EPI, bool TAPS_INNER, int NTW>
+template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES>
 static void launch_fat_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES>), grid, dim3(64 * WAVES), lds, s, p);
 }
 
-// NTW = 11: the 256 x 352 tile (caller guarantees N % 352 == 0, BIAS epilogue); NTW = 8: the 256 x 256 one-wave-per-SIMD tile.
-template <typename E, int EPI, int NTW>
+// NTW = 11: the 256 x 352 tile (caller guarantees N % 352 == 0, BIAS epilogue); NTW = 8: the 256 x 256 tile, with one
+// (WAVES = 4) or two (WAVES = 8) waves per SIMD.
+template <typename E, int EPI, int NTW, int WAVES = 4>
 static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   constexpr int BNF = 32 * NTW;
-  constexpr int ring = 4 * (BNF + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
+  constexpr int ring = 4 * (BNF + 256) * ROWB2, slabs = WAVES * 64 * EP_LD * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + 255) / 256) * ((np + BNF - 1) / BNF), p.groups);
@@ -1614,8 +1627,8 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
            (intptr_t)a.W - (intptr_t)b.W == (intptr_t)t1.W - (intptr_t)t0.W;
   }
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-  if (taps) launch_fat_variant<E, EPI, true, NTW>(p, grid, lds, s);
-  else launch_fat_variant<E, EPI, false, NTW>(p, grid, lds, s);
+  if (taps) launch_fat_variant<E, EPI, true, NTW, WAVES>(p, grid, lds, s);
+  else launch_fat_variant<E, EPI, false, NTW, WAVES>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm (one-wave-per-SIMD tile)");
   return DN_OK;
@@ -1641,6 +1654,7 @@ static int launch(const DnGemmParams& p, hipStream_t s) {
   }
   if constexpr (std::is_same<E, BF16>::value) {
     if (force == 6) return launch_fat<E, EPI, 8>(p, s);
+    if (force == 7) return launch_fat<E, EPI, 8, 8>(p, s);
   }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;

@@ -93,7 +93,7 @@ typedef struct {
   int32_t pad_;        /* profiling / tests only.  bit4: 4-column instead of 8-column bf16 stores (the K-loop ablations that
                           used bits 0..3 are compile-time now: -DDN_GEMM_ABL); 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start; bits 16..19: force a tile variant (tests: 1 = 128x128,
-                          2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0, 6 = 256x256 with one wave per SIMD [bf16]),
+                          2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0, 6 / 7 = hand-scheduled 256x256 with one / two waves per SIMD [bf16]),
                           0 = chosen from the shape; bit 22: let the
                           256x352 tile run the taps of a causal conv innermost in K (fewer fabric re-reads of the
                           activation panel; changes the fp32 summation order, so off unless asked for)          */

@@ -79,12 +79,12 @@ def test_causal_conv_gemm(ops, dtype, cin, cout, k, dil, B, T):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (128, 1056, 1, 1, 1, 515),
                                                 (64, 352, 1, 1, 2, 130), (1408, 1408, 3, 1, 4, 512)])
 def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil, B, T):
     """The same causal conv through each forced tile variant (128x128, 256x128, 256x256, 256x352, and 256x352 with the
-    taps innermost in K = "tile 5"; 6 = the 256x256 one-wave-per-SIMD tile, bf16 only): ragged M, N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term
+    taps innermost in K = "tile 5"; 6 / 7 = the hand-scheduled 256x256 tile with one / two waves per SIMD, bf16 only): ragged M, N a multiple of 352 but not of 128/256, K of 1..3 K-tiles per term
     (pipeline prologue/drain edges), sequence starts inside a tile (T = 100, 130, 300)."""
     ops_, packing, _lib = ops
     code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
@@ -114,7 +114,7 @@ def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil
         assert maxerr(got, O.causal_conv1d(x, w, b, dil)) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 6])
+@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wavenet_block_group_film_gate(ops, dtype, tile):
     """Grouped dilated conv + FiLM + tanh*sigmoid + residual (reference latent_module.py:513-536), through the tile
@@ -158,7 +158,7 @@ def test_wavenet_block_group_film_gate(ops, dtype, tile):
         assert maxerr(got[i], want[i]) < tol, i
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 6])
+@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_geglu_and_resadd_and_posemb(ops, dtype, tile):
     """GEGLU-interleaved Linear (reference :881-903), residual epilogue (:692,704), pos-emb epilogue (:867-868)."""
@@ -253,7 +253,7 @@ def test_rowtile_resadd_with_fused_rmsnorm(ops, dtype, D, K, B, T):
     assert maxerr(xn.float().cpu().view(B, T, Dp)[..., :D], want_n) < tol * max(1.0, want_n.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [1, 3, 4, 6])
+@pytest.mark.parametrize("tile", [1, 3, 4, 6, 7])
 def test_grouped_bias_gemm_every_variant(ops, tile):
     """Groups (the per-block 1x1 convs of a WaveNet stack share one launch): 3 independent [M,128]x[128,352] problems with
     their own weights, biases and outputs, shared activations; every variant incl. the one-wave-per-SIMD tiles."""
@@ -293,7 +293,7 @@ def test_random_shapes_every_variant_bit_identical(ops):
         bias = packing._vec(b, W.shape[1]).to(DEV)
         terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
         outs = {}
-        for tile in (1, 2, 3, 6) + ((4,) if cout % 352 == 0 else ()):
+        for tile in (1, 2, 3, 6, 7) + ((4,) if cout % 352 == 0 else ()):
             out = torch.full((B * T, cout), float("nan"), device=DEV)
             ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=tile)
             outs[tile] = out
@@ -335,7 +335,7 @@ def test_geglu_on_the_352_wide_tile(ops, tile):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("tile", [0, 1, 3, 7])
 @pytest.mark.parametrize("mode", ["adaptive", "adaptive_shared", "learned"])
 @pytest.mark.parametrize("D,K,N2,B,T", [(512, 320, 384, 2, 100), (100, 64, 200, 3, 37)])
 def test_split_rmsnorm_producer_and_consumers(ops, dtype, tile, mode, D, K, N2, B, T):

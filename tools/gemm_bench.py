@@ -28,6 +28,7 @@ def mk(rows, cols):
 
 
 rows = []
+TILE = int(os.environ.get("DN_BENCH_TILE", "0"))  # forced tile variant for every shape (0 = the library's own choice)
 def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
     Kp, Np = packing.padk(K), packing.padk(N)
     a = mk(M, Kp) if groups == 1 else (torch.randn(groups, M, Kp, device=dev) * 0.5).to(dt)
@@ -46,7 +47,7 @@ def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
         kw["gb_half"] = Np
         kw["shift_by_group"] = True
     terms = [(a, w[j], taps - 1 - j) for j in range(taps)]
-    sec = timeit(lambda: ops.conv_gemm(terms, out, T, Np, bias=bias, epilogue=epi, groups=groups, **kw))
+    sec = timeit(lambda: ops.conv_gemm(terms, out, T, Np, bias=bias, epilogue=epi, groups=groups, tile=TILE, **kw))
     flops = 2.0 * M * K * taps * N * groups * (2 if epi == _lib.EPI_GEGLU else 1)
     rows.append((name, count, sec * 1e6, flops / sec / 1e12, count * sec * 1e3))
     print(f"{name:28s} x{count:2d}  {sec*1e6:8.1f} us  {flops/sec/1e12:7.1f} TF/s   {count*sec*1e3:6.3f} ms/step", flush=True)
