@@ -20,10 +20,13 @@ class DiffNormHipError(RuntimeError):
     pass
 
 
+LAYOUT_A_KBLOCKED, LAYOUT_W_KBLOCKED, LAYOUT_OUT_KBLOCKED = 1, 2, 1
+
+
 class GemmTerm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("lda", C.c_int32), ("shift", C.c_int32),
                 ("a_gstride", C.c_int64), ("w_gstride", C.c_int64), ("shift_by_group", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("layout", C.c_int32)]
 
 
 class GemmParams(C.Structure):
@@ -38,7 +41,7 @@ class GemmParams(C.Structure):
                 ("pad_", C.c_int32), ("lengths", C.c_void_p),
                 ("norm_out", C.c_void_p), ("norm_ld", C.c_int32), ("norm_dtype", C.c_int32), ("norm_D", C.c_int32),
                 ("norm_gb_ld", C.c_int32), ("norm_gamma", C.c_void_p), ("norm_gb", C.c_void_p),
-                ("norm_gb_half", C.c_int32), ("pad2_", C.c_int32),
+                ("norm_gb_half", C.c_int32), ("out_layout", C.c_int32),
                 ("norm_split", C.c_int32), ("norm_ssq_ld", C.c_int32), ("norm_ssq", C.c_void_p),
                 ("row_ssq", C.c_void_p), ("row_ssq_ld", C.c_int32), ("row_ssq_parts", C.c_int32),
                 ("row_D", C.c_float), ("row_bias_ld", C.c_int32), ("row_bias", C.c_void_p)]
@@ -76,6 +79,7 @@ class VaeConfig(C.Structure):
 _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 SYMBOLS = {
     "dn_conv_gemm": (C.c_int, [C.POINTER(GemmParams), _vp]),
+    "dn_conv_gemm_kblocked_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "dn_profile_start": (C.c_int, [_i32, _i32]),
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),

@@ -41,15 +41,17 @@ constexpr int kWavenetTensors = 10;
 //   qkv_W [depth][padn(3*hd)][padk(D)]  (rows: to_q ; to_kv)       out_W [depth][padn(D)][padk(hd)]
 //   ffin_W [depth][2*padk(inner)][padk(D)] GEGLU-interleaved        ffin_b [depth][2*padk(inner)]
 //   ffconv_W [depth][3][padn(inner)][padk(inner)]                   ffconv_b [depth][padk(inner)]
+//   ffconv_Wkb: the same weights K-blocked, [depth][3][padk(inner)/32][padn(inner)][32] (bf16; DN_LAYOUT_W_KBLOCKED) -- the
+//               form the 256 x 352 tile stages as whole cache lines; any pointer (unused) in f32 mode
 //   ffout_W [depth][padn(D)][padk(inner)]                           ffout_b [depth][padk(D)]
 //   g1, g2 [depth][D] learned RMSNorm gammas (NULL when time-conditioned)
 //   pred_gamma [D]   pred_W [padn(D)][padk(D)]
 struct TransformerW {
   int dim, depth, heads, dim_head, inner;
-  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W;
+  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W, *ffconv_Wkb;
   const float *ffin_b, *ffconv_b, *ffout_b, *g1, *g2, *pred_gamma;
 };
-constexpr int kTransformerTensors = 12;
+constexpr int kTransformerTensors = 13;
 
 }  // namespace dn
 

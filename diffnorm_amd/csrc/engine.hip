@@ -228,25 +228,34 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     }
     if (!fuse && !split) DN_TRY(standalone_norm(l, 1));
     scaled = split;
+    // CausalConv1d(inner, inner, 3) (:894), set up first: when it runs on the 256 x 352 tile its operands go K-blocked --
+    // the GEGLU projection writes its output that way and the weights come from their K-blocked copy (the tile then stages
+    // 1 KiB pieces of whole cache lines instead of sixteen half-lines: -5 % on this contraction; DN_NO_KBLOCK=1 disables)
+    DnGemmParams pc = gemm_base(dtype, M, ip, ip, T);
+    pc.n_terms = 3;
+    for (int j = 0; j < 3; ++j) {
+      pc.terms[j].A = tb.gg; pc.terms[j].lda = ip; pc.terms[j].shift = 2 - j;
+      pc.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
+    }
+    pc.bias = w.ffconv_b + (size_t)l * ip; pc.out = tb.fc; pc.ldo = ip;
+    pc.pad_ = DN_TAG_FFN_CONV << 8;
+    static const bool no_kblock = getenv("DN_NO_KBLOCK") && atoi(getenv("DN_NO_KBLOCK")) != 0;
+    const bool kblocked = !no_kblock && dtype == DN_BF16 && w.ffconv_Wkb && dn_conv_gemm_kblocked_ok(&pc);
+    if (kblocked)
+      for (int j = 0; j < 3; ++j) {
+        pc.terms[j].W = eoff(w.ffconv_Wkb, ((size_t)l * 3 + j) * in_n * ip, es);
+        pc.terms[j].layout = DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED;
+      }
     {  // Linear(D -> 2*inner) + GEGLU (:899,881-884)
       DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
       p.bias = w.ffin_b + (size_t)l * 2 * ip;
       p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
+      p.out_layout = kblocked ? DN_LAYOUT_OUT_KBLOCKED : 0;
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
-    {  // CausalConv1d(inner, inner, 3) (:894)
-      DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
-      p.n_terms = 3;
-      for (int j = 0; j < 3; ++j) {
-        p.terms[j].A = tb.gg; p.terms[j].lda = ip; p.terms[j].shift = 2 - j;
-        p.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
-      }
-      p.bias = w.ffconv_b + (size_t)l * ip; p.out = tb.fc; p.ldo = ip;
-      p.pad_ = DN_TAG_FFN_CONV << 8;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
+    DN_TRY(dn_conv_gemm(&pc, s));
     {  // Linear(inner -> D) + residual (:902,704) [+ the next layer's attention norm (:691) or to_pred's norm (:677)]
       DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
       p.terms[0].A = tb.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
@@ -279,6 +288,7 @@ const void* const* take_transformer(TransformerW& w, const void* const* t) {
   w.qkv_W = t[0]; w.out_W = t[1]; w.ffin_W = t[2]; w.ffin_b = (const float*)t[3]; w.ffconv_W = t[4];
   w.ffconv_b = (const float*)t[5]; w.ffout_W = t[6]; w.ffout_b = (const float*)t[7];
   w.g1 = (const float*)t[8]; w.g2 = (const float*)t[9]; w.pred_gamma = (const float*)t[10]; w.pred_W = t[11];
+  w.ffconv_Wkb = t[12];
   return t + kTransformerTensors;
 }
 

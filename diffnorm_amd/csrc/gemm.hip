@@ -253,7 +253,8 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
-      store8_bf16(out, (int64_t)m * p.ldo + n, o);
+      // K-blocked output ([N/32][M][32]): the 8 columns stay inside one 32-column block
+      store8_bf16(out, p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n, o);
     }
   } else {
     const int c8 = (lane & 7) * 8;
@@ -342,7 +343,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         gt = make_float4(__fadd_rn(__fmul_rn(gt.x, sm), rg.x), __fadd_rn(__fmul_rn(gt.y, sm), rg.y), __fadd_rn(__fmul_rn(gt.z, sm), rg.z),
                          __fadd_rn(__fmul_rn(gt.w, sm), rg.w));
       }
-      store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
+      store4t<OUT_BF>(out, p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n,
+                      gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
                       gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
     }
   } else {
@@ -1239,22 +1241,32 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
   int a_inc[APW];          // term-outer: 64 or 0 (zero page); tap-inner: the row's frame index m % T
   uint32_t w_voff = 0;
   uint64_t w_base = 0;   // uniform: term weight base + tile's first row (term-outer)
+  uint32_t w_step = ROWB2;  // bytes from a K-tile of the weight to the next: 64 along a row, or a whole [rows][32] block (K-blocked)
+  uint64_t piece_stride = (uint64_t)16 * p.K * ES;  // bytes between weight pieces (16 rows)
+  const int w_rows = (np_total + 127) / 128 * 128;  // rows of the packed weight
   int s_term = 0, s_kk = 0;
   const char* const zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
     const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    // K-blocked operands ([K/32][rows][32], DN_LAYOUT_*): a 16-row piece is 1 KiB of whole cache lines, the next K-tile a block away
+    const bool a_kb = tm.layout & DN_LAYOUT_A_KBLOCKED, w_kb = tm.layout & DN_LAYOUT_W_KBLOCKED;
+    const int64_t a_row = a_kb ? ROWB2 : (int64_t)tm.lda * ES;
+    const int a_step = a_kb ? p.M * ROWB2 : ROWB2;
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
       int m = m0 + (wave * APW + i) * 16 + srow;
       m = m < p.M ? m : p.M - 1;
       const bool valid = (m % p.T) >= shift;
-      a_ptr[i] = valid ? A + (int64_t)(m - shift) * tm.lda * ES : zero_src;
-      a_inc[i] = valid ? ROWB2 : 0;
+      a_ptr[i] = valid ? A + (int64_t)(m - shift) * a_row : zero_src;
+      a_inc[i] = valid ? a_step : 0;
     }
-    w_base = (uint64_t)(uintptr_t)tm.W + ((uint64_t)tm.w_gstride * g + (uint64_t)n0 * p.K) * ES;
-    w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
+    const int w_row = w_kb ? ROWB2 : p.K * ES;
+    w_base = (uint64_t)(uintptr_t)tm.W + (uint64_t)tm.w_gstride * g * ES + (uint64_t)n0 * w_row;
+    w_voff = (uint32_t)(srow * w_row + schunk * 16);
+    w_step = w_kb ? (uint32_t)w_rows * ROWB2 : ROWB2;
+    piece_stride = (uint64_t)16 * w_row;
   };
   // tap-inner: the per-tap uniforms are affine in the tap index (launch_fat checks it: shift_t = shift_0 - t * step,
   // W_t = W_0 + t * stride), so they are carried as running scalars -- no per-tap table (a table indexed by the
@@ -1283,7 +1295,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
-  const uint64_t piece_stride = (uint64_t)16 * p.K * ES;
   // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces.  Two halves (M0 <- LDS address,
   // then the load) so that the K loop can put them into different MFMA gaps; stage_piece = both, back to back.
   auto piece_lds_addr = [&](auto i_c, int slot) -> uint32_t {
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
       } else {
 #pragma unroll
         for (int i = 0; i < APW; ++i) a_ptr[i] += a_inc[i];
-        w_voff += ROWB2;
+        w_voff += w_step;
       }
     }
   };
@@ -1620,6 +1631,7 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   // Needs the taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression.
   static const bool env_taps = getenv("DN_FAT_TAPS_INNER") && atoi(getenv("DN_FAT_TAPS_INNER")) != 0;
   bool taps = p.n_terms >= 2 && p.n_terms <= 4 && (env_taps || ((p.pad_ >> 22) & 1));
+  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == 0;
   for (int i = 1; i < p.n_terms && taps; ++i) {
     const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
     taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&
@@ -1634,24 +1646,38 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
+// Tile variant forced for this call: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests); 0 = choose by shape.
+static int forced_tile(const DnGemmParams& p) {
+  static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
+  return ((p.pad_ >> 16) & 15) ? ((p.pad_ >> 16) & 15) : env_tile;
+}
+
+// Does this contraction run on the 256 x 352 one-wave-per-SIMD tile?  bf16, BIAS or GEGLU, packed columns a multiple of
+// 352 and at least ~half a chip of tiles (a workgroup owns a CU's whole LDS; measured +2.5 % per denoising step on half
+// batches, +5 % on whole ones, against the 256 x 256 tile on the FFN conv).  Chosen by itself only for the long-K BIAS
+// contractions; on the GEGLU projection (K = 512: 16 K-tiles) it measured level with the 256 x 256 tile (67.6 vs 66.1
+// us), so there it runs only when forced.
+static bool routes_to_352(const DnGemmParams& p) {
+  if (p.dtype != DN_BF16 || (p.epilogue != DN_EPI_BIAS && p.epilogue != DN_EPI_GEGLU)) return false;
+  if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split) return false;
+  const int force = forced_tile(p);
+  const int npk = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
+  const long tiles_fat = (long)((p.M + 255) / 256) * (npk / 352) * p.groups;
+  return npk % 352 == 0 && (force == 4 || (force == 0 && p.epilogue == DN_EPI_BIAS && tiles_fat >= 100));
+}
+
 template <typename E, int EPI>
 static int launch(const DnGemmParams& p, hipStream_t s) {
   if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
     if (p.norm_out && !p.norm_split) return launch_row<E, EPI>(p, s);
   }
-  // Tile variant: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests) force one, 0 = choose by shape.
-  static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
-  const int force = ((p.pad_ >> 16) & 15) ? ((p.pad_ >> 16) & 15) : env_tile;
+  const int force = forced_tile(p);
   if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && std::is_same<E, BF16>::value) {
-    // the 256 x 352 one-wave-per-SIMD tile: bf16, packed columns a multiple of 352 and at least ~half a chip of tiles (a
-    // workgroup owns a CU's whole LDS; measured +2.5 % per denoising step on half batches, +5 % on whole ones, against the
-    // 256 x 256 tile on the FFN conv)
-    const int npk = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
-    const long tiles_fat = (long)((p.M + 255) / 256) * (npk / 352) * p.groups;
-    // chosen by itself only for the long-K BIAS contractions; on the GEGLU projection (K = 512: 16 K-tiles) it measured
-    // level with the 256 x 256 tile (67.6 vs 66.1 us), so there it runs only when forced
-    if (npk % 352 == 0 && (force == 4 || (force == 0 && EPI == DN_EPI_BIAS && tiles_fat >= 100))) return launch_fat<E, EPI, 11>(p, s);
+    if (routes_to_352(p)) return launch_fat<E, EPI, 11>(p, s);
   }
+  for (int i = 0; i < p.n_terms; ++i)
+    DN_CHECK_ARG(p.terms[i].layout == 0, "dn_conv_gemm: K-blocked operands (term %d) are taken only by the 256 x 352 tile; "
+                 "this contraction does not run there (dn_conv_gemm_kblocked_ok)", i);
   if constexpr (std::is_same<E, BF16>::value) {
     if (force == 6) return launch_fat<E, EPI, 8>(p, s);
     if (force == 7) return launch_fat<E, EPI, 8, 8>(p, s);
@@ -1700,6 +1726,10 @@ static int dispatch_epi(const DnGemmParams& p, hipStream_t s) {
 
 }  // namespace dn
 
+extern "C" int dn_conv_gemm_kblocked_ok(const DnGemmParams* pp) {
+  return pp && pp->K % 32 == 0 && dn::routes_to_352(*pp) ? 1 : 0;
+}
+
 extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   DN_CHECK_ARG(pp != nullptr, "dn_conv_gemm: null params");
   const DnGemmParams& p = *pp;
@@ -1737,6 +1767,13 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
                  "dn_conv_gemm: bad norm_D=%d / norm_ld=%d", p.norm_D, p.norm_ld);
     DN_CHECK_ARG(!p.norm_gb || (p.norm_gb_ld % 4 == 0 && p.norm_gb_half % 4 == 0), "dn_conv_gemm: norm_gb strides must be multiples of 4");
   }
+  for (int i = 0; i < p.n_terms; ++i)
+    DN_CHECK_ARG((p.terms[i].layout & ~3) == 0 && (p.terms[i].layout == 0 || p.dtype == DN_BF16),
+                 "dn_conv_gemm: term %d layout=%d (K-blocked operands are bf16 only)", i, p.terms[i].layout);
+  if (p.out_layout)
+    DN_CHECK_ARG(p.out_layout == DN_LAYOUT_OUT_KBLOCKED && p.epilogue == DN_EPI_GEGLU && p.out_dtype == DN_BF16 && p.N % 32 == 0 &&
+                     p.groups == 1,
+                 "dn_conv_gemm: K-blocked output needs the GEGLU epilogue, a bf16 destination, one group and N a multiple of 32");
   if (p.row_ssq) {
     DN_CHECK_ARG(p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU,
                  "dn_conv_gemm: row_ssq (split norm) needs a BIAS, SILU or GEGLU epilogue");

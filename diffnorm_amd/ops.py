@@ -33,7 +33,8 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               norm_D: int = 0, norm_gamma: Optional[torch.Tensor] = None, norm_gb: Optional[torch.Tensor] = None,
               norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: bool = False,
               norm_ssq: Optional[torch.Tensor] = None, row_ssq: Optional[torch.Tensor] = None, row_D: int = 0,
-              row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False):
+              row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False, a_kblocked: bool = False,
+              w_kblocked: bool = False, out_kblocked: bool = False):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
@@ -45,12 +46,15 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
     M = A0.shape[-2]
     p.n_terms = len(terms)
     p.dtype = _code(A0)
-    p.M, p.N, p.K, p.T = M, N, W0.shape[-1], T
+    # K-blocked operands (packing.kblock): [K/32, rows, 32]
+    K = W0.shape[-3] * 32 if w_kblocked else W0.shape[-1]
+    p.M, p.N, p.K, p.T = M, N, K, T
     p.groups, p.epilogue = groups, epilogue
     for i, (A, W, shift) in enumerate(terms):
         assert A.is_contiguous() and W.is_contiguous() and A.dtype == W.dtype
         t = p.terms[i]
-        t.A, t.W, t.lda, t.shift = A.data_ptr(), W.data_ptr(), A.shape[-1], shift
+        t.A, t.W, t.lda, t.shift = A.data_ptr(), W.data_ptr(), (K if a_kblocked else A.shape[-1]), shift
+        t.layout = (_lib.LAYOUT_A_KBLOCKED if a_kblocked else 0) | (_lib.LAYOUT_W_KBLOCKED if w_kblocked else 0)
         t.a_gstride = A.shape[-2] * A.shape[-1] if (groups > 1 and a_grouped and A.dim() == 3) else 0
         t.w_gstride = W.shape[-2] * W.shape[-1] if (groups > 1 and W.dim() == 3) else 0
         t.shift_by_group = int(shift_by_group)
@@ -58,7 +62,8 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
         assert bias.dtype == torch.float32
         p.bias = bias.data_ptr()
         p.bias_gstride = bias.shape[-1] if groups > 1 else 0
-    p.out, p.ldo, p.out_dtype = out.data_ptr(), out.shape[-1], _code(out)
+    p.out, p.ldo, p.out_dtype = out.data_ptr(), (N if out_kblocked else out.shape[-1]), _code(out)
+    p.out_layout = _lib.LAYOUT_OUT_KBLOCKED if out_kblocked else 0
     p.out_gstride = out.shape[-2] * out.shape[-1] if groups > 1 else 0
     if res is not None:
         p.res, p.ldr, p.res_dtype = res.data_ptr(), res.shape[-1], _code(res)

@@ -134,6 +134,8 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
         torch.stack(ffc_b), torch.stack(ffo), torch.stack(ffo_b),
         torch.stack(g1) if g1 else dummy, torch.stack(g2) if g2 else dummy.clone(),
         g("to_pred.0.gamma").float().clone(), _mat(g("to_pred.1.weight"), dtype),
+        # the FFN conv weights once more, K-blocked, for the 256 x 352 tile (bf16 only; a placeholder in f32 mode)
+        kblock(torch.stack(ffc)) if dtype == _lib.DN_BF16 else dummy.clone(),
     ]
 
 
@@ -202,3 +204,17 @@ def pack_vae(sd: SD, dim: int, mults: List[int], depth: int, heads: int, dim_hea
     tensors += pack_transformer(tsd, "", dim, depth, heads, dim_head, dtype, conditioned=False)
     tensors += [_mat(sd["decoder_lm.weight"], dtype), _vec(sd["decoder_lm.bias"], padn(vocab))]
     return tensors
+
+
+def kblock(t: torch.Tensor) -> torch.Tensor:
+    """[.., rows, K] -> the K-blocked layout [.., K/32, rows, 32] (include/diffnorm_hip.h, DN_LAYOUT_*): the 64 bytes a
+    32-deep K-tile takes from a row sit next to the neighbouring rows' 64 bytes of the same K-tile."""
+    *lead, rows, K = t.shape
+    assert K % 32 == 0
+    return t.reshape(*lead, rows, K // 32, 32).transpose(-3, -2).contiguous()
+
+
+def unkblock(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of kblock: [.., K/32, rows, 32] -> [.., rows, K]."""
+    *lead, kb, rows, _ = t.shape
+    return t.transpose(-3, -2).reshape(*lead, rows, kb * 32).contiguous()

@@ -59,8 +59,17 @@ typedef struct {
   int64_t a_gstride;  /* elements added to A per group (0 = all groups share A)                     */
   int64_t w_gstride;  /* elements added to W per group                                              */
   int32_t shift_by_group; /* 1: effective shift = shift << group (WaveNet dilation 2^i)             */
-  int32_t pad_;
+  int32_t layout;     /* DN_LAYOUT_* bits; 0 = row-major A and W as described above                 */
 } DnGemmTerm;
+
+/* K-blocked operand layout, bf16 only: [K/32][rows][32] instead of [rows][K] -- the 32 K-elements (64 bytes) a K-tile
+ * takes from each row lie next to the same K-tile's elements of the neighbouring rows, so the 16-row pieces the
+ * contraction stages are 1 KiB of whole cache lines (row-major pieces are sixteen half-lines; measured 2-4x the
+ * L2 -> LDS fill rate, tools/dma_issue_cost.hip) and a causal shift is a plain row offset.  rows = M for A and for
+ * out, Np for W.  The contraction consumes K-blocked A / W only on its 256 x 352 tile (dn_conv_gemm returns
+ * DN_EINVAL when the shape does not route there: ask dn_conv_gemm_kblocked_ok first); the GEGLU epilogue can emit
+ * K-blocked output (out_layout) for such a consumer on every tile.                                              */
+enum { DN_LAYOUT_A_KBLOCKED = 1, DN_LAYOUT_W_KBLOCKED = 2, DN_LAYOUT_OUT_KBLOCKED = 1 };
 
 /* out[g] = epilogue( sum_terms shift(A_term[g]) @ W_term[g]^T ), g = 0..groups-1.
  * Replaces nn.Linear / CausalConv1d(k=1,3) and the ops the reference runs after them
@@ -105,7 +114,8 @@ typedef struct {
   int32_t norm_ld, norm_dtype, norm_D, norm_gb_ld; /* norm_gb_ld: 0 = one conditioning row for the batch */
   const float* norm_gamma; /* learned gamma [norm_D] or NULL                                         */
   const float* norm_gb;    /* adaptive rows [Bc, norm_gb_ld]: gamma at col 0.., beta at norm_gb_half.. or NULL */
-  int32_t norm_gb_half, pad2_;
+  int32_t norm_gb_half;
+  int32_t out_layout;      /* DN_LAYOUT_OUT_KBLOCKED: out is [N/32][M][32] (bf16, GEGLU epilogue, ldo ignored)      */
   /* Split RMSNorm: the norm of a row is divided between the contraction that produces the row and the one that consumes
    * it, so no separate pass over the residual stream remains (x/|x| * sqrt(D) * g + b feeding a Linear W equals
    * (sqrt(D)/|x|) * ((x*g) W^T) + b W^T).
@@ -124,6 +134,9 @@ typedef struct {
 } DnGemmParams;
 
 int dn_conv_gemm(const DnGemmParams* p, void* stream);
+/* 1 when dn_conv_gemm would run this contraction (M, N, K, groups, dtype, epilogue, n_terms are read) on the tile that
+ * takes K-blocked A / W terms, else 0.                                                                            */
+int dn_conv_gemm_kblocked_ok(const DnGemmParams* p);
 
 /* launch tags set by the engine on its dominant contractions */
 enum { DN_TAG_FFN_CONV = 1, DN_TAG_WN_DILATED = 2 };

@@ -46,12 +46,12 @@ def test_struct_layout_matches_header(lib, tmp_path):
     from diffnorm_amd import _lib
 
     probes = {
-        "DnGemmTerm": (_lib.GemmTerm, ["A", "W", "lda", "shift", "a_gstride", "w_gstride", "shift_by_group"]),
+        "DnGemmTerm": (_lib.GemmTerm, ["A", "W", "lda", "shift", "a_gstride", "w_gstride", "shift_by_group", "layout"]),
         "DnGemmParams": (_lib.GemmParams, ["terms", "n_terms", "dtype", "M", "N", "K", "T", "groups", "epilogue", "bias",
                                            "bias_gstride", "out", "ldo", "out_dtype", "out_gstride", "res", "ldr", "res_dtype",
                                            "res_gstride", "gamma_beta", "gb_ld", "gb_half", "gb_gstride", "pos_table", "pos_ld",
                                            "lengths", "norm_out", "norm_ld", "norm_dtype", "norm_D", "norm_gb_ld", "norm_gamma",
-                                           "norm_gb", "norm_gb_half", "norm_split", "norm_ssq_ld", "norm_ssq", "row_ssq",
+                                           "norm_gb", "norm_gb_half", "out_layout", "norm_split", "norm_ssq_ld", "norm_ssq", "row_ssq",
                                            "row_ssq_ld", "row_ssq_parts", "row_D", "row_bias_ld", "row_bias"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
                                            "dtype", "lengths", "scale"]),

@@ -303,6 +303,54 @@ def test_random_shapes_every_variant_bit_identical(ops):
             assert torch.equal(o, outs[1]), (case, tile, k, cin, cout, B, T, dil)
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (1408, 1408, 3, 1, 4, 512),
+                                                (128, 1056, 1, 1, 1, 515)])
+def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
+    """K-blocked activations and/or weights ([K/32][rows][32], DN_LAYOUT_*) through the 256x352 tile: bit-identical to the
+    row-major operands (same K order), causal shifts and ragged M included; tiles that do not take them refuse."""
+    ops_, packing, _lib = ops
+    x = seeded((B, T, cin), 21)
+    w = seeded((cout, cin, k), 22, (1.0 / (cin * k)) ** 0.5)
+    b = seeded((cout,), 23, 0.1)
+    N = (cout + 31) // 32 * 32
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+    W = packing._conv(w, _lib.DN_BF16).to(DEV)
+    bias = packing._vec(b, W.shape[1]).to(DEV)
+    xb, Wb = packing.kblock(xa), packing.kblock(W)
+    assert torch.equal(packing.unkblock(xb), xa)
+    ref = torch.empty((B * T, N), device=DEV)
+    ops_.conv_gemm([(xa, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=4)
+    for a_kb, w_kb in ((True, False), (False, True), (True, True)):
+        out = torch.full((B * T, N), float("nan"), device=DEV)
+        terms = [(xb if a_kb else xa, (Wb if w_kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
+        ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4, a_kblocked=a_kb, w_kblocked=w_kb)
+        assert torch.equal(out, ref), (a_kb, w_kb)
+    with pytest.raises(RuntimeError, match="K-blocked"):
+        ops_.conv_gemm([(xb, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=3, a_kblocked=True)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 4])
+def test_geglu_emits_kblocked_output(ops, tile):
+    """The GEGLU epilogue writing its output K-blocked for a 352-tile consumer: same values, other addresses."""
+    ops_, packing, _lib = ops
+    B, T, D, inner = 3, 100, 128, 700
+    ip = padk(inner)
+    x = seeded((B, T, D), 1)
+    w = seeded((2 * inner, D), 2, D ** -0.5)
+    b = seeded((2 * inner,), 3, 0.2)
+    rows = packing._geglu_rows(inner)
+    keep = rows >= 0
+    wp, bp = torch.zeros(2 * ip, D), torch.zeros(2 * ip)
+    wp[keep], bp[keep] = w[rows[keep]], b[rows[keep]]
+    M = B * T
+    xa = act(x.view(M, D), "bf16")
+    ref = torch.empty((M, ip), device=DEV, dtype=torch.bfloat16)
+    ops_.conv_gemm([(xa, act(wp, "bf16"), 0)], ref, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tile)
+    out = torch.full((ip // 32, M, 32), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops_.conv_gemm([(xa, act(wp, "bf16"), 0)], out, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tile, out_kblocked=True)
+    assert torch.equal(packing.unkblock(out), ref)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4])
 def test_geglu_on_the_352_wide_tile(ops, tile):
     """GEGLU projection whose packed width (2 x padk(inner) = 1408) is a multiple of 352: the one-wave-per-SIMD tile cuts the

@@ -52,9 +52,25 @@ def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
     rows.append((name, count, sec * 1e6, flops / sec / 1e12, count * sec * 1e3))
     print(f"{name:28s} x{count:2d}  {sec*1e6:8.1f} us  {flops/sec/1e12:7.1f} TF/s   {count*sec*1e3:6.3f} ms/step", flush=True)
 
+def ffn_kblocked(a_kb, w_kb):
+    """The FFN causal conv with K-blocked operands ([K/32][rows][32]) on the 256x352 tile."""
+    Kp = packing.padk(1365)
+    a, w = mk(M, Kp), (torch.randn(3, packing.padn(1365), Kp, device=dev) * 0.02).to(dt)
+    ab, wb = packing.kblock(a), packing.kblock(w)
+    out, bias = torch.empty(M, Kp, device=dev, dtype=dt), torch.zeros(packing.padn(1365), device=dev)
+    terms = [(ab if a_kb else a, (wb if w_kb else w)[j], 2 - j) for j in range(3)]
+    sec = timeit(lambda: ops.conv_gemm(terms, out, T, Kp, bias=bias, a_kblocked=a_kb, w_kblocked=w_kb), iters=60)
+    fl = 2.0 * M * 1365 * 3 * 1365
+    print(f"ffn_conv A {'K-blocked' if a_kb else 'row-major'}, W {'K-blocked' if w_kb else 'row-major'}: {sec*1e6:8.1f} us  {fl/sec/1e12:7.1f} TF/s", flush=True)
+
+
 only = sys.argv[2] if len(sys.argv) > 2 else None
 if only == "ffn":
     shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
+    sys.exit(0)
+if only == "kblock":
+    for a_kb, w_kb in ((False, False), (True, False), (False, True), (True, True)) + ((False, False), (True, True)) * 4:
+        ffn_kblocked(a_kb, w_kb)
     sys.exit(0)
 shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
 shape("wn_dilated k3 512 g8", 512, 512, taps=3, groups=8, epi=_lib.EPI_FILM_GATE, count=4)
