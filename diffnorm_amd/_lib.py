@@ -80,6 +80,7 @@ _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_s
 SYMBOLS = {
     "dn_conv_gemm": (C.c_int, [C.POINTER(GemmParams), _vp]),
     "dn_conv_gemm_kblocked_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "dn_conv_gemm_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "dn_profile_start": (C.c_int, [_i32, _i32]),
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),

@@ -30,12 +30,14 @@ struct Arena {  // bump allocator over the caller's workspace; base == nullptr o
 //   res_W  [S][L][padn(cout)][padk(cout)]      res_b  [S][L][padk(cout)]
 //   skip_W [L][padn(cout)][padk(cout)]         skip_b [padk(cout)]  (sum over the L blocks)
 //   final_W [padn(cout)][padk(cout)]           final_b [padk(cout)]
+//   conv_Wkb, res_Wkb: conv_W and res_W once more, K-blocked ([..][padk(cout)/32][padn(cout)][32], bf16; DN_LAYOUT_W_KBLOCKED)
+//                      for the 256 x 256 tile, whose fill path moves whole cache lines; any pointer (unused) in f32 mode
 struct WavenetW {
   int cin, cout, stacks, layers;
-  const void *init_W, *conv_W, *res_W, *skip_W, *final_W;
+  const void *init_W, *conv_W, *res_W, *skip_W, *final_W, *conv_Wkb, *res_Wkb;
   const float *init_b, *conv_b, *res_b, *skip_b, *final_b;
 };
-constexpr int kWavenetTensors = 10;
+constexpr int kWavenetTensors = 12;
 
 // ConditionableTransformer (latent_module.py:642-706).  Packed tensors:
 //   qkv_W [depth][padn(3*hd)][padk(D)]  (rows: to_q ; to_kv)       out_W [depth][padn(D)][padk(hd)]

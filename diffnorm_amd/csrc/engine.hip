@@ -41,6 +41,13 @@ inline bool split_norm_enabled(int Dp) {
   return !(e && atoi(e) != 0) && Dp % 64 == 0 && !fuse_norm_enabled(Dp);
 }
 
+// DN_KBLOCK: unset = K-blocked buffers where the consuming contraction lands on a tile that gains from them, 0 = never,
+// 1 = always (the contraction then runs on a tile that takes them; tests).  Read per call (host side, once per capture).
+int kblock_mode() {
+  const char* e = getenv("DN_KBLOCK");
+  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}
+
 DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
   DnGemmParams p;
   memset(&p, 0, sizeof(p));
@@ -75,6 +82,18 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
   const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.layers, S = w.stacks;
   const size_t mat = (size_t)cn * cp;
   const int64_t plane = (int64_t)M * cp;
+  // The hidden states between the init conv, the res convs and the dilated convs go K-blocked ([cp/32][M][32]) when both of
+  // their consumers run on the 256 x 256 tile (large M): its 16-row staging pieces are then whole cache lines (-10 % on the
+  // dilated conv, -11 % on the res conv at [32,512]).  The last stack's outputs stay row-major for the skip contraction.
+  bool kb = false;
+  if (kblock_mode() != 0 && dtype == DN_BF16 && w.conv_Wkb && w.res_Wkb) {
+    DnGemmParams q = gemm_base(dtype, M, cp, cp, T);
+    q.groups = L;
+    const int t_res = dn_conv_gemm_tile(&q);
+    q.n_terms = 3; q.epilogue = DN_EPI_FILM_GATE;
+    kb = kblock_mode() == 1 || (t_res == 3 && dn_conv_gemm_tile(&q) == 3);
+  }
+  const int a_layout = kb ? (DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED) : 0;
   {  // init conv, k=3, dilation 1 (latent_module.py:596,614 / 1014,1029)
     DnGemmParams p = gemm_base(dtype, M, cp, cinp, T);
     p.n_terms = 3;
@@ -83,6 +102,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
       p.terms[j].W = eoff(w.init_W, (size_t)j * cn * cinp, es);
     }
     p.bias = w.init_b; p.out = wb.hw; p.ldo = cp;
+    p.out_layout = kb ? DN_LAYOUT_OUT_KBLOCKED : 0;
     DN_TRY(dn_conv_gemm(&p, s));
   }
   for (int st = 0; st < S; ++st) {
@@ -93,7 +113,8 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
       DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
       p.groups = L;
       p.terms[0].A = in_s; p.terms[0].lda = cp; p.terms[0].a_gstride = a_gs;
-      p.terms[0].W = eoff(w.res_W, (size_t)st * L * mat, es); p.terms[0].w_gstride = (int64_t)mat;
+      p.terms[0].W = eoff(kb ? w.res_Wkb : w.res_W, (size_t)st * L * mat, es); p.terms[0].w_gstride = (int64_t)mat;
+      p.terms[0].layout = a_layout;
       p.bias = w.res_b + (size_t)st * L * cp; p.bias_gstride = cp;
       p.out = wb.resb; p.ldo = cp; p.out_gstride = plane;
       DN_TRY(dn_conv_gemm(&p, s));
@@ -105,7 +126,8 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
       for (int j = 0; j < 3; ++j) {
         p.terms[j].A = in_s; p.terms[j].lda = cp; p.terms[j].a_gstride = a_gs;
         p.terms[j].shift = 2 - j; p.terms[j].shift_by_group = 1;
-        p.terms[j].W = eoff(w.conv_W, ((size_t)st * L * 3 + j) * mat, es); p.terms[j].w_gstride = (int64_t)(3 * mat);
+        p.terms[j].W = eoff(kb ? w.conv_Wkb : w.conv_W, ((size_t)st * L * 3 + j) * mat, es); p.terms[j].w_gstride = (int64_t)(3 * mat);
+        p.terms[j].layout = a_layout;
       }
       p.bias = w.conv_b + (size_t)st * L * cp; p.bias_gstride = cp;
       p.epilogue = DN_EPI_FILM_GATE;
@@ -114,6 +136,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
         p.gamma_beta = gb + (size_t)st * L * 2 * cp; p.gb_ld = gb_ld; p.gb_half = cp; p.gb_gstride = 2 * cp;
       }
       p.out = out_s; p.ldo = cp; p.out_gstride = plane;
+      p.out_layout = kb && st + 1 < S ? DN_LAYOUT_OUT_KBLOCKED : 0;
       p.pad_ = DN_TAG_WN_DILATED << 8;
       DN_TRY(dn_conv_gemm(&p, s));
     }
@@ -230,7 +253,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     scaled = split;
     // CausalConv1d(inner, inner, 3) (:894), set up first: when it runs on the 256 x 352 tile its operands go K-blocked --
     // the GEGLU projection writes its output that way and the weights come from their K-blocked copy (the tile then stages
-    // 1 KiB pieces of whole cache lines instead of sixteen half-lines: -5 % on this contraction; DN_NO_KBLOCK=1 disables)
+    // 1 KiB pieces of whole cache lines instead of sixteen half-lines: -5 % on this contraction; DN_KBLOCK=0 disables)
     DnGemmParams pc = gemm_base(dtype, M, ip, ip, T);
     pc.n_terms = 3;
     for (int j = 0; j < 3; ++j) {
@@ -239,8 +262,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     }
     pc.bias = w.ffconv_b + (size_t)l * ip; pc.out = tb.fc; pc.ldo = ip;
     pc.pad_ = DN_TAG_FFN_CONV << 8;
-    static const bool no_kblock = getenv("DN_NO_KBLOCK") && atoi(getenv("DN_NO_KBLOCK")) != 0;
-    const bool kblocked = !no_kblock && dtype == DN_BF16 && w.ffconv_Wkb && dn_conv_gemm_kblocked_ok(&pc);
+    const bool kblocked = kblock_mode() != 0 && dtype == DN_BF16 && w.ffconv_Wkb && (kblock_mode() == 1 || dn_conv_gemm_kblocked_ok(&pc));
     if (kblocked)
       for (int j = 0; j < 3; ++j) {
         pc.terms[j].W = eoff(w.ffconv_Wkb, ((size_t)l * 3 + j) * in_n * ip, es);
@@ -281,6 +303,7 @@ const void* const* take_wavenet(WavenetW& w, const void* const* t) {
   w.init_W = t[0]; w.init_b = (const float*)t[1]; w.conv_W = t[2]; w.conv_b = (const float*)t[3];
   w.res_W = t[4]; w.res_b = (const float*)t[5]; w.skip_W = t[6]; w.skip_b = (const float*)t[7];
   w.final_W = t[8]; w.final_b = (const float*)t[9];
+  w.conv_Wkb = t[10]; w.res_Wkb = t[11];
   return t + kWavenetTensors;
 }
 

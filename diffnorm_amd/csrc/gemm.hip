@@ -190,6 +190,12 @@ __device__ __forceinline__ const float* row_bias_of(const DnGemmParams& p, int m
 
 // 8 consecutive bf16 outputs per lane = one 16-byte store: bf16 output stores are issue-bound (a wave-instruction moves
 // 512 B as dwordx2 but 1 KiB as dwordx4), so halving their number halves the store tail of the epilogue.
+// Element offset of output (row m, column n): row-major, or K-blocked [N/32][M][32] for a consumer that stages whole
+// cache lines (DN_LAYOUT_OUT_KBLOCKED; the 4 or 8 columns a lane stores never straddle a 32-column block).
+__device__ __forceinline__ int64_t out_off(const DnGemmParams& p, int m, int n) {
+  return p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n;
+}
+
 __device__ __forceinline__ void store8_bf16(void* base, int64_t off, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
       make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
@@ -254,7 +260,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
       // K-blocked output ([N/32][M][32]): the 8 columns stay inside one 32-column block
-      store8_bf16(out, p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n, o);
+      store8_bf16(out, out_off(p, m, n), o);
     }
   } else {
     const int c8 = (lane & 7) * 8;
@@ -297,7 +303,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
         v[i] += bv[i];
         if constexpr (EPI == DN_EPI_SILU) v[i] = silu(v[i]);
       }
-      store8_bf16(out, (int64_t)m * p.ldo + n, v);
+      store8_bf16(out, out_off(p, m, n), v);
     }
   }
 }
@@ -343,7 +349,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         gt = make_float4(__fadd_rn(__fmul_rn(gt.x, sm), rg.x), __fadd_rn(__fmul_rn(gt.y, sm), rg.y), __fadd_rn(__fmul_rn(gt.z, sm), rg.z),
                          __fadd_rn(__fmul_rn(gt.w, sm), rg.w));
       }
-      store4t<OUT_BF>(out, p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n,
+      store4t<OUT_BF>(out, out_off(p, m, n),
                       gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
                       gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
     }
@@ -450,7 +456,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         } else if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           v0 += rv[i].x; v1 += rv[i].y; v2 += rv[i].z; v3 += rv[i].w;
         }
-        store4t<OUT_BF>(out, (int64_t)m * p.ldo + n, v0, v1, v2, v3);
+        store4t<OUT_BF>(out, out_off(p, m, n), v0, v1, v2, v3);
         if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           if (p.norm_split) {  // split norm, producer side: row * gamma for the consuming contraction + this slab's sum of squares
             float4 ga = split_gamma;
@@ -760,19 +766,24 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
   const char* a_ptr[2];
   const char* w_ptr[2];
-  int a_inc[2];
+  int a_inc[2], w_inc = ROWB2;
   int s_term = 0, s_kk = 0;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
     const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
     const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
+    // K-blocked operands ([K/32][rows][32], DN_LAYOUT_*): rows are 64 bytes apart, K-tiles a whole block apart
+    const bool a_kb = tm.layout & DN_LAYOUT_A_KBLOCKED, w_kb = tm.layout & DN_LAYOUT_W_KBLOCKED;
+    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)tm.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)p.K * ES;
+    const int a_step = a_kb ? p.M * ROWB2 : ROWB2;
+    w_inc = w_kb ? w_rows * ROWB2 : ROWB2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool valid = a_t[i] >= shift;
-      a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * tm.lda * ES : zero_src;
-      a_inc[i] = valid ? ROWB2 : 0;
-      w_ptr[i] = W + (int64_t)w_row[i] * p.K * ES;
+      a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * a_rowb : zero_src;
+      a_inc[i] = valid ? a_step : 0;
+      w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
     }
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         a_ptr[i] += a_inc[i];
-        w_ptr[i] += ROWB2;
+        w_ptr[i] += w_inc;
       }
     }
   };
@@ -1666,47 +1677,56 @@ static bool routes_to_352(const DnGemmParams& p) {
   return npk % 352 == 0 && (force == 4 || (force == 0 && p.epilogue == DN_EPI_BIAS && tiles_fat >= 100));
 }
 
-template <typename E, int EPI>
-static int launch(const DnGemmParams& p, hipStream_t s) {
-  if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
-    if (p.norm_out && !p.norm_split) return launch_row<E, EPI>(p, s);
-  }
+// The tile variant a contraction runs on: 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256, 4 = 256 x 352, 5 = whole-row (fused norm),
+// 6 / 7 = the forced-only hand-scheduled 256 x 256 forms; -1 = K-blocked operands with a tile forced that does not take them.
+static int choose_tile(const DnGemmParams& p) {
+  const bool bf = p.dtype == DN_BF16;
+  if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split) return 5;
   const int force = forced_tile(p);
-  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && std::is_same<E, BF16>::value) {
-    if (routes_to_352(p)) return launch_fat<E, EPI, 11>(p, s);
-  }
-  for (int i = 0; i < p.n_terms; ++i)
-    DN_CHECK_ARG(p.terms[i].layout == 0, "dn_conv_gemm: K-blocked operands (term %d) are taken only by the 256 x 352 tile; "
-                 "this contraction does not run there (dn_conv_gemm_kblocked_ok)", i);
-  if constexpr (std::is_same<E, BF16>::value) {
-    if (force == 6) return launch_fat<E, EPI, 8>(p, s);
-    if (force == 7) return launch_fat<E, EPI, 8, 8>(p, s);
-  }
-  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  if (routes_to_352(p)) return 4;
+  bool kblocked = false;
+  for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
+  if (kblocked) return bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them
+  if (bf && (force == 6 || force == 7)) return force;
+  if (force >= 1 && force <= 3) return force;
+  const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
   const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
   const long tiles_big = mt256 * ((np + 255) / 256) * p.groups;
   const long tiles_mid = mt256 * ((np + BN - 1) / BN) * p.groups;
   const long tiles_small = mt128 * ((np + BN - 1) / BN) * p.groups;
-  if (force == 3) return launch_big<E, EPI>(p, s);
-  if (force == 2) return launch_tile<E, EPI, 256, 3>(p, s);
-  if (force == 1) return launch_tile<E, EPI, 128, 2>(p, s);
   // Choose by how evenly the tiles fill the 256 CUs: score = (throughput of the variant on a full chip, relative)
   // x (rounds / ceil(rounds)), rounds = tiles / (CUs x workgroups that share a CU).  The 256 x 256 and 256 x 128
   // rings own a CU's LDS (one workgroup per CU); two 128 x 128 workgroups share one and cover each other's
   // prologue and epilogue, which is what the short-K contractions (K = 512: 8 K-tiles) are made of.
   static const int heur = getenv("DN_GEMM_HEUR") ? atoi(getenv("DN_GEMM_HEUR")) : 1;
-  if (heur == 0) {  // previous rule, kept for A/B timing
-    if (tiles_big >= 360) return launch_big<E, EPI>(p, s);
-    if (tiles_mid >= 192) return launch_tile<E, EPI, 256, 3>(p, s);
-    return launch_tile<E, EPI, 128, 2>(p, s);
-  }
+  if (heur == 0)  // previous rule, kept for A/B timing
+    return tiles_big >= 360 ? 3 : tiles_mid >= 192 ? 2 : 1;
   auto fill = [](long tiles, int per_cu) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
   };
   const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = 0.92 * fill(tiles_small, 2);
-  if (s_big >= s_mid && s_big >= s_small) return launch_big<E, EPI>(p, s);
-  if (s_mid > s_small) return launch_tile<E, EPI, 256, 3>(p, s);
+  if (s_big >= s_mid && s_big >= s_small) return 3;
+  return s_mid > s_small ? 2 : 1;
+}
+
+template <typename E, int EPI>
+static int launch(const DnGemmParams& p, hipStream_t s) {
+  const int tile = choose_tile(p);
+  DN_CHECK_ARG(tile > 0, "dn_conv_gemm: K-blocked operands are taken by the 256 x 352 and 256 x 256 tiles only (bf16; forced tile %d)",
+               forced_tile(p));
+  if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
+    if (tile == 5) return launch_row<E, EPI>(p, s);
+  }
+  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && std::is_same<E, BF16>::value) {
+    if (tile == 4) return launch_fat<E, EPI, 11>(p, s);
+  }
+  if constexpr (std::is_same<E, BF16>::value) {
+    if (tile == 6) return launch_fat<E, EPI, 8>(p, s);
+    if (tile == 7) return launch_fat<E, EPI, 8, 8>(p, s);
+  }
+  if (tile == 3) return launch_big<E, EPI>(p, s);
+  if (tile == 2) return launch_tile<E, EPI, 256, 3>(p, s);
   return launch_tile<E, EPI, 128, 2>(p, s);
 }
 
@@ -1729,6 +1749,8 @@ static int dispatch_epi(const DnGemmParams& p, hipStream_t s) {
 extern "C" int dn_conv_gemm_kblocked_ok(const DnGemmParams* pp) {
   return pp && pp->K % 32 == 0 && dn::routes_to_352(*pp) ? 1 : 0;
 }
+
+extern "C" int dn_conv_gemm_tile(const DnGemmParams* pp) { return pp ? dn::choose_tile(*pp) : -1; }
 
 extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   DN_CHECK_ARG(pp != nullptr, "dn_conv_gemm: null params");
@@ -1771,9 +1793,9 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
     DN_CHECK_ARG((p.terms[i].layout & ~3) == 0 && (p.terms[i].layout == 0 || p.dtype == DN_BF16),
                  "dn_conv_gemm: term %d layout=%d (K-blocked operands are bf16 only)", i, p.terms[i].layout);
   if (p.out_layout)
-    DN_CHECK_ARG(p.out_layout == DN_LAYOUT_OUT_KBLOCKED && p.epilogue == DN_EPI_GEGLU && p.out_dtype == DN_BF16 && p.N % 32 == 0 &&
-                     p.groups == 1,
-                 "dn_conv_gemm: K-blocked output needs the GEGLU epilogue, a bf16 destination, one group and N a multiple of 32");
+    DN_CHECK_ARG(p.out_layout == DN_LAYOUT_OUT_KBLOCKED && p.out_dtype == DN_BF16 && p.N % 32 == 0 && !p.norm_out &&
+                     (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU || p.epilogue == DN_EPI_FILM_GATE),
+                 "dn_conv_gemm: K-blocked output needs a BIAS, SILU, GEGLU or FILM_GATE epilogue, a bf16 destination and N a multiple of 32");
   if (p.row_ssq) {
     DN_CHECK_ARG(p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU,
                  "dn_conv_gemm: row_ssq (split norm) needs a BIAS, SILU or GEGLU epilogue");

@@ -64,7 +64,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
         p.bias_gstride = bias.shape[-1] if groups > 1 else 0
     p.out, p.ldo, p.out_dtype = out.data_ptr(), (N if out_kblocked else out.shape[-1]), _code(out)
     p.out_layout = _lib.LAYOUT_OUT_KBLOCKED if out_kblocked else 0
-    p.out_gstride = out.shape[-2] * out.shape[-1] if groups > 1 else 0
+    p.out_gstride = (M * N if out_kblocked else out.shape[-2] * out.shape[-1]) if groups > 1 else 0
     if res is not None:
         p.res, p.ldr, p.res_dtype = res.data_ptr(), res.shape[-1], _code(res)
         p.res_gstride = res.shape[-2] * res.shape[-1] if groups > 1 else 0

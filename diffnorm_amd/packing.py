@@ -87,6 +87,9 @@ def pack_wavenet(sd: SD, prefix: str, cin: int, cout: int, stacks: int, layers: 
         torch.stack(conv_W), torch.stack(conv_b), torch.stack(res_W), torch.stack(res_b),
         skip_W, skip_b,
         _mat(g("final_conv.weight")[:, :, 0], dtype), _vec(g("final_conv.bias"), cp),
+        # conv_W and res_W once more, K-blocked, for the 256 x 256 tile (bf16 only; placeholders in f32 mode)
+        kblock(torch.stack(conv_W)) if dtype == _lib.DN_BF16 else torch.zeros(4),
+        kblock(torch.stack(res_W)) if dtype == _lib.DN_BF16 else torch.zeros(4),
     ]
 
 

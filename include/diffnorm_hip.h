@@ -66,9 +66,10 @@ typedef struct {
  * takes from each row lie next to the same K-tile's elements of the neighbouring rows, so the 16-row pieces the
  * contraction stages are 1 KiB of whole cache lines (row-major pieces are sixteen half-lines; measured 2-4x the
  * L2 -> LDS fill rate, tools/dma_issue_cost.hip) and a causal shift is a plain row offset.  rows = M for A and for
- * out, Np for W.  The contraction consumes K-blocked A / W only on its 256 x 352 tile (dn_conv_gemm returns
- * DN_EINVAL when the shape does not route there: ask dn_conv_gemm_kblocked_ok first); the GEGLU epilogue can emit
- * K-blocked output (out_layout) for such a consumer on every tile.                                              */
+ * out, Np for W.  K-blocked A / W are taken by the 256 x 352 tile and, where the shape does not route there, by the
+ * 256 x 256 tile (the contraction then runs on that tile whatever the shape heuristic would have chosen; forcing
+ * another tile is DN_EINVAL); dn_conv_gemm_kblocked_ok tells whether the shape routes to the 256 x 352 tile, where the
+ * layout pays.  The GEGLU epilogue can emit K-blocked output (out_layout) on every tile.                          */
 enum { DN_LAYOUT_A_KBLOCKED = 1, DN_LAYOUT_W_KBLOCKED = 2, DN_LAYOUT_OUT_KBLOCKED = 1 };
 
 /* out[g] = epilogue( sum_terms shift(A_term[g]) @ W_term[g]^T ), g = 0..groups-1.
@@ -137,6 +138,10 @@ int dn_conv_gemm(const DnGemmParams* p, void* stream);
 /* 1 when dn_conv_gemm would run this contraction (M, N, K, groups, dtype, epilogue, n_terms are read) on the tile that
  * takes K-blocked A / W terms, else 0.                                                                            */
 int dn_conv_gemm_kblocked_ok(const DnGemmParams* p);
+/* The tile variant dn_conv_gemm would run this contraction on (1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x352,
+ * 5 = whole-row fused norm, 6 / 7 forced-only forms; -1 = K-blocked operands with an unsuitable tile forced): lets a
+ * caller lay its buffers out K-blocked only where the contraction lands on a tile that gains from it.              */
+int dn_conv_gemm_tile(const DnGemmParams* p);
 
 /* launch tags set by the engine on its dominant contractions */
 enum { DN_TAG_FFN_CONV = 1, DN_TAG_WN_DILATED = 2 };

@@ -80,6 +80,37 @@ def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
         assert ((got - base)[mask] ** 2).mean().item() < 1e-3
 
 
+def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
+    """DN_KBLOCK=1 lays the WaveNet hidden states and the FFN conv's operands out K-blocked at every size (by default only
+    where the consuming contraction lands on a tile that gains from whole-cache-line staging pieces, i.e. large batches)
+    and runs those contractions on the tile that takes them: same K order, so the same bits as row-major buffers -- for
+    the eps-predictor (tiny and BASELINE config 2 shapes) and for both VAE ends."""
+    engine, _ = eng
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DN_KBLOCK", mode)
+        g = golden("eps_tiny")
+        e = engine.EpsEngine(O.make_eps_state_dict(TINY_EPS, "tiny"), TINY_EPS, dtype="bf16", device=DEV)
+        a = e.forward(T_(g["x"]).to(DEV), T_(g["t"]), T_(g["lens"]), shared_t=False).cpu()
+        g2 = golden("eps_full_cfg2")
+        e2 = engine.EpsEngine(O.make_eps_state_dict(FULL_EPS, "full"), FULL_EPS, dtype="bf16", device=DEV)
+        b = e2.forward(seeded((8, 256, 128), 0).to(DEV), T_(g2["t"]), T_(g2["lens"]), shared_t=True).cpu()
+        del e2
+        ve = engine.VaeEngine(O.make_vae_state_dict(CHAIN_VAE, "chain"), dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim,
+                              dtype="bf16", device=DEV)
+        feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+        lens = torch.tensor([48, 20, 33])
+        params = ve.encode_params(feat.to(DEV))
+        recon, logits, _ = ve.decode(ve.sample_posterior(params, seeded((3, 48, CHAIN_VAE.z), 5)), lens)
+        outs[mode] = (a, b, params.cpu(), recon.cpu(), logits.cpu())
+    monkeypatch.delenv("DN_KBLOCK")
+    for x, y in zip(outs["0"], outs["1"]):
+        assert torch.equal(x, y)
+    g2 = golden("eps_full_cfg2")
+    mask = O.lengths_to_mask(T_(g2["lens"]), 256)
+    assert ((outs["1"][1] - T_(g2["eps"]))[mask] ** 2).mean().item() < 1e-4
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_eps_properties(eng, dtype):
     """Reference properties: valid frames are invariant to the content of right-padded frames,

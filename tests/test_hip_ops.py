@@ -325,8 +325,11 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
         terms = [(xb if a_kb else xa, (Wb if w_kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
         ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4, a_kblocked=a_kb, w_kblocked=w_kb)
         assert torch.equal(out, ref), (a_kb, w_kb)
+    out = torch.full((B * T, N), float("nan"), device=DEV)  # the 256x256 tile takes them too
+    ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], out, T, N, bias=bias, tile=3, a_kblocked=True, w_kblocked=True)
+    assert torch.equal(out, ref)
     with pytest.raises(RuntimeError, match="K-blocked"):
-        ops_.conv_gemm([(xb, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=3, a_kblocked=True)
+        ops_.conv_gemm([(xb, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=1, a_kblocked=True)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 3, 4])
@@ -349,6 +352,25 @@ def test_geglu_emits_kblocked_output(ops, tile):
     out = torch.full((ip // 32, M, 32), float("nan"), device=DEV, dtype=torch.bfloat16)
     ops_.conv_gemm([(xa, act(wp, "bf16"), 0)], out, T, ip, bias=bp.to(DEV), epilogue=_lib.EPI_GEGLU, tile=tile, out_kblocked=True)
     assert torch.equal(packing.unkblock(out), ref)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_bias_and_film_epilogues_emit_kblocked_output(ops, tile):
+    """K-blocked output from the BIAS and the FiLM-gate epilogues (the WaveNet hidden states), grouped: same values as row-major."""
+    ops_, packing, _lib = ops
+    L, B, T, D = 3, 2, 150, 128
+    M = B * T
+    xa = act(seeded((M, D), 1), "bf16")
+    W = act(seeded((L, 128, D), 2, D ** -0.5), "bf16")
+    bias = seeded((L, 128), 3, 0.1).to(DEV)
+    res = act(seeded((L, M, D), 4), "bf16")
+    gb = seeded((B, L, 2 * D), 5).to(DEV)
+    for epi, kw in ((_lib.EPI_BIAS, {}), (_lib.EPI_FILM_GATE, dict(res=res, gamma_beta=gb, gb_half=D))):
+        ref = torch.empty((L, M, D), device=DEV, dtype=torch.bfloat16)
+        ops_.conv_gemm([(xa, W, 1)], ref, T, D, bias=bias, epilogue=epi, groups=L, a_grouped=False, tile=tile, **kw)
+        out = torch.full((L, D // 32, M, 32), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops_.conv_gemm([(xa, W, 1)], out, T, D, bias=bias, epilogue=epi, groups=L, a_grouped=False, tile=tile, out_kblocked=True, **kw)
+        assert torch.equal(packing.unkblock(out), ref)
 
 
 @pytest.mark.parametrize("tile", [0, 3, 4])

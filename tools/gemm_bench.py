@@ -29,7 +29,7 @@ def mk(rows, cols):
 
 rows = []
 TILE = int(os.environ.get("DN_BENCH_TILE", "0"))  # forced tile variant for every shape (0 = the library's own choice)
-def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
+def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1, kb=False):
     Kp, Np = packing.padk(K), packing.padk(N)
     a = mk(M, Kp) if groups == 1 else (torch.randn(groups, M, Kp, device=dev) * 0.5).to(dt)
     nrows = packing.padn(N) if epi != _lib.EPI_GEGLU else 2 * Np
@@ -46,6 +46,9 @@ def shape(name, K, N, taps=1, groups=1, epi=_lib.EPI_BIAS, count=1):
         kw["gb_shared"] = True
         kw["gb_half"] = Np
         kw["shift_by_group"] = True
+    if kb:  # K-blocked operands ([K/32][rows][32])
+        a, w = packing.kblock(a), [packing.kblock(x) for x in w]
+        kw.update(a_kblocked=True, w_kblocked=True)
     terms = [(a, w[j], taps - 1 - j) for j in range(taps)]
     sec = timeit(lambda: ops.conv_gemm(terms, out, T, Np, bias=bias, epilogue=epi, groups=groups, tile=TILE, **kw))
     flops = 2.0 * M * K * taps * N * groups * (2 if epi == _lib.EPI_GEGLU else 1)
@@ -67,6 +70,16 @@ def ffn_kblocked(a_kb, w_kb):
 only = sys.argv[2] if len(sys.argv) > 2 else None
 if only == "ffn":
     shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
+    sys.exit(0)
+if only == "kblock256":  # the 256 x 256 tile's shapes, row-major vs K-blocked, alternating
+    TILE = 3
+    for rep_ in range(3):
+        for kb in (False, True):
+            print("K-blocked" if kb else "row-major", flush=True)
+            shape("wn_dilated k3 512 g8", 512, 512, taps=3, groups=8, epi=_lib.EPI_FILM_GATE, count=4, kb=kb)
+            shape("wn_res 1x1 512 g8", 512, 512, groups=8, count=4, kb=kb)
+            shape("ffn_in GEGLU 512->2x1365", 512, 1365, epi=_lib.EPI_GEGLU, count=12, kb=kb)
+            shape("qkv 512->1536", 512, 1536, count=12, kb=kb)
     sys.exit(0)
 if only == "kblock":
     for a_kb, w_kb in ((False, False), (True, False), (False, True), (True, True)) + ((False, False), (True, True)) * 4:
