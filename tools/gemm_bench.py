@@ -68,7 +68,10 @@ def ffn_kblocked(a_kb, w_kb):
 
 
 only = sys.argv[2] if len(sys.argv) > 2 else None
-if only == "ffn":
+if only == "ffn":  # as the engine runs it at this size: K-blocked operands on the 256x352 tile (PMC passes use this)
+    ffn_kblocked(True, True)
+    sys.exit(0)
+if only == "ffn_rowmajor":
     shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
     sys.exit(0)
 if only == "kblock256":  # the 256 x 256 tile's shapes, row-major vs K-blocked, alternating
