@@ -47,6 +47,11 @@ class GemmParams(C.Structure):
                 ("row_D", C.c_float), ("row_bias_ld", C.c_int32), ("row_bias", C.c_void_p)]
 
 
+class AdamParams(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int32), ("pad_", C.c_int32)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
@@ -81,6 +86,8 @@ SYMBOLS = {
     "dn_conv_gemm": (C.c_int, [C.POINTER(GemmParams), _vp]),
     "dn_conv_gemm_kblocked_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "dn_conv_gemm_tile": (C.c_int, [C.POINTER(GemmParams)]),
+    "dn_grad_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int32, _vp]),
+    "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamParams), _vp, _vp, _vp]),
     "dn_profile_start": (C.c_int, [_i32, _i32]),
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),

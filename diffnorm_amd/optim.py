@@ -1,0 +1,89 @@
+"""Optimizer step of the reference's training recipe on the HIP path (first piece): fairseq's Adam
+(fairseq/optim/adam.py:97-239), gradient clipping by global norm (fairseq/utils.py:347-397) and the inverse_sqrt schedule
+(fairseq/optim/lr_scheduler/inverse_square_root_schedule.py:31-85) -- scripts/diffusion/train.sh:29-31.  Parameters, gradients
+and both moments live in flat fp32 device buffers (one launch each for the norm and the update, no host round trip between
+them); the backward kernels that would fill the gradient buffer are not part of this round.
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _flat_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a flat contiguous fp32 CUDA tensor")
+    return t
+
+
+class InverseSquareRootSchedule:
+    """fairseq's `inverse_sqrt` (same arguments and `step_update` contract): linear warm-up from warmup_init_lr to lr over
+    warmup_updates, then lr * sqrt(warmup_updates / num_updates)."""
+
+    def __init__(self, lr: float, warmup_updates: int, warmup_init_lr: float = -1.0):
+        if warmup_init_lr < 0:
+            warmup_init_lr = 0 if warmup_updates > 0 else lr
+        self.warmup_updates, self.warmup_init_lr = warmup_updates, warmup_init_lr
+        self.lr_step = (lr - warmup_init_lr) / warmup_updates
+        self.decay_factor = lr * warmup_updates ** 0.5
+        self.lr = warmup_init_lr
+
+    def step_update(self, num_updates: int) -> float:
+        if num_updates < self.warmup_updates:
+            self.lr = self.warmup_init_lr + num_updates * self.lr_step
+        else:
+            self.lr = self.decay_factor * num_updates ** -0.5
+        return self.lr
+
+
+class Adam:
+    """fairseq.optim.adam.Adam over one flat fp32 parameter buffer (updated in place), with --clip-norm folded in.
+
+    step(grad) = clip_grad_norm_(params, clip_norm) followed by optimizer.step(): returns the gradient norm (a device
+    scalar, like the reference) without synchronising.  `bf16_copy` (same length, bf16) receives the updated parameters in
+    the operand type of the forward kernels."""
+
+    def __init__(self, params: torch.Tensor, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, clip_norm: float = 0.0, bf16_copy: Optional[torch.Tensor] = None):
+        self.params = _flat_f32(params, "params")
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.step_count = 0
+        self.bf16_copy = bf16_copy
+        if bf16_copy is not None and not (bf16_copy.is_cuda and bf16_copy.dtype == torch.bfloat16 and bf16_copy.numel() == params.numel()):
+            raise ValueError("bf16_copy: expected a bf16 CUDA tensor of the parameters' length")
+        self._scratch = torch.empty(1024 + 1, device=params.device, dtype=torch.float32)  # partial sums + the sum of squares
+
+    def set_lr(self, lr: float):
+        self.lr = lr
+
+    def get_lr(self) -> float:
+        return self.lr
+
+    def grad_sumsq(self, grad: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+        """Sum of squares of a gradient buffer into the optimizer's norm slot (accumulate=True adds a further buffer)."""
+        lib = _lib.load()
+        g = _flat_f32(grad, "grad")
+        _lib.check(lib.dn_grad_sumsq(g.data_ptr(), g.numel(), self._scratch.data_ptr(), self._scratch[1024:].data_ptr(),
+                                     int(accumulate), _stream()), "dn_grad_sumsq")
+        return self._scratch[1024:]
+
+    def step(self, grad: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        g = _flat_f32(grad, "grad")
+        if g.numel() != self.params.numel():
+            raise ValueError("grad and params differ in length")
+        sumsq = self.grad_sumsq(g)
+        self.step_count += 1
+        hp = _lib.AdamParams(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
+                             max_norm=self.clip_norm, step=self.step_count)
+        _lib.check(lib.dn_adam_step(self.params.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                    g.numel(), C.byref(hp), sumsq.data_ptr(), _lib.ptr(self.bf16_copy), _stream()), "dn_adam_step")
+        return sumsq.sqrt()[0]

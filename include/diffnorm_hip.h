@@ -230,6 +230,30 @@ int dn_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
 int dn_convert_rows(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype,
                     int32_t ldd, int32_t M, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------ optimizer step */
+/* The update of the reference's training recipe (scripts/diffusion/train.sh:29-31: Adam, betas (0.9, 0.98),
+ * --clip-norm 2.0, inverse_sqrt schedule) over flat fp32 buffers; the schedule itself is host arithmetic
+ * (diffnorm_amd/optim.py).  Backward kernels are not part of this round.                                      */
+
+/* sumsq[0] (+)= sum_i grad[i]^2: the square of fairseq.utils.clip_grad_norm_'s total_norm (fairseq/utils.py:347-390;
+ * call once per gradient buffer with accumulate != 0 after the first).  scratch: 1024 floats.  Two launches, fixed
+ * summation order (bit-reproducible).                                                                          */
+int dn_grad_sumsq(const float* grad, int64_t n, float* scratch, float* sumsq, int32_t accumulate, void* stream);
+
+typedef struct {
+  double lr, beta1, beta2, eps, weight_decay; /* doubles, as the reference's Python floats: 1 - beta and the step size
+                                                 are formed in double and rounded to fp32 once                  */
+  double max_norm;  /* --clip-norm; <= 0 or sumsq == NULL: no clipping                                          */
+  int32_t step;     /* 1 for the first update (fairseq/optim/adam.py:212)                                       */
+  int32_t pad_;
+} DnAdamParams;
+
+/* One fairseq Adam update (fairseq/optim/adam.py:159-239) of n fp32 parameters in place, with the gradient scaled by
+ * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) first (fairseq/utils.py:392-396; the gradient buffer itself is left
+ * unscaled); param_bf16 != NULL also receives the updated parameters in bf16 (the forward kernels' operand type). */
+int dn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const DnAdamParams* hp,
+                 const float* sumsq, void* param_bf16, void* stream);
+
 /* ------------------------------------------------------------------ whole-path engine ---------- */
 
 typedef struct {

@@ -144,3 +144,48 @@ def load_reference_dataset():
     ds = _load("fairseq.data.audio.repr_to_repr_unit_dataset", "fairseq/data/audio/repr_to_repr_unit_dataset.py")
     _CACHE["ds"], _CACHE["dict"] = ds, fd.Dictionary
     return ds, fd.Dictionary
+
+
+def load_reference_optim():
+    """Returns the reference's (Adam class, clip_grad_norm_, InverseSquareRootSchedule class) -- fairseq/optim/adam.py:97-239,
+    fairseq/utils.py:347-397, fairseq/optim/lr_scheduler/inverse_square_root_schedule.py:31-85.  The registry /
+    dataclass / omegaconf plumbing those files import is not on the path and is replaced by inert stand-ins; the optimizer
+    arithmetic, the clipping and the schedule run as they lie."""
+    if "optim" in _CACHE:
+        return _CACHE["optim"]
+    load_reference()
+    import dataclasses
+
+    def stub(modname, **names):
+        m = types.ModuleType(modname)
+        m.__path__ = []
+        for k, v in names.items():
+            setattr(m, k, v)
+        sys.modules[modname] = m
+        return m
+
+    if "omegaconf" not in sys.modules:
+        stub("omegaconf", II=lambda key: None, OmegaConf=type("OmegaConf", (), {}))
+
+    @dataclasses.dataclass
+    class FairseqDataclass:
+        pass
+
+    passthrough = lambda *a, **k: (lambda cls: cls)
+    stub("fairseq.dataclass", FairseqDataclass=FairseqDataclass)
+    stub("fairseq.optim", FairseqOptimizer=type("FairseqOptimizer", (), {}), register_optimizer=passthrough)
+    stub("fairseq.optim.fused_adam", get_fused_adam_class=lambda: None)
+
+    class FairseqLRScheduler:  # the base class's state only (fairseq/optim/lr_scheduler/fairseq_lr_scheduler.py)
+        def __init__(self, cfg, optimizer):
+            self.cfg, self.optimizer, self.best = cfg, optimizer, None
+
+        def step(self, epoch, val_loss=None):
+            pass
+
+    stub("fairseq.optim.lr_scheduler", FairseqLRScheduler=FairseqLRScheduler, register_lr_scheduler=passthrough)
+    adam = _load("fairseq.optim.adam", "fairseq/optim/adam.py")
+    sched = _load("fairseq.optim.lr_scheduler.inverse_square_root_schedule",
+                  "fairseq/optim/lr_scheduler/inverse_square_root_schedule.py")
+    _CACHE["optim"] = (adam.Adam, sys.modules["fairseq.utils"].clip_grad_norm_, sched.InverseSquareRootSchedule)
+    return _CACHE["optim"]
