@@ -83,6 +83,18 @@ def traffic_from_profiles():
         return None
 
 
+def step_traffic_from_profiles():
+    """Fabric-side bytes of one denoising step at [32,512] bf16 from the committed PMC passes (profiles/*pmc_step_traffic*.json,
+    tools/collect_step_traffic.sh); None when absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_traffic*.json")))
+    try:
+        return json.load(open(files[-1]))["bytes_per_step"] if files else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores(cap):
     """Threads the CPU leg may use: affinity mask, cgroup CPU quota, and the per-GPU host share (`cap`)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -245,6 +257,13 @@ def main():
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "launches_timed": n_l.value,
                          "avg_launch_ms_isolated_back_to_back": ksec_iso * 1e3, "traffic": traffic_from_profiles()},
         }
+        # BASELINE config 2 asks for an HBM rate beside steps/s: the measured fabric-side bytes of one step (PMC, committed under
+        # profiles/; an upper bound on HBM bytes, Infinity-Cache hits included) x the measured step rate.  Only for the shape and
+        # dtype the passes were collected on.
+        sb = step_traffic_from_profiles()
+        if sb is not None and (B, T, args.dtype) == (32, 512, "bf16"):
+            result["hbm_bytes_per_step"] = sb
+            result["hbm_gbps_per_gpu"] = sb * K / dt / 1e9
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B), args.cpu_threads)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
