@@ -476,6 +476,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
 template <int EPI>
 __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
                                               int ncols = 64, float row_scale = -1.f) {
+  if constexpr ((DN_GEMM_ABL & 16) != 0) return;  // diagnostic build: no epilogue (LDS reads, math and stores skipped)
   const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)

@@ -9,6 +9,12 @@
 #include <stdlib.h>
 #include <vector>
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+// the same 16 bytes per lane into VGPRs instead of LDS (register staging: the data would then go to LDS with ds_write_b128)
+__device__ __forceinline__ void vload16(const void* src, u32x4_t& dst) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+
 __device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
 }
@@ -28,22 +34,38 @@ __global__ __launch_bounds__(256) void dma_cost(const char* buf, int64_t row_str
   const int64_t piece_stride = rows * row_stride;
   const uint32_t lds = (uint32_t)(uintptr_t)smem + wave * 8192;
   uint64_t issue = 0, total = 0;
+  uint32_t sink = 0;
+  const bool vsink = iters < 0;  // never: keeps the loaded registers alive without costing the loop anything
   if (wave < active_waves) {
     int pc = 0;
     for (int it = 0; it < iters; ++it) {
       // mode 1: 16 x 64 B pieces that read the two halves of each 128 B line in consecutive batches (consecutive K-tiles)
       const char* p = p0 + pc * piece_stride + (mode == 1 ? (it & 1) * 64 : 0);
       const uint64_t c0 = __builtin_readcyclecounter();
+      uint64_t c1;
+      if (mode == 3) {
+        u32x4_t r[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma16(p + i * piece_stride, lds + i * 1024);
-      const uint64_t c1 = __builtin_readcyclecounter();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = 0; i < 8; ++i) vload16(p + i * piece_stride, r[i]);
+        c1 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : : "memory");
+        if (vsink) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sink ^= r[i][0];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16(p + i * piece_stride, lds + i * 1024);
+        c1 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const uint64_t c2 = __builtin_readcyclecounter();
       if (it >= 4) { issue += c1 - c0; total += c2 - c0; }
       if (mode != 1 || (it & 1)) pc += 8;
       if (pc + 8 > pieces_per_region) pc = 0;
     }
   }
+  if (sink == 0x12345678u) out[0] = sink;
   if (lane == 0) {
     out[(blockIdx.x * 4 + wave) * 2] = issue;
     out[(blockIdx.x * 4 + wave) * 2 + 1] = total;
@@ -62,10 +84,11 @@ int main() {
   hipMemset(buf, 1, bytes);
   hipMalloc(&out, sizeof(uint64_t) * cus * 8);
   hipFuncSetAttribute(reinterpret_cast<const void*>(dma_cost), hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-  const char* names[] = {"1 x 1024 B", "2 x 512 B", "4 x 256 B", "8 x 128 B", "16 x 64 B", "16x64 halves", "8x128 split"};
+  const char* names[] = {"1 x 1024 B", "2 x 512 B", "4 x 256 B", "8 x 128 B", "16 x 64 B", "16x64 halves", "8x128 split",
+                         "VGPR 8x128 B", "VGPR 16x64 B"};
   for (int active = 1; active <= 4; active += 3)
-    for (int cfg = 0; cfg <= 6; ++cfg) {
-      const int rl = cfg <= 4 ? cfg : cfg == 5 ? 4 : 3, mode = cfg <= 4 ? 0 : cfg - 4;
+    for (int cfg = 0; cfg <= 8; ++cfg) {
+      const int rl = cfg <= 4 ? cfg : cfg == 5 ? 4 : cfg == 8 ? 4 : 3, mode = cfg <= 4 ? 0 : cfg >= 7 ? 3 : cfg - 4;
       for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL(dma_cost, dim3(cus), dim3(256), 32768, 0, buf, row_stride, rl, active, iters, pieces, mode, out);
         hipDeviceSynchronize();

@@ -74,6 +74,13 @@ if only == "ffn":  # as the engine runs it at this size: K-blocked operands on t
 if only == "ffn_rowmajor":
     shape("ffn_conv k3 1365->1365", 1365, 1365, taps=3, count=12)
     sys.exit(0)
+if only == "shortk":  # the K = 512 shapes on the 256 x 256 tile (diagnostic builds: make EXTRA=-DDN_GEMM_ABL=<bits>)
+    TILE = 3
+    for rep_ in range(2):
+        shape("ffn_in GEGLU 512->2x1365", 512, 1365, epi=_lib.EPI_GEGLU, count=12)
+        shape("qkv 512->1536", 512, 1536, count=12)
+        shape("wn_res 1x1 512 g8", 512, 512, groups=8, count=4)
+    sys.exit(0)
 if only == "kblock256":  # the 256 x 256 tile's shapes, row-major vs K-blocked, alternating
     TILE = 3
     for rep_ in range(3):
