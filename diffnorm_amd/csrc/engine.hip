@@ -251,7 +251,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     }
     if (!fuse && !split) DN_TRY(standalone_norm(l, 1));
     scaled = split;
-    // CausalConv1d(inner, inner, 3) (:894), set up first: when it runs on the 256 x 352 tile its operands go K-blocked --
+    // CausalConv1d(inner, inner, 3) (:894), set up first: when it runs on one of the two 256-row tiles its operands go K-blocked --
     // the GEGLU projection writes its output that way and the weights come from their K-blocked copy (the tile then stages
     // 1 KiB pieces of whole cache lines instead of sixteen half-lines: -5 % on this contraction; DN_KBLOCK=0 disables)
     DnGemmParams pc = gemm_base(dtype, M, ip, ip, T);
@@ -262,7 +262,8 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     }
     pc.bias = w.ffconv_b + (size_t)l * ip; pc.out = tb.fc; pc.ldo = ip;
     pc.pad_ = DN_TAG_FFN_CONV << 8;
-    const bool kblocked = kblock_mode() != 0 && dtype == DN_BF16 && w.ffconv_Wkb && (kblock_mode() == 1 || dn_conv_gemm_kblocked_ok(&pc));
+    const int conv_tile = dn_conv_gemm_tile(&pc);  // 4 = 256 x 352 (the eps-predictor's width), 3 = 256 x 256 (the VAE's)
+    const bool kblocked = kblock_mode() != 0 && dtype == DN_BF16 && w.ffconv_Wkb && (kblock_mode() == 1 || conv_tile == 4 || conv_tile == 3);
     if (kblocked)
       for (int j = 0; j < 3; ++j) {
         pc.terms[j].W = eoff(w.ffconv_Wkb, ((size_t)l * 3 + j) * in_n * ip, es);
