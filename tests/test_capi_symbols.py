@@ -118,3 +118,40 @@ def test_no_kernel_spills_or_uses_scratch():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(["gemm.hip", "attention.hip"]) == []
+
+
+def test_tile_choice_is_host_logic(lib, monkeypatch):
+    """dn_conv_gemm_tile / dn_conv_gemm_kblocked_ok read only the shape fields (no GPU): the routing the engines rely on when
+    they decide which buffers to lay out K-blocked -- the shapes of one denoising step at [32,512] and their small-batch cases."""
+    from diffnorm_amd import _lib
+
+    for v in ("DN_GEMM_TILE", "DN_GEMM_HEUR"):
+        monkeypatch.delenv(v, raising=False)
+
+    def params(M, N, K, T=512, groups=1, n_terms=1, epi=_lib.EPI_BIAS, dtype=_lib.DN_BF16, tile=0, layout=0):
+        p = _lib.GemmParams()
+        p.M, p.N, p.K, p.T, p.groups, p.n_terms, p.epilogue, p.dtype = M, N, K, T, groups, n_terms, epi, dtype
+        p.pad_ = tile << 16
+        for i in range(n_terms):
+            p.terms[i].layout = layout
+        return p
+
+    tile = lambda p: lib.dn_conv_gemm_tile(C.byref(p))
+    M = 32 * 512
+    ffn_conv = params(M, 1408, 1408, n_terms=3)
+    assert tile(ffn_conv) == 4 and lib.dn_conv_gemm_kblocked_ok(C.byref(ffn_conv)) == 1      # 256 x 352: 1408 = 4 x 352
+    assert tile(params(M, 1408, 1408, n_terms=3, dtype=_lib.DN_F32)) != 4                      # bf16 only
+    assert tile(params(2 * 100, 1408, 1408, T=100, n_terms=3)) != 4                            # too few tiles to own whole CUs
+    assert lib.dn_conv_gemm_kblocked_ok(C.byref(params(2 * 100, 1408, 1408, T=100, n_terms=3))) == 0
+    assert tile(params(M, 512, 512, groups=8)) == 3                                            # WaveNet res conv: 256 x 256
+    assert tile(params(M, 512, 512, groups=8, n_terms=3, epi=_lib.EPI_FILM_GATE)) == 3         # dilated conv + FiLM gate
+    assert tile(params(M, 1408, 512, epi=_lib.EPI_GEGLU)) == 3                                 # GEGLU projection (2816 packed columns)
+    assert tile(params(M, 1536, 512)) == 1                                                     # q/kv: two 128 x 128 workgroups per CU
+    assert tile(params(M, 2048, 2048, n_terms=3)) == 3                                         # the VAE's FFN conv (not a multiple of 352)
+    # K-blocked operands: taken by the two 256-row tiles; a forced tile that cannot take them is an error (-1)
+    assert tile(params(M, 1536, 512, layout=3)) == 3
+    assert tile(params(M, 1408, 1408, n_terms=3, layout=3)) == 4
+    assert tile(params(M, 1536, 512, layout=3, tile=1)) == -1
+    assert tile(params(M, 1536, 512, layout=1, dtype=_lib.DN_F32)) == -1
+    for forced in (1, 2, 3):
+        assert tile(params(M, 1536, 512, tile=forced)) == forced
