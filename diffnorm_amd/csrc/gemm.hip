@@ -190,6 +190,10 @@ __device__ __forceinline__ const float* row_bias_of(const DnGemmParams& p, int m
 
 // 8 consecutive bf16 outputs per lane = one 16-byte store: bf16 output stores are issue-bound (a wave-instruction moves
 // 512 B as dwordx2 but 1 KiB as dwordx4), so halving their number halves the store tail of the epilogue.
+// Is the frame a term reads for output frame t inside the sequence?  shift >= 0: the causal case, frame t - shift (frames before the
+// sequence start are zeros); shift < 0: the transposed conv of the backward data path, frame t + |shift| (zeros past the end).
+__device__ __forceinline__ bool shift_valid(int t, int shift, int T) { return shift >= 0 ? t >= shift : t - shift < T; }
+
 // Element offset of output (row m, column n): row-major, or K-blocked [N/32][M][32] for a consumer that stages whole
 // cache lines (DN_LAYOUT_OUT_KBLOCKED; the 4 or 8 columns a lane stores never straddle a 32-column block).
 __device__ __forceinline__ int64_t out_off(const DnGemmParams& p, int m, int n) {
@@ -569,12 +573,12 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   int s_term = 0, s_kk = 0;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
-    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const int shift = tm.shift_by_group ? tm.shift * (1 << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
     const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool valid = a_t[i] >= shift;  // frames before the sequence start read the zero page
+      const bool valid = shift_valid(a_t[i], shift, p.T);  // frames before the sequence start read the zero page
       a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * tm.lda * ES : zero_src;
       a_inc[i] = valid ? ROWB : 0;
     }
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   int s_term = 0, s_kk = 0;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
-    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const int shift = tm.shift_by_group ? tm.shift * (1 << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
     const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
     // K-blocked operands ([K/32][rows][32], DN_LAYOUT_*): rows are 64 bytes apart, K-tiles a whole block apart
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     w_inc = w_kb ? w_rows * ROWB2 : ROWB2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool valid = a_t[i] >= shift;
+      const bool valid = shift_valid(a_t[i], shift, p.T);
       a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * a_rowb : zero_src;
       a_inc[i] = valid ? a_step : 0;
       w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
@@ -943,10 +947,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
   int s_term = 0, s_kk = 0;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
-    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const int shift = tm.shift_by_group ? tm.shift * (1 << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
     const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
-    const bool valid = a_t >= shift;
+    const bool valid = shift_valid(a_t, shift, p.T);
     a_ptr = valid ? A + (int64_t)(a_row - shift) * tm.lda * ES : zero_src;
     a_inc = valid ? ROWB : 0;
 #pragma unroll
@@ -1260,7 +1264,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
   const char* const zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
   auto setup_term = [&](int term) {
     const DnGemmTerm& tm = p.terms[term];
-    const int shift = tm.shift_by_group ? (tm.shift << g) : tm.shift;
+    const int shift = tm.shift_by_group ? tm.shift * (1 << g) : tm.shift;
     const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
     // K-blocked operands ([K/32][rows][32], DN_LAYOUT_*): a 16-row piece is 1 KiB of whole cache lines, the next K-tile a block away
     const bool a_kb = tm.layout & DN_LAYOUT_A_KBLOCKED, w_kb = tm.layout & DN_LAYOUT_W_KBLOCKED;
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     for (int i = 0; i < APW; ++i) {
       int m = m0 + (wave * APW + i) * 16 + srow;
       m = m < p.M ? m : p.M - 1;
-      const bool valid = (m % p.T) >= shift;
+      const bool valid = shift_valid(m % p.T, shift, p.T);
       a_ptr[i] = valid ? A + (int64_t)(m - shift) * a_row : zero_src;
       a_inc[i] = valid ? a_step : 0;
     }
@@ -1643,7 +1647,7 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   // Needs the taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression.
   static const bool env_taps = getenv("DN_FAT_TAPS_INNER") && atoi(getenv("DN_FAT_TAPS_INNER")) != 0;
   bool taps = p.n_terms >= 2 && p.n_terms <= 4 && (env_taps || ((p.pad_ >> 22) & 1));
-  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == 0;
+  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == 0 && p.terms[i].shift >= 0;
   for (int i = 1; i < p.n_terms && taps; ++i) {
     const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
     taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&
@@ -1768,7 +1772,7 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
     DN_CHECK_ARG(p.terms[i].A && p.terms[i].W, "dn_conv_gemm: term %d null operand", i);
     DN_CHECK_ARG(p.terms[i].lda >= p.K && p.terms[i].lda % (16 / (p.dtype == DN_BF16 ? 2 : 4)) == 0,
                  "dn_conv_gemm: term %d lda=%d (K=%d)", i, p.terms[i].lda, p.K);
-    DN_CHECK_ARG(p.terms[i].shift >= 0, "dn_conv_gemm: term %d negative shift", i);
+    DN_CHECK_ARG(p.terms[i].shift > -p.T && p.terms[i].shift < p.T + (1 << 20), "dn_conv_gemm: term %d shift %d", i, p.terms[i].shift);
     DN_CHECK_ARG((reinterpret_cast<uintptr_t>(p.terms[i].A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.terms[i].W) & 15) == 0,
                  "dn_conv_gemm: term %d operands must be 16-byte aligned", i);
   }

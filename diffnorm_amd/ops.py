@@ -174,3 +174,45 @@ def convert_rows(src, dst, C_):
     _lib.check(lib.dn_convert_rows(src.data_ptr(), _code(src), src.shape[-1], dst.data_ptr(), _code(dst), dst.shape[-1], M, C_,
                                    _stream()), "dn_convert_rows")
     return dst
+
+
+def conv_weight_grad(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: int, shifts: Sequence[int],
+                     k_slices: int = 0) -> torch.Tensor:
+    """Weight gradient of a causal conv / Linear, y[t] = sum_j W_j x[t - shifts[j]]: dW_j = sum_frames
+    dy[t] (x) x[t - shifts[j]] -> fp32 [len(shifts), cout, cin].  x [B*T, >= cin], dy [B*T, >= cout] bf16.
+
+    The contraction over frames runs on the same dn_conv_gemm as the forward: both operands are transposed to channels-major
+    (dn_transpose_pad; x once per tap with `shift` zero frames in front of every sequence), the frame index is split into
+    k_slices groups that fill the chip, and the fp32 partial sums are added at the end."""
+    lib = _lib.load()
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.dim() == 2 and dy.dim() == 2
+    M = x.shape[0]
+    assert M % T == 0 and dy.shape[0] == M and all(s >= 0 for s in shifts)
+    B = M // T
+    q = 64 * max(k_slices, 1)  # an explicit slice count must divide the padded frame index into whole K-tiles
+    Tp = (T + max(shifts) + q - 1) // q * q
+    cols = B * Tp
+    if k_slices <= 0:  # enough 256-row tiles for the whole chip, K-slices of at least 8 K-tiles
+        tiles = ((cout + 255) // 256) * ((cin + 255) // 256)
+        k_slices = 1
+        while k_slices * 2 * tiles <= 512 and cols % (k_slices * 2 * 64) == 0 and cols // (k_slices * 2) >= 512:
+            k_slices *= 2
+    chunk = cols // k_slices
+    assert chunk * k_slices == cols and chunk % 64 == 0
+    rows_a, rows_w = cout, (cin + 127) // 128 * 128  # A rows are clamped by the kernel, packed-weight rows go in 128s
+    N = (cin + 3) // 4 * 4
+
+    def transposed(src, C_, front, rows):
+        dst = torch.empty((k_slices, rows, chunk), device=src.device, dtype=torch.bfloat16)
+        _lib.check(lib.dn_transpose_pad(src.data_ptr(), src.shape[1], B, T, C_, front, Tp, dst.data_ptr(), rows, chunk, _stream()),
+                   "dn_transpose_pad")
+        return dst
+
+    dyT = transposed(dy, cout, 0, rows_a)
+    grads = []
+    for s in shifts:
+        xT = transposed(x, cin, s, rows_w)
+        part = torch.empty((k_slices, cout, N), device=x.device, dtype=torch.float32)
+        conv_gemm([(dyT, xT, 0)], part, cout, N, groups=k_slices)
+        grads.append(part.sum(dim=0)[:, :cin])
+    return torch.stack(grads)

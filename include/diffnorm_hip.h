@@ -55,10 +55,11 @@ typedef struct {
   const void* A;      /* [M, lda] activations, element type = dtype                                */
   const void* W;      /* [Np, K] packed weights (K contiguous), Np = N rounded up to 128           */
   int32_t lda;        /* elements between rows of A                                                 */
-  int32_t shift;      /* causal shift in frames (tap j of a k-tap conv: (k-1-j)*dilation)           */
+  int32_t shift;      /* causal shift in frames (tap j of a k-tap conv: (k-1-j)*dilation); negative = frames AFTER t
+                         (zeros past the sequence end): the transposed conv of the backward data path (f2)   */
   int64_t a_gstride;  /* elements added to A per group (0 = all groups share A)                     */
   int64_t w_gstride;  /* elements added to W per group                                              */
-  int32_t shift_by_group; /* 1: effective shift = shift << group (WaveNet dilation 2^i)             */
+  int32_t shift_by_group; /* 1: effective shift = shift * 2^group (WaveNet dilation 2^i)            */
   int32_t layout;     /* DN_LAYOUT_* bits; 0 = row-major A and W as described above                 */
 } DnGemmTerm;
 
@@ -247,6 +248,15 @@ typedef struct {
   int32_t step;     /* 1 for the first update (fairseq/optim/adam.py:212)                                       */
   int32_t pad_;
 } DnAdamParams;
+
+/* Operand preparation for the weight gradient of a causal conv / Linear (the contraction over frames): bf16 [B*T, ld]
+ * frames-major -> channels-major with `front` zero frames in front of every sequence and zeros up to Tp frames and in rows
+ * >= C; the B*Tp columns are stored as [B*Tp / chunk][rows][chunk] (chunk a multiple of 64), one K-slice per group of a
+ * split-K dn_conv_gemm.  dW_j = dY^T . shift_j(X) is then that contraction with A = transposed dY (front 0), W =
+ * transposed X with front = shift_j (the padding supplies the zeros of the causal left context), groups = K-slices spread
+ * over the chip, fp32 partial outputs summed by the caller (diffnorm_amd/ops.py: conv_weight_grad).                    */
+int dn_transpose_pad(const void* src, int32_t ld, int32_t B, int32_t T, int32_t C, int32_t front, int32_t Tp, void* dst,
+                     int32_t rows, int32_t chunk, void* stream);
 
 /* One fairseq Adam update (fairseq/optim/adam.py:159-239) of n fp32 parameters in place, with the gradient scaled by
  * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) first (fairseq/utils.py:392-396; the gradient buffer itself is left

@@ -373,6 +373,56 @@ def test_bias_and_film_epilogues_emit_kblocked_output(ops, tile):
         assert torch.equal(packing.unkblock(out), ref)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cin,cout,k,dil,B,T", [(352, 192, 3, 1, 3, 100), (352, 64, 3, 2, 2, 300), (1408, 1408, 3, 1, 2, 512),
+                                                (704, 128, 1, 1, 1, 515)])
+def test_backward_data_contraction_with_negative_shifts(ops, dtype, tile, cin, cout, k, dil, B, T):
+    """SURVEY 8 f2, the data gradient of a causal conv through the same entry point: dX[t] = sum_j W_j^T dY[t + (k-1-j) dil]
+    (zeros past the sequence end) is a contraction with negative shifts and transposed weights.  Against torch autograd of the
+    oracle's causal conv, every tile variant, ragged M, sequence ends inside a tile."""
+    ops_, packing, _lib = ops
+    code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
+    r = bf16r if dtype == "bf16" else (lambda t: t)
+    x = seeded((B, T, cin), 31).requires_grad_(True)
+    w = r(seeded((cout, cin, k), 32, (1.0 / (cin * k)) ** 0.5))
+    dy = r(seeded((B, T, cout), 33))
+    O.causal_conv1d(x, w, None, dil).backward(dy)
+    want = x.grad
+    N = (cin + 31) // 32 * 32  # dX has cin columns
+    assert N % 352 == 0 or tile != 4
+    dya = act(pad_cols(dy, padk(cout)).view(B * T, -1), dtype)
+    Wt = packing._conv(w.permute(1, 0, 2).contiguous(), code).to(DEV)  # [k][cin -> rows][cout -> K]: W_j^T
+    out = torch.full((B * T, N), float("nan"), device=DEV)
+    terms = [(dya, Wt[j], -(k - 1 - j) * dil) for j in range(k)]
+    ops_.conv_gemm(terms, out, T, N, tile=tile)
+    got = out.cpu().view(B, T, -1)[..., :cin]
+    assert maxerr(got, want) < (2e-4 if dtype == "bf16" else 1e-4) * max(1.0, want.abs().max().item())
+    if tile > 1:
+        ref_out = torch.empty_like(out)
+        ops_.conv_gemm(terms, ref_out, T, N, tile=1)
+        assert torch.equal(out, ref_out)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,B,T,slices", [(192, 96, 3, 1, 3, 100, 0), (64, 352, 3, 2, 2, 300, 4), (1408, 1408, 3, 1, 4, 512, 0),
+                                                        (128, 1000, 1, 1, 1, 515, 1)])
+def test_weight_gradient_contraction_over_frames(ops, cin, cout, k, dil, B, T, slices):
+    """SURVEY 8 f2, the weight gradient of a causal conv through the same contraction kernels: dW_j = dY^T . shift_j(X) over the
+    frame index, split across the chip (ops.conv_weight_grad = dn_transpose_pad + grouped dn_conv_gemm + partial sums), against
+    torch autograd of the oracle's causal conv on the bf16-rounded operands."""
+    ops_, packing, _lib = ops
+    x = bf16r(seeded((B, T, cin), 41))
+    w = seeded((cout, cin, k), 42, (1.0 / (cin * k)) ** 0.5).requires_grad_(True)
+    dy = bf16r(seeded((B, T, cout), 43))
+    O.causal_conv1d(x, w, None, dil).backward(dy)
+    want = w.grad.permute(2, 0, 1)  # [k, cout, cin]
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+    dya = act(pad_cols(dy, padk(cout)).view(B * T, -1), "bf16")
+    got = ops_.conv_weight_grad(xa, dya, T, cin, cout, [(k - 1 - j) * dil for j in range(k)], k_slices=slices).cpu()
+    assert got.shape == want.shape
+    assert maxerr(got, want) < 1e-4 * max(1.0, want.abs().max().item())  # fp32 accumulation of exact bf16 products, other order
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4])
 def test_geglu_on_the_352_wide_tile(ops, tile):
     """GEGLU projection whose packed width (2 x padk(inner) = 1408) is a multiple of 352: the one-wave-per-SIMD tile cuts the
