@@ -87,7 +87,8 @@ SYMBOLS = {
     "dn_conv_gemm_kblocked_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "dn_conv_gemm_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "dn_grad_sumsq": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int32, _vp]),
-    "dn_transpose_pad": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp]),
+    "dn_transpose_pad": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, _vp]),
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamParams), _vp, _vp, _vp]),
     "dn_profile_start": (C.c_int, [_i32, _i32]),
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),

@@ -105,10 +105,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
 // ---- frames-major -> channels-major with per-sequence front padding (operand of the weight-gradient contraction) ----
 // dst[c, b * Tp + front + t] = src[b * T + t, c]; every other element of dst [rows, B * Tp] (pad columns, rows >= C) = 0.
 // The B * Tp columns are stored in groups of `chunk`: dst is [cols / chunk][rows][chunk], one K-slice of a split-K contraction
-// per group with its rows contiguous (the contraction's weight operand has no row stride of its own).
+// per group with its rows contiguous (the contraction's weight operand has no row stride of its own); this call fills rows
+// [row0, row0 + rows) of the destination's rows_total (the taps of a conv stack their transposed inputs in one operand).
 // 64 x 64 tiles through LDS: 128-byte reads along c, 128-byte writes along the frame index.
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __restrict__ src, int ld, int B, int T, int C, int front, int Tp,
-                                                            uint16_t* __restrict__ dst, int rows, int chunk) {
+                                                            uint16_t* __restrict__ dst, int rows, int rows_total, int row0,
+                                                            int chunk) {
   __shared__ uint16_t tile[64][66];
   const int64_t cols = (int64_t)B * Tp;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
@@ -128,22 +130,23 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
   for (int r = ty; r < 64; r += 4) {  // r: channel within the tile, tx: frame
     const int c = c0 + r;
     const int64_t j = j0 + tx;
-    if (c < rows && j < cols) dst[((j / chunk) * rows + c) * chunk + j % chunk] = tile[tx][r];
+    if (c < rows && j < cols) dst[((j / chunk) * rows_total + row0 + c) * chunk + j % chunk] = tile[tx][r];
   }
 }
 
 }  // namespace dn
 
 extern "C" int dn_transpose_pad(const void* src, int32_t ld, int32_t B, int32_t T, int32_t C, int32_t front, int32_t Tp, void* dst,
-                                int32_t rows, int32_t chunk, void* stream) {
+                                int32_t rows, int32_t rows_total, int32_t row0, int32_t chunk, void* stream) {
   DN_CHECK_ARG(src && dst && B > 0 && T > 0 && C > 0 && ld >= C && front >= 0 && Tp >= T + front && rows >= C,
                "dn_transpose_pad: B=%d T=%d C=%d ld=%d front=%d Tp=%d rows=%d", B, T, C, ld, front, Tp, rows);
   const int64_t cols = (int64_t)B * Tp;
+  DN_CHECK_ARG(row0 >= 0 && row0 + rows <= rows_total, "dn_transpose_pad: rows [%d, %d) outside the destination's %d", row0, row0 + rows, rows_total);
   DN_CHECK_ARG(chunk > 0 && chunk % 64 == 0 && cols % chunk == 0, "dn_transpose_pad: chunk=%d must be a multiple of 64 dividing B*Tp=%lld",
                chunk, (long long)cols);
   dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
   hipLaunchKernelGGL(dn::transpose_pad_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const uint16_t*>(src), ld, B, T, C, front, Tp, reinterpret_cast<uint16_t*>(dst), rows, chunk);
+                     reinterpret_cast<const uint16_t*>(src), ld, B, T, C, front, Tp, reinterpret_cast<uint16_t*>(dst), rows, rows_total, row0, chunk);
   DN_CHECK_LAUNCH("dn_transpose_pad");
   return DN_OK;
 }

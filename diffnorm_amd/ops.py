@@ -200,19 +200,18 @@ def conv_weight_grad(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: 
     chunk = cols // k_slices
     assert chunk * k_slices == cols and chunk % 64 == 0
     rows_a, rows_w = cout, (cin + 127) // 128 * 128  # A rows are clamped by the kernel, packed-weight rows go in 128s
-    N = (cin + 3) // 4 * 4
+    n_taps = len(shifts)
 
-    def transposed(src, C_, front, rows):
-        dst = torch.empty((k_slices, rows, chunk), device=src.device, dtype=torch.bfloat16)
-        _lib.check(lib.dn_transpose_pad(src.data_ptr(), src.shape[1], B, T, C_, front, Tp, dst.data_ptr(), rows, chunk, _stream()),
-                   "dn_transpose_pad")
-        return dst
+    def transposed(src, C_, front, dst, rows, row0):
+        _lib.check(lib.dn_transpose_pad(src.data_ptr(), src.shape[1], B, T, C_, front, Tp, dst.data_ptr(), rows, dst.shape[1], row0, chunk,
+                                        _stream()), "dn_transpose_pad")
 
-    dyT = transposed(dy, cout, 0, rows_a)
-    grads = []
-    for s in shifts:
-        xT = transposed(x, cin, s, rows_w)
-        part = torch.empty((k_slices, cout, N), device=x.device, dtype=torch.float32)
-        conv_gemm([(dyT, xT, 0)], part, cout, N, groups=k_slices)
-        grads.append(part.sum(dim=0)[:, :cin])
-    return torch.stack(grads)
+    dyT = torch.empty((k_slices, rows_a, chunk), device=x.device, dtype=torch.bfloat16)
+    transposed(dy, cout, 0, dyT, rows_a, 0)
+    xT = torch.empty((k_slices, n_taps * rows_w, chunk), device=x.device, dtype=torch.bfloat16)  # the taps' operands, stacked
+    for j, s in enumerate(shifts):
+        transposed(x, cin, s, xT, rows_w, j * rows_w)
+    N = n_taps * rows_w
+    part = torch.empty((k_slices, cout, N), device=x.device, dtype=torch.float32)
+    conv_gemm([(dyT, xT, 0)], part, cout, N, groups=k_slices)  # one contraction for all taps: dY^T is read once
+    return part.sum(dim=0).view(cout, n_taps, rows_w)[:, :, :cin].permute(1, 0, 2).contiguous()

@@ -251,12 +251,12 @@ typedef struct {
 
 /* Operand preparation for the weight gradient of a causal conv / Linear (the contraction over frames): bf16 [B*T, ld]
  * frames-major -> channels-major with `front` zero frames in front of every sequence and zeros up to Tp frames and in rows
- * >= C; the B*Tp columns are stored as [B*Tp / chunk][rows][chunk] (chunk a multiple of 64), one K-slice per group of a
- * split-K dn_conv_gemm.  dW_j = dY^T . shift_j(X) is then that contraction with A = transposed dY (front 0), W =
+ * >= C; the B*Tp columns are stored as [B*Tp / chunk][rows_total][chunk] (chunk a multiple of 64), one K-slice per group
+ * of a split-K dn_conv_gemm; the call fills rows [row0, row0 + rows) (the taps of a conv stack their operands).  dW_j = dY^T . shift_j(X) is then that contraction with A = transposed dY (front 0), W =
  * transposed X with front = shift_j (the padding supplies the zeros of the causal left context), groups = K-slices spread
  * over the chip, fp32 partial outputs summed by the caller (diffnorm_amd/ops.py: conv_weight_grad).                    */
 int dn_transpose_pad(const void* src, int32_t ld, int32_t B, int32_t T, int32_t C, int32_t front, int32_t Tp, void* dst,
-                     int32_t rows, int32_t chunk, void* stream);
+                     int32_t rows, int32_t rows_total, int32_t row0, int32_t chunk, void* stream);
 
 /* One fairseq Adam update (fairseq/optim/adam.py:159-239) of n fp32 parameters in place, with the gradient scaled by
  * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) first (fairseq/utils.py:392-396; the gradient buffer itself is left
