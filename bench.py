@@ -148,8 +148,29 @@ def cpu_baseline(sd, cfg, B, T, timesteps, sample_b, max_threads):
                       f"rate scaled by {sample_b}/{B}) in {dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this parent (which has made NO GPU call) starts N ranks through
+    torch.distributed.run on 127.0.0.1 and relays their output; rank 0's JSON line is the result.  Returns the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(env_world or "1") != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus N`")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +192,13 @@ def main():
             dist.init_process_group(backend=backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl_ranks = 1
+    if world > 1:  # the ranks the collective backend actually connected: must be the N that was asked for
+        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != args.gpus:
+            sys.exit(f"bench.py: {rccl_ranks} ranks joined the process group, --gpus {args.gpus} expected")
 
     from diffnorm_amd import _lib, engine, ops, packing, scheduler, synthetic
 
@@ -241,7 +269,7 @@ def main():
         achieved = kflops / ksec / 1e12
         result = {
             "metric": "denoising-steps/sec (BxT latents)", "value": world * K / dt, "unit": "denoising-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[2]: DDIM/DDPM-schedule reverse chain, eps-predictor Model(512, z=128) on "
                                    f"[B={B},T={T}] latents per GPU, {args.timesteps}-step cosine schedule, random-init weights",

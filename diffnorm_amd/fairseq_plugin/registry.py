@@ -7,40 +7,64 @@ registers are *replaced* so the plugin can be loaded with --user-dir inside the 
 (this image) the same decorator contract is provided locally: duplicate names raise ValueError, models must
 subclass the base model class, architectures map to a config function.
 """
-try:  # pragma: no cover - fairseq is not installable in the build image
+try:
     import fairseq.models as _fm
     import fairseq.tasks as _ft
-    from fairseq import registry as _freg
     from fairseq.criterions import CRITERION_REGISTRY as _CRIT, FairseqCriterion, register_criterion as _reg_crit
     from fairseq.models import BaseFairseqModel, FairseqEncoder, FairseqEncoderModel
     from fairseq.tasks import FairseqTask
 
     HAVE_FAIRSEQ = True
 
-    def _forget(name, *tables):
-        for t in tables:
-            t.pop(name, None)
+    def _closure_sets(fn):
+        """The `set` objects a decorator factory closes over (fairseq/registry.py:62-100 keeps the criterion registry's
+        class-name set in a closure cell of `register_x`)."""
+        return [c.cell_contents for c in (getattr(fn, "__closure__", None) or ()) if isinstance(c.cell_contents, set)]
+
+    def _forget_class_name(old_cls, *name_sets):
+        if old_cls is not None:
+            for s in name_sets:
+                s.discard(old_cls.__name__)
 
     def register_model(name):
-        _forget(name, _fm.MODEL_REGISTRY, _fm.MODEL_DATACLASS_REGISTRY, _fm.ARCH_MODEL_REGISTRY)
+        """fairseq's decorator, after dropping what the fork registered under `name` (fairseq/models/__init__.py:109-153
+        rejects a duplicate model name)."""
+        for t in (_fm.MODEL_REGISTRY, _fm.MODEL_DATACLASS_REGISTRY):
+            t.pop(name, None)
         return _fm.register_model(name)
 
     def register_model_architecture(model_name, arch_name):
+        """(fairseq/models/__init__.py:156-205: duplicate architecture names are rejected; the inverse table is a list)."""
         for t in (_fm.ARCH_MODEL_REGISTRY, _fm.ARCH_MODEL_NAME_REGISTRY, _fm.ARCH_CONFIG_REGISTRY):
             t.pop(arch_name, None)
-        if arch_name in _fm.ARCH_MODEL_INV_REGISTRY.get(model_name, []):
-            _fm.ARCH_MODEL_INV_REGISTRY[model_name].remove(arch_name)
+        inv = _fm.ARCH_MODEL_INV_REGISTRY.get(model_name, [])
+        while arch_name in inv:
+            inv.remove(arch_name)
         return _fm.register_model_architecture(model_name, arch_name)
 
     def register_task(name):
-        _forget(name, _ft.TASK_REGISTRY, _ft.TASK_DATACLASS_REGISTRY)
-        for cls in list(_ft.TASK_CLASS_NAMES):
-            pass
-        return _ft.register_task(name)
+        """(fairseq/tasks/__init__.py:48-101: rejects a duplicate task name AND a duplicate class name -- the plugin's task
+        classes carry the fork's class names, so the old class's name leaves TASK_CLASS_NAMES together with its entry)."""
+        old = _ft.TASK_REGISTRY.pop(name, None)
+        _ft.TASK_DATACLASS_REGISTRY.pop(name, None)
+        _forget_class_name(old, _ft.TASK_CLASS_NAMES)
+
+        def deco(cls):
+            _ft.TASK_CLASS_NAMES.discard(cls.__name__)  # a same-named class registered under another task name
+            return _ft.register_task(name)(cls)
+        return deco
 
     def register_criterion(name):
-        _CRIT.pop(name, None)
-        return _reg_crit(name)
+        """(fairseq/registry.py:62-100: duplicate name and duplicate class name are both rejected)."""
+        old = _CRIT.pop(name, None)
+        sets = _closure_sets(_reg_crit)
+        _forget_class_name(old, *sets)
+
+        def deco(cls):
+            for s in sets:
+                s.discard(cls.__name__)
+            return _reg_crit(name)(cls)
+        return deco
 
     MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY = _fm.MODEL_REGISTRY, _fm.ARCH_MODEL_REGISTRY, _fm.ARCH_CONFIG_REGISTRY
     TASK_REGISTRY, CRITERION_REGISTRY = _ft.TASK_REGISTRY, _CRIT
