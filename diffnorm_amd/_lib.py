@@ -57,7 +57,14 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("B", C.c_int32), ("T", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32),
                 ("dtype", C.c_int32), ("pad_", C.c_int32), ("lengths", C.c_void_p),
-                ("scale", C.c_float), ("pad2_", C.c_int32)]
+                ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p)]
+
+
+class AttnBwdParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "out", "dout", "dq", "dk", "dv")] + \
+               [(n, C.c_int32) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv", "B", "T", "heads", "dim_head",
+                                         "dtype", "pad_")] + \
+               [("lengths", C.c_void_p), ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p), ("delta", C.c_void_p)]
 
 
 class GaussianStep(C.Structure):
@@ -93,6 +100,24 @@ SYMBOLS = {
     "dn_profile_start": (C.c_int, [_i32, _i32]),
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),
+    "dn_attention_backward": (C.c_int, [C.POINTER(AttnBwdParams), _vp]),
+    "dn_gate_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "dn_gate_backward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "dn_geglu_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "dn_geglu_backward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "dn_rmsnorm_backward_scratch_bytes": (_sz, [_i32, _i32, _i32]),
+    "dn_rmsnorm_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32,
+                                      _vp, _vp, _i32, _vp, _vp]),
+    "dn_colsum_scratch_bytes": (_sz, [_i32, _i32, _i32]),
+    "dn_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, C.c_float, _i32, _vp, _vp]),
+    "dn_posterior_backward": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_float, _vp]),
+    "dn_lsce_loss_grad": (C.c_int, [_vp, _i32, _vp, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _i32, _i32, _vp]),
+    "dn_masked_mse_grad": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, C.c_float, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "dn_sum_groups": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i64, _vp]),
+    "dn_transpose_weights": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
+    "dn_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "dn_add_broadcast": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "dn_transpose_pad_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dn_rmsnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "dn_time_cond": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "dn_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

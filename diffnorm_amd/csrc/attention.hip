@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
       const f32x4 o = acc_o[dt][qt];
       store4(op, ((int64_t)b * T + q) * p.ldo + h * dh + d, p.dtype, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
     }
+    // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: P = 2^(s * sc - lse)
+    if (p.lse && fg == 0)
+      p.lse[((int64_t)b * p.heads + h) * T + q] = m_run[qt] * sc + __builtin_amdgcn_logf(ES == 2 ? acc_l[qt][0] : l_run[qt]);
   }
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/diffnorm_hip.h"
 
@@ -12,6 +13,29 @@ namespace dn {
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int padk(int c) { return round_up(c, 64); }    // channel width as a K dimension / row stride
 inline int padn(int c) { return round_up(c, 128); }   // packed weight rows
+
+inline const void* eoff(const void* p, size_t elems, int es) { return static_cast<const char*>(p) + elems * es; }
+inline void* eoff(void* p, size_t elems, int es) { return static_cast<char*>(p) + elems * es; }
+inline int esize(int dtype) { return dtype == DN_BF16 ? 2 : 4; }
+
+#define DN_TRY(expr)          \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != DN_OK) return rc__; \
+  } while (0)
+
+inline DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
+  DnGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.dtype = dtype;
+  p.M = M; p.N = N; p.K = K; p.T = T;
+  p.groups = 1;
+  p.n_terms = 1;
+  p.epilogue = DN_EPI_BIAS;
+  p.out_dtype = dtype;
+  p.res_dtype = dtype;
+  return p;
+}
 
 struct Arena {  // bump allocator over the caller's workspace; base == nullptr only measures
   char* base;

@@ -13,16 +13,6 @@ using namespace dn;
 
 namespace {
 
-inline const void* eoff(const void* p, size_t elems, int es) { return static_cast<const char*>(p) + elems * es; }
-inline void* eoff(void* p, size_t elems, int es) { return static_cast<char*>(p) + elems * es; }
-inline int esize(int dtype) { return dtype == DN_BF16 ? 2 : 4; }
-
-#define DN_TRY(expr)          \
-  do {                        \
-    int rc__ = (expr);        \
-    if (rc__ != DN_OK) return rc__; \
-  } while (0)
-
 // The residual-closing contractions can also emit the next block's RMSNorm (64 x 512 whole-row tile, dn_conv_gemm's
 // norm_out).  Measured on [32,512] x dim 512 it loses to 256 x 128 tiles + a standalone norm kernel (one workgroup
 // re-reads the whole weight for 64 rows): 6.85 vs 6.63 ms per denoising step.  Off unless DN_FUSE_NORM=1.
@@ -46,19 +36,6 @@ inline bool split_norm_enabled(int Dp) {
 int kblock_mode() {
   const char* e = getenv("DN_KBLOCK");
   return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-}
-
-DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
-  DnGemmParams p;
-  memset(&p, 0, sizeof(p));
-  p.dtype = dtype;
-  p.M = M; p.N = N; p.K = K; p.T = T;
-  p.groups = 1;
-  p.n_terms = 1;
-  p.epilogue = DN_EPI_BIAS;
-  p.out_dtype = dtype;
-  p.res_dtype = dtype;
-  return p;
 }
 
 // ------------------------------------------------------------------------------------------ WaveNet

@@ -179,13 +179,14 @@ def convert_rows(src, dst, C_):
 def conv_weight_grad(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: int, shifts: Sequence[int],
                      k_slices: int = 0) -> torch.Tensor:
     """Weight gradient of a causal conv / Linear, y[t] = sum_j W_j x[t - shifts[j]]: dW_j = sum_frames
-    dy[t] (x) x[t - shifts[j]] -> fp32 [len(shifts), cout, cin].  x [B*T, >= cin], dy [B*T, >= cout] bf16.
+    dy[t] (x) x[t - shifts[j]] -> fp32 [len(shifts), cout, cin].  x [B*T, >= cin], dy [B*T, >= cout], both bf16 or both fp32.
 
     The contraction over frames runs on the same dn_conv_gemm as the forward: both operands are transposed to channels-major
     (dn_transpose_pad; x once per tap with `shift` zero frames in front of every sequence), the frame index is split into
     k_slices groups that fill the chip, and the fp32 partial sums are added at the end."""
     lib = _lib.load()
-    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.dim() == 2 and dy.dim() == 2
+    assert x.dtype == dy.dtype and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 2 and dy.dim() == 2
+    f32 = x.dtype == torch.float32
     M = x.shape[0]
     assert M % T == 0 and dy.shape[0] == M and all(s >= 0 for s in shifts)
     B = M // T
@@ -201,17 +202,179 @@ def conv_weight_grad(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: 
     assert chunk * k_slices == cols and chunk % 64 == 0
     rows_a, rows_w = cout, (cin + 127) // 128 * 128  # A rows are clamped by the kernel, packed-weight rows go in 128s
     n_taps = len(shifts)
+    tp = lib.dn_transpose_pad_f32 if f32 else lib.dn_transpose_pad
 
     def transposed(src, C_, front, dst, rows, row0):
-        _lib.check(lib.dn_transpose_pad(src.data_ptr(), src.shape[1], B, T, C_, front, Tp, dst.data_ptr(), rows, dst.shape[1], row0, chunk,
-                                        _stream()), "dn_transpose_pad")
+        _lib.check(tp(src.data_ptr(), src.shape[1], B, T, C_, front, Tp, dst.data_ptr(), rows, dst.shape[1], row0, chunk,
+                      _stream()), "dn_transpose_pad")
 
-    dyT = torch.empty((k_slices, rows_a, chunk), device=x.device, dtype=torch.bfloat16)
+    dyT = torch.empty((k_slices, rows_a, chunk), device=x.device, dtype=x.dtype)
     transposed(dy, cout, 0, dyT, rows_a, 0)
-    xT = torch.empty((k_slices, n_taps * rows_w, chunk), device=x.device, dtype=torch.bfloat16)  # the taps' operands, stacked
+    xT = torch.empty((k_slices, n_taps * rows_w, chunk), device=x.device, dtype=x.dtype)  # the taps' operands, stacked
     for j, s in enumerate(shifts):
         transposed(x, cin, s, xT, rows_w, j * rows_w)
     N = n_taps * rows_w
     part = torch.empty((k_slices, cout, N), device=x.device, dtype=torch.float32)
     conv_gemm([(dyT, xT, 0)], part, cout, N, groups=k_slices)  # one contraction for all taps: dY^T is read once
-    return part.sum(dim=0).view(cout, n_taps, rows_w)[:, :, :cin].permute(1, 0, 2).contiguous()
+    Np, Kp = (cout + 127) // 128 * 128, (cin + 63) // 64 * 64
+    grad = torch.zeros((n_taps, Np, Kp), device=x.device, dtype=torch.float32)  # the packed layout of the weight itself
+    _lib.check(lib.dn_wgrad_reduce(part.data_ptr(), k_slices, cout, N, rows_w, n_taps, grad.data_ptr(), Np, Kp, _stream()),
+               "dn_wgrad_reduce")
+    return grad[:, :cout, :cin].contiguous()
+
+
+# ------------------------------------------------------------------------------------------ backward ops
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device)
+
+
+def attention_fwd_lse(q, k, v, out, B, T, heads, dim_head, lengths, ldq=None, ldk=None, ldv=None):
+    """dn_attention that also keeps the per-query log-sum-exp [B, heads, T] for `attention_backward`."""
+    lib = _lib.load()
+    lse = torch.empty(B, heads, T, dtype=torch.float32, device=q.device)
+    a = _lib.AttnParams()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = ldq or q.shape[-1], ldk or k.shape[-1], ldv or v.shape[-1], out.shape[-1]
+    a.B, a.T, a.heads, a.dim_head = B, T, heads, dim_head
+    a.dtype = _code(q)
+    a.lengths = _lib.ptr(lengths)
+    a.scale = dim_head ** -0.5
+    a.lse = lse.data_ptr()
+    _lib.check(lib.dn_attention(C.byref(a), _stream()), "dn_attention")
+    return out, lse
+
+
+def attention_backward(q, k, v, out, dout, lse, B, T, heads, dim_head, lengths, ld_qkv=None):
+    """-> (dq, dk, dv) as three column blocks of one [B*T, 3*heads*dim_head] tensor (reference :299-343 differentiated)."""
+    lib = _lib.load()
+    hd = heads * dim_head
+    dqkv = torch.empty(B * T, 3 * hd, dtype=q.dtype, device=q.device)
+    delta = torch.empty(B, heads, T, dtype=torch.float32, device=q.device)
+    a = _lib.AttnBwdParams()
+    a.q, a.k, a.v, a.out, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr()
+    es = dqkv.element_size()
+    a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + hd * es, dqkv.data_ptr() + 2 * hd * es
+    ld = ld_qkv or q.shape[-1]
+    a.ldq = a.ldk = a.ldv = ld
+    a.ldo, a.lddo = out.shape[-1], dout.shape[-1]
+    a.lddq = a.lddk = a.lddv = 3 * hd
+    a.B, a.T, a.heads, a.dim_head = B, T, heads, dim_head
+    a.dtype = _code(q)
+    a.lengths = _lib.ptr(lengths)
+    a.scale = dim_head ** -0.5
+    a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+    _lib.check(lib.dn_attention_backward(C.byref(a), _stream()), "dn_attention_backward")
+    return dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:]
+
+
+def gate_forward(h, res, T, gamma_beta=None, gb_half=0):
+    lib = _lib.load()
+    out = torch.empty_like(h)
+    M, ld = h.shape
+    _lib.check(lib.dn_gate_forward(h.data_ptr(), res.data_ptr(), out.data_ptr(), _code(h), M, ld, T, _lib.ptr(gamma_beta),
+                                   gamma_beta.stride(0) if gamma_beta is not None else 0, gb_half, _stream()), "dn_gate_forward")
+    return out
+
+
+def gate_backward(dout, h, T, gamma_beta=None, gb_half=0, want_rows=False):
+    lib = _lib.load()
+    dh = torch.empty_like(h)
+    M, ld = h.shape
+    rows = torch.zeros(M, 2 * gb_half, dtype=torch.float32, device=h.device) if want_rows else None
+    _lib.check(lib.dn_gate_backward(dout.data_ptr(), h.data_ptr(), dh.data_ptr(), _code(h), M, ld, T, _lib.ptr(gamma_beta),
+                                    gamma_beta.stride(0) if gamma_beta is not None else 0, gb_half, _lib.ptr(rows),
+                                    2 * gb_half, _stream()), "dn_gate_backward")
+    return (dh, rows) if want_rows else dh
+
+
+def geglu_forward(pre, ip):
+    lib = _lib.load()
+    M = pre.shape[0]
+    out = torch.empty(M, ip, dtype=pre.dtype, device=pre.device)
+    _lib.check(lib.dn_geglu_forward(pre.data_ptr(), out.data_ptr(), _code(pre), M, ip, _stream()), "dn_geglu_forward")
+    return out
+
+
+def geglu_backward(dout, pre, ip):
+    lib = _lib.load()
+    dpre = torch.empty_like(pre)
+    _lib.check(lib.dn_geglu_backward(dout.data_ptr(), pre.data_ptr(), dpre.data_ptr(), _code(pre), pre.shape[0], ip, _stream()),
+               "dn_geglu_backward")
+    return dpre
+
+
+def rmsnorm_backward(x, dy, B, T, D, gamma=None, gamma_beta=None, gb_half=0, dres=None, act_dtype=None, dgamma=None, dgamma_beta=None):
+    """-> (dx fp32 [B*T, ldx], dx_act or None); dgamma / dgamma_beta are accumulated in place."""
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dx_act = torch.empty(x.shape[0], x.shape[1], dtype=act_dtype, device=x.device) if act_dtype is not None else None
+    scratch = _scratch(int(lib.dn_rmsnorm_backward_scratch_bytes(B, T, D)), x.device)
+    _lib.check(lib.dn_rmsnorm_backward(x.data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], _code(dy), B, T, D, _lib.ptr(gamma),
+                                       _lib.ptr(gamma_beta), gamma_beta.stride(0) if gamma_beta is not None else 0, gb_half,
+                                       _lib.ptr(dres), dx.data_ptr(), _lib.ptr(dx_act), _code(dx_act) if dx_act is not None else DN_F32,
+                                       x.shape[1], _lib.ptr(dgamma), _lib.ptr(dgamma_beta),
+                                       dgamma_beta.stride(0) if dgamma_beta is not None else 0, scratch.data_ptr(), _stream()),
+               "dn_rmsnorm_backward")
+    return dx, dx_act
+
+
+def colsum(src, groups, rows_per_group, C_, out=None, scale=1.0, accumulate=False):
+    lib = _lib.load()
+    out = torch.zeros(groups, C_, dtype=torch.float32, device=src.device) if out is None else out
+    scratch = _scratch(int(lib.dn_colsum_scratch_bytes(groups, rows_per_group, C_)), src.device)
+    _lib.check(lib.dn_colsum(src.data_ptr(), src.shape[-1], _code(src), groups, rows_per_group, C_, out.data_ptr(), out.stride(0),
+                             float(scale), int(accumulate), scratch.data_ptr(), _stream()), "dn_colsum")
+    return out
+
+
+def posterior_backward(params, noise, dz, Z, T, lengths, kl_weight, act_dtype, ldo):
+    lib = _lib.load()
+    M = params.shape[0]
+    out = torch.empty(M, ldo, dtype=act_dtype, device=params.device)
+    _lib.check(lib.dn_posterior_backward(params.data_ptr(), params.shape[1], noise.data_ptr(), noise.shape[1], dz.data_ptr(), dz.shape[1],
+                                         out.data_ptr(), _code(out), ldo, M, Z, T, _lib.ptr(lengths), float(kl_weight), _stream()),
+               "dn_posterior_backward")
+    return out
+
+
+def lsce_loss_grad(logits, target_i32, epsilon, grad_scale, act_dtype=None, ldd=0):
+    """-> (rows [M,4] = nll, smooth, correct, valid; dlogits [M, ldd] or None)."""
+    lib = _lib.load()
+    M, V = logits.shape
+    rows = torch.empty(M, 4, dtype=torch.float32, device=logits.device)
+    dl = torch.empty(M, ldd, dtype=act_dtype, device=logits.device) if act_dtype is not None else None
+    _lib.check(lib.dn_lsce_loss_grad(logits.data_ptr(), logits.stride(0), target_i32.data_ptr(), M, V, float(epsilon), float(grad_scale),
+                                     rows.data_ptr(), _lib.ptr(dl), _code(dl) if dl is not None else DN_F32, ldd, _stream()),
+               "dn_lsce_loss_grad")
+    return rows, dl
+
+
+def masked_mse_grad(pred, target, T, lengths, grad_scale, C_, dpred=None, accumulate=False, act_dtype=None, ld_act=0):
+    lib = _lib.load()
+    M = pred.shape[0]
+    sq = torch.empty(M, dtype=torch.float32, device=pred.device)
+    dact = torch.empty(M, ld_act, dtype=act_dtype, device=pred.device) if act_dtype is not None else None
+    _lib.check(lib.dn_masked_mse_grad(pred.data_ptr(), pred.stride(0), target.data_ptr(), target.stride(0), M, C_, T, _lib.ptr(lengths),
+                                      float(grad_scale), sq.data_ptr(), _lib.ptr(dpred), dpred.stride(0) if dpred is not None else 0,
+                                      int(accumulate), _lib.ptr(dact), _code(dact) if dact is not None else DN_F32, ld_act, _stream()),
+               "dn_masked_mse_grad")
+    return sq, dact
+
+
+def sum_groups(src):
+    """[count, ...] -> sum over the leading dim."""
+    lib = _lib.load()
+    dst = torch.empty_like(src[0])
+    _lib.check(lib.dn_sum_groups(src.data_ptr(), src[0].numel(), src.shape[0], dst.data_ptr(), _code(src), dst.numel(), _stream()),
+               "dn_sum_groups")
+    return dst
+
+
+def transpose_weights(w, Rp, Cp):
+    """[count, R, Cc] -> [count, Cp, Rp] padded transposes."""
+    lib = _lib.load()
+    n, R, Cc = w.shape
+    out = torch.empty(n, Cp, Rp, dtype=w.dtype, device=w.device)
+    _lib.check(lib.dn_transpose_weights(w.data_ptr(), _code(w), n, R * Cc, R, Cc, out.data_ptr(), Rp * Cp, Rp, Cp, _stream()),
+               "dn_transpose_weights")
+    return out

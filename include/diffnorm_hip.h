@@ -165,6 +165,8 @@ typedef struct {
   const int32_t* lengths; /* [B] or NULL (no mask)                                                  */
   float scale;        /* dim_head ** -0.5                                                           */
   int32_t pad2_;
+  float* lse;         /* optional fp32 [B, heads, T]: log2-domain log-sum-exp of the scaled scores of every query
+                         (max * scale * log2(e) + log2(sum)), what dn_attention_backward recomputes P from; NULL = not kept */
 } DnAttnParams;
 
 int dn_attention(const DnAttnParams* p, void* stream);
@@ -263,6 +265,104 @@ int dn_transpose_pad(const void* src, int32_t ld, int32_t B, int32_t T, int32_t 
  * unscaled); param_bf16 != NULL also receives the updated parameters in bf16 (the forward kernels' operand type). */
 int dn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const DnAdamParams* hp,
                  const float* sumsq, void* param_bf16, void* stream);
+
+/* ------------------------------------------------------------------ backward ops ---------- */
+/* The contractions of a backward pass are dn_conv_gemm itself (data gradient: negative shifts + transposed packed weights from
+ * dn_transpose_weights; weight gradient: dn_transpose_pad operands + split-K groups + dn_wgrad_reduce).  The entry points
+ * below are the backward of everything that is not a contraction, the loss gradients and the reductions over frames.  All
+ * reductions are two-stage with fixed block counts (no atomics): a training step is bit-reproducible.                     */
+
+/* Gradient of dn_attention (Attend.forward non-flash branch, latent_module.py:299-343): P is recomputed from the forward's
+ * per-query log-sum-exp (DnAttnParams.lse); dq / dk / dv have the layout of q / k / v (row m = b*T+t, head h at columns
+ * [h*dh, (h+1)*dh)) with their own row strides, so they can be three column blocks of one [M, 3*heads*dh] buffer.
+ * delta: fp32 scratch [B, heads, T] (sum_d dO*O per query, written by the call).  No atomics: dk/dv and dq each have one
+ * writer.  Attention dropout (p = 0.1 in the reference's training mode, :338,668) is not applied.                        */
+typedef struct {
+  const void *q, *k, *v, *out, *dout;
+  void *dq, *dk, *dv;
+  int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int32_t B, T, heads, dim_head;
+  int32_t dtype;
+  int32_t pad_;
+  const int32_t* lengths; /* [B] or NULL */
+  float scale;
+  int32_t pad2_;
+  const float* lse;       /* [B, heads, T] from the forward */
+  float* delta;           /* [B, heads, T] scratch */
+} DnAttnBwdParams;
+int dn_attention_backward(const DnAttnBwdParams* p, void* stream);
+
+/* WaveNet gate as a stand-alone pass (the training forward keeps the pre-activation h that its derivative needs):
+ * out = tanh(h') sigmoid(h') + res with h' = h * gamma[b] + beta[b] when gamma_beta != NULL (latent_module.py:525-530).
+ * h, res, out, dout, dh: [M, ld] in `dtype`, same ld.  Backward: dh = dout * gate'(h') [* gamma]; with FiLM, dgb_rows
+ * (fp32 [M, dgb_ld], optional) receives the per-frame terms of the conditioning gradient: [dg * h | dg] at [c | gb_half + c]. */
+int dn_gate_forward(const void* h, const void* res, void* out, int32_t dtype, int32_t M, int32_t ld, int32_t T,
+                    const float* gamma_beta, int32_t gb_ld, int32_t gb_half, void* stream);
+int dn_gate_backward(const void* dout, const void* h, void* dh, int32_t dtype, int32_t M, int32_t ld, int32_t T,
+                     const float* gamma_beta, int32_t gb_ld, int32_t gb_half, float* dgb_rows, int32_t dgb_ld, void* stream);
+
+/* GEGLU (latent_module.py:881-884) on the packed column order of the GEGLU projection (DN_EPI_GEGLU: per 16 columns, 8 values
+ * then the 8 gates of the same outputs): pre [M, 2*ip] -> out [M, ip] = gelu_erf(gate) * value; backward fills dpre [M, 2*ip]. */
+int dn_geglu_forward(const void* pre, void* out, int32_t dtype, int32_t M, int32_t ip, void* stream);
+int dn_geglu_backward(const void* dout, const void* pre, void* dpre, int32_t dtype, int32_t M, int32_t ip, void* stream);
+
+/* Gradient of dn_rmsnorm (latent_module.py:620-639).  x fp32 [B*T, ldx] (the norm's input), dy [B*T, lddy] in dy_dtype;
+ * dx fp32 [B*T, ldx] = norm gradient (+ dres, the gradient arriving on the residual branch, when not NULL; dx may alias dres);
+ * dx_act (optional): dx once more in act_dtype [B*T, ld_act], pad columns zero (the next contraction's operand).
+ * Parameter gradients are ACCUMULATED: dgamma fp32 [D] (learned gamma) or dgamma_beta fp32 [B, dgb_ld] = [d g_c | d b_c] at
+ * [c | gb_half + c] per sample (adaptive norm).  scratch: dn_rmsnorm_backward_scratch_bytes(B, T, D).  D <= 1024.          */
+size_t dn_rmsnorm_backward_scratch_bytes(int32_t B, int32_t T, int32_t D);
+int dn_rmsnorm_backward(const float* x, int32_t ldx, const void* dy, int32_t lddy, int32_t dy_dtype, int32_t B, int32_t T, int32_t D,
+                        const float* gamma, const float* gamma_beta, int32_t gb_ld, int32_t gb_half, const float* dres, float* dx,
+                        void* dx_act, int32_t act_dtype, int32_t ld_act, float* dgamma, float* dgamma_beta, int32_t dgb_ld,
+                        float* scratch, void* stream);
+
+/* out[g, c] (+)= scale * sum over the rows of group g of src[row, c] (bias gradients, per-sample conditioning gradients,
+ * loss sums): src [groups * rows_per_group, ld] in dtype, out fp32 [groups, out_ld].  scratch: dn_colsum_scratch_bytes.    */
+size_t dn_colsum_scratch_bytes(int32_t groups, int32_t rows_per_group, int32_t C);
+int dn_colsum(const void* src, int32_t ld, int32_t dtype, int32_t groups, int32_t rows_per_group, int32_t C, float* out,
+              int32_t out_ld, float scale, int32_t accumulate, float* scratch, void* stream);
+
+/* Gradient of dn_posterior_sample + the KL term (distributions.py:24-41, 62-74): dparams [M, ldo] (act_dtype, pad columns
+ * zero) = [d mean ; d logvar] from dz fp32 [M, lddz] and kl_weight = (loss weight of the KL) / (B * Z * T); the clamp of
+ * logvar to [-30, 20] passes no gradient outside the range, KL only counts valid frames.                                 */
+int dn_posterior_backward(const float* params, int32_t ldp, const float* noise, int32_t ldn, const float* dz, int32_t lddz,
+                          void* dparams, int32_t act_dtype, int32_t ldo, int32_t M, int32_t Z, int32_t T, const int32_t* lengths,
+                          float kl_weight, void* stream);
+
+/* Label-smoothed cross entropy over log_softmax(logits) and its gradient (fairseq/criterions/label_smoothed_cross_entropy.py:
+ * 34-51 with ignore_index 0; speech_vae_decoder_loss.py:60-79): rows fp32 [M, 4] = {nll, smooth, correct, valid} per frame
+ * (nll = -lprob[target], smooth = -sum lprobs; loss = (1 - eps - eps_i) nll + eps_i smooth, eps_i = eps / (V - 1));
+ * dlogits (optional, act_dtype [M, ldd], pad columns zero) = grad_scale * d loss / d logits.  V <= 1024.                  */
+int dn_lsce_loss_grad(const float* logits, int32_t ld, const int32_t* target, int32_t M, int32_t V, float epsilon, float grad_scale,
+                      float* rows, void* dlogits, int32_t act_dtype, int32_t ldd, void* stream);
+
+/* Masked MSE (latent_module.py:1135-1138, 1576-1577: mean over the elements of valid frames): sq_rows fp32 [M] = sum_c
+ * (pred - target)^2 of valid frames (0 for pads); dpred fp32 [M, ldd] (+)= grad_scale * (pred - target), and dpred_act its
+ * copy in act_dtype [M, ld_act] (both optional, pad columns and pad frames zero).                                          */
+int dn_masked_mse_grad(const float* pred, int32_t ldp, const float* target, int32_t ldt, int32_t M, int32_t C, int32_t T,
+                       const int32_t* lengths, float grad_scale, float* sq_rows, float* dpred, int32_t ldd, int32_t accumulate,
+                       void* dpred_act, int32_t act_dtype, int32_t ld_act, void* stream);
+
+/* dst[i] = sum_{k < count} src[k * stride + i], i < n (the gradients a tensor receives from several consumers). */
+int dn_sum_groups(const void* src, int64_t stride, int32_t count, void* dst, int32_t dtype, int64_t n, void* stream);
+
+/* Batched padded transpose of packed weights, the W operand of the data-gradient contraction: dst[n] [Cp][Rp] = (the first
+ * R rows of src[n], [R][Cc])^T, zeros beyond; matrices src_stride / dst_stride elements apart.                           */
+int dn_transpose_weights(const void* src, int32_t dtype, int32_t count, int64_t src_stride, int32_t R, int32_t Cc, void* dst,
+                         int64_t dst_stride, int32_t Rp, int32_t Cp, void* stream);
+
+/* Last step of a weight gradient: grad[tap][n][k] += sum_s part[s][n][tap * rows_w + k] for n < cout, k < Kp; part is the fp32
+ * split-K output [slices][cout][n_total] of the contraction over frames, grad the packed fp32 layout [n_taps][Np][Kp].    */
+int dn_wgrad_reduce(const float* part, int32_t slices, int32_t cout, int32_t n_total, int32_t rows_w, int32_t n_taps, float* grad,
+                    int32_t Np, int32_t Kp, void* stream);
+
+/* dst[j * ld + c] += src[c], j < count (the L skip-conv biases of a WaveNet share one gradient). */
+int dn_add_broadcast(const float* src, float* dst, int32_t C, int32_t ld, int32_t count, void* stream);
+
+/* dn_transpose_pad for fp32 operands (exact-fp32 mode); chunk a multiple of 32. */
+int dn_transpose_pad_f32(const float* src, int32_t ld, int32_t B, int32_t T, int32_t C, int32_t front, int32_t Tp, float* dst,
+                         int32_t rows, int32_t rows_total, int32_t row0, int32_t chunk, void* stream);
 
 /* ------------------------------------------------------------------ whole-path engine ---------- */
 

@@ -55,7 +55,10 @@ def test_struct_layout_matches_header(lib, tmp_path):
                                            "row_ssq_ld", "row_ssq_parts", "row_D", "row_bias_ld", "row_bias"]),
         "DnAdamParams": (_lib.AdamParams, ["lr", "beta1", "beta2", "eps", "weight_decay", "max_norm", "step"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
-                                           "dtype", "lengths", "scale"]),
+                                           "dtype", "lengths", "scale", "lse"]),
+        "DnAttnBwdParams": (_lib.AttnBwdParams, ["q", "k", "v", "out", "dout", "dq", "dk", "dv", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq",
+                                                 "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
+                                                 "delta"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
                                          "dtype", "max_pos"]),
         "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",
