@@ -49,7 +49,8 @@ class GemmParams(C.Structure):
 
 class AdamParams(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int32), ("pad_", C.c_int32)]
+                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int32), ("pad_", C.c_int32),
+                ("grad_scale", C.c_double), ("grad_scale_dev", C.c_void_p)]
 
 
 class AttnParams(C.Structure):
@@ -87,6 +88,13 @@ class VaeConfig(C.Structure):
                                          "vocab", "n_mults")] + [("mults", C.c_int32 * 4), ("dtype", C.c_int32)]
 
 
+class VaeTrainBatch(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("units", C.c_void_p), ("lengths", C.c_void_p), ("noise", C.c_void_p), ("B", C.c_int32),
+                ("T", C.c_int32), ("ntokens", C.c_int32), ("w_lsce", C.c_float), ("w_mse", C.c_float), ("w_kl", C.c_float),
+                ("label_smoothing", C.c_float), ("loss_scale", C.c_float), ("stats", C.c_void_p), ("logits_out", C.c_void_p),
+                ("recon_out", C.c_void_p)]
+
+
 # every symbol include/diffnorm_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 SYMBOLS = {
@@ -113,6 +121,18 @@ SYMBOLS = {
     "dn_posterior_backward": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_float, _vp]),
     "dn_lsce_loss_grad": (C.c_int, [_vp, _i32, _vp, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _i32, _i32, _vp]),
     "dn_masked_mse_grad": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, C.c_float, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "dn_vec_sum": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "dn_vae_train_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),
+    "dn_vae_train_destroy": (None, [_vp]),
+    "dn_vae_train_param_count": (_i64, [_vp]),
+    "dn_vae_train_aux_bytes": (_sz, [_vp]),
+    "dn_vae_train_offsets": (C.c_int, [_vp, C.POINTER(_i64), _i32]),
+    "dn_vae_train_stage_range": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dn_vae_train_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "dn_vae_train_refresh": (C.c_int, [_vp, _vp]),
+    "dn_vae_train_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "dn_vae_train_forward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _vp, _sz, _vp]),
+    "dn_vae_train_backward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _i32, _i32, _vp, _sz, _vp]),
     "dn_sum_groups": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i64, _vp]),
     "dn_transpose_weights": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "dn_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -51,10 +51,12 @@ __global__ __launch_bounds__(256) void grad_sumsq_final_kernel(const float* __re
 }
 
 struct AdamScalars {
-  float beta1, beta2, one_m_beta1, one_m_beta2, eps, neg_step_size, neg_wd_lr, max_norm;
+  float beta1, beta2, one_m_beta1, one_m_beta2, eps, neg_step_size, neg_wd_lr, max_norm, grad_scale;
+  const float* grad_scale_dev;
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& h, float clip) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& h, float clip, float gs) {
+  g *= gs;                                             // trainer.py:918-933  multiply_grads(world / sample_size)
   g *= clip;                                           // utils.py:394-396  g.mul_(clip_coef)
   m = __fmaf_rn(g, h.one_m_beta1, m * h.beta1);        // adam.py:215  exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
   v = __fmaf_rn(h.one_m_beta2, g * g, v * h.beta2);    // adam.py:216  exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
@@ -67,14 +69,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, int64_t n, AdamScalars h,
                                                         const float* __restrict__ sumsq, uint16_t* __restrict__ p_bf16) {
   float clip = 1.f;
-  if (sumsq && h.max_norm > 0.f) clip = fminf(h.max_norm / (sqrtf(sumsq[0]) + 1e-6f), 1.f);  // utils.py:392-394
+  const float gs = h.grad_scale_dev ? h.grad_scale * h.grad_scale_dev[0] : h.grad_scale;
+  if (sumsq && h.max_norm > 0.f) clip = fminf(h.max_norm / (gs * sqrtf(sumsq[0]) + 1e-6f), 1.f);  // utils.py:392-394
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   auto update = [&](int64_t i, float4 pp, const float4 gg, float4 mm, float4 vv) {
-    adam_one(pp.x, gg.x, mm.x, vv.x, h, clip);
-    adam_one(pp.y, gg.y, mm.y, vv.y, h, clip);
-    adam_one(pp.z, gg.z, mm.z, vv.z, h, clip);
-    adam_one(pp.w, gg.w, mm.w, vv.w, h, clip);
+    adam_one(pp.x, gg.x, mm.x, vv.x, h, clip, gs);
+    adam_one(pp.y, gg.y, mm.y, vv.y, h, clip, gs);
+    adam_one(pp.z, gg.z, mm.z, vv.z, h, clip, gs);
+    adam_one(pp.w, gg.w, mm.w, vv.w, h, clip, gs);
     *reinterpret_cast<float4*>(p + 4 * i) = pp;
     *reinterpret_cast<float4*>(m + 4 * i) = mm;
     *reinterpret_cast<float4*>(v + 4 * i) = vv;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
     float pp = p[i], mm = m[i], vv = v[i];
-    adam_one(pp, g[i], mm, vv, h, clip);
+    adam_one(pp, g[i], mm, vv, h, clip, gs);
     p[i] = pp; m[i] = mm; v[i] = vv;
     if (p_bf16) p_bf16[i] = (uint16_t)pack_bf16x2(pp, 0.f);
   }
@@ -179,6 +182,8 @@ extern "C" int dn_adam_step(float* param, const float* grad, float* exp_avg, flo
   h.eps = (float)hp->eps; h.neg_step_size = (float)-step_size;
   h.neg_wd_lr = hp->weight_decay != 0. ? (float)(-hp->weight_decay * hp->lr) : 0.f;
   h.max_norm = (float)hp->max_norm;
+  h.grad_scale = hp->grad_scale != 0. ? (float)hp->grad_scale : 1.f;
+  h.grad_scale_dev = hp->grad_scale_dev;
   const int64_t n4 = (n + 3) >> 2;
   static const int wg_per_cu = getenv("DN_ADAM_WG_PER_CU") ? atoi(getenv("DN_ADAM_WG_PER_CU")) : 8;  // measured best of 4..32 at 384 Mi elements
   const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * wg_per_cu);  // grid-stride beyond

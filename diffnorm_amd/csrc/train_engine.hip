@@ -1,0 +1,983 @@
+// Training step of the speech VAE on the HIP path (SURVEY 8 f2 / BASELINE config 4): forward with every activation the
+// backward needs kept in the caller's workspace, loss + loss gradients, and the backward pass into one flat fp32 gradient
+// buffer laid out exactly like the flat parameter buffer (so the optimizer step, the gradient norm and the data-parallel
+// all-reduce are single passes over one buffer).
+//   reference: SpeechVAEEncoderDecoder.forward latent_module.py:1118-1142, the criterion algebra of
+//   fairseq/criterions/speech_vae_decoder_loss.py:60-95, WavenetEncoder :1003-1032, ConditionableTransformer :642-706.
+//
+// Parameters live in the PACKED layout the contractions consume (engine.h; rows padded to 128, K to 64, the GEGLU projection
+// interleaved, conv taps as separate matrices): `master` (fp32) is what the optimizer updates, `work` the same buffer in the
+// arithmetic dtype (bf16: written by dn_adam_step's bf16 copy; f32: == master), `aux` holds what dn_vae_train_refresh derives
+// after every update (the transposed matrices of the data-gradient contractions, the summed skip biases).  Every contraction,
+// forward and backward, is dn_conv_gemm:
+//   data gradient    dX[t] = sum_j dY[t + shift_j] W_j            negative shifts, transposed weights
+//   weight gradient  dW_j  = dY^T shift_j(X)                      both operands transposed to channels-major K-slices,
+//                                                                 grouped split-K contraction, fixed-order reduction
+// Everything is enqueued on one stream, allocates nothing and never synchronises.
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "engine.h"
+
+using namespace dn;
+
+namespace dn {
+
+// dst[(j / chunk)][row0 + c][j % chunk] = src[b*T + t, c] with j = b*Tp + front + t; zero for pad frames, rows >= C and the
+// tail columns [B*Tp, cols_total) that round the frame index up to whole K-slices.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_slices_kernel(const T* __restrict__ src, int ld, int B, int Tn, int C, int front, int Tp,
+                                                               int64_t cols_total, T* __restrict__ dst, int rows, int rows_total, int row0,
+                                                               int chunk) {
+  __shared__ T tile[64][66];
+  const int64_t cols = (int64_t)B * Tp;
+  const int64_t j0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t j = j0 + r;
+    T v = T(0);
+    if (j < cols) {
+      const int b = (int)(j / Tp), t = (int)(j - (int64_t)b * Tp) - front;
+      const int c = c0 + tx;
+      if (t >= 0 && t < Tn && c < C) v = src[((int64_t)b * Tn + t) * ld + c];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r;
+    const int64_t j = j0 + tx;
+    if (c < rows && j < cols_total) dst[((j / chunk) * rows_total + row0 + c) * chunk + j % chunk] = tile[tx][r];
+  }
+}
+
+__global__ void vae_loss_kernel(const float* __restrict__ sums, float* __restrict__ stats, float w_lsce, float w_mse, float w_kl,
+                                float eps, int V, float inv_ntokens, float inv_mse, float inv_kl) {
+  // sums: [0..3] = sum over frames of {nll, smooth, correct, valid}; [4] = sum of squared errors; [5] = sum of kl rows
+  const float eps_i = eps / (float)(V - 1);
+  const float lsce = (1.0f - eps - eps_i) * sums[0] + eps_i * sums[1];
+  const float nll = sums[0] * inv_ntokens, mse = sums[4] * inv_mse, kl = sums[5] * inv_kl;
+  stats[0] = w_lsce * lsce * inv_ntokens + w_mse * mse + w_kl * kl;  // speech_vae_decoder_loss.py:80-83
+  stats[1] = nll;
+  stats[2] = mse;
+  stats[3] = kl;
+  stats[4] = sums[3] > 0.f ? sums[2] / sums[3] : 0.f;  // acc
+  stats[5] = sums[3];
+  stats[6] = lsce * inv_ntokens;
+  stats[7] = 0.f;
+}
+
+}  // namespace dn
+
+namespace {
+
+inline int64_t r64(int64_t n) { return (n + 63) / 64 * 64; }
+inline int64_t take(int64_t& cur, int64_t n) {
+  const int64_t o = cur;
+  cur += r64(n);
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------ parameter layout
+struct WaveP {
+  int cin, cout, S, L;
+  int64_t init_W, init_b, conv_W, conv_b, res_W, res_b, skip_W, skip_b, final_W, final_b;  // elements in master/work/grads
+  int64_t t_init, t_conv, t_res, t_skip, t_final;                                          // elements in the transposed region
+  int64_t skip_bsum;                                                                       // floats in the derived-fp32 region
+};
+
+// The transformer's parameters are stored LAYER-major ([layer][qkv_W, out_W, ffin_W, ffin_b, ffconv_W, ffconv_b, ffout_W,
+// ffout_b, g1, g2]) so that the gradients of a layer are one contiguous range that is complete -- and can enter the
+// all-reduce -- as soon as that layer's backward has run.  X(l) = element offset of tensor X of layer l.
+struct TfP {
+  int dim, depth, heads, dim_head, inner;
+  int64_t layer0, layer_stride;
+  int64_t o_qkv, o_out, o_ffin, o_ffin_b, o_ffconv, o_ffconv_b, o_ffout, o_ffout_b, o_g1, o_g2;
+  int64_t pred_gamma, pred_W;
+  int64_t t_qkv, t_out, t_ffin, t_ffconv, t_ffout, t_pred;
+  int64_t qkv_W(int l) const { return layer0 + l * layer_stride + o_qkv; }
+  int64_t out_W(int l) const { return layer0 + l * layer_stride + o_out; }
+  int64_t ffin_W(int l) const { return layer0 + l * layer_stride + o_ffin; }
+  int64_t ffin_b(int l) const { return layer0 + l * layer_stride + o_ffin_b; }
+  int64_t ffconv_W(int l) const { return layer0 + l * layer_stride + o_ffconv; }
+  int64_t ffconv_b(int l) const { return layer0 + l * layer_stride + o_ffconv_b; }
+  int64_t ffout_W(int l) const { return layer0 + l * layer_stride + o_ffout; }
+  int64_t ffout_b(int l) const { return layer0 + l * layer_stride + o_ffout_b; }
+  int64_t g1(int l) const { return layer0 + l * layer_stride + o_g1; }
+  int64_t g2(int l) const { return layer0 + l * layer_stride + o_g2; }
+};
+
+void layout_wave(WaveP& w, int64_t& cur, int64_t& tcur, int64_t& fcur) {
+  const int64_t cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), S = w.S, L = w.L;
+  w.init_W = take(cur, 3 * cn * cinp); w.init_b = take(cur, cp);
+  w.conv_W = take(cur, S * L * 3 * cn * cp); w.conv_b = take(cur, S * L * cp);
+  w.res_W = take(cur, S * L * cn * cp); w.res_b = take(cur, S * L * cp);
+  w.skip_W = take(cur, L * cn * cp); w.skip_b = take(cur, L * cp);
+  w.final_W = take(cur, cn * cp); w.final_b = take(cur, cp);
+  w.t_init = take(tcur, 3 * (int64_t)padn(cinp) * cp);
+  w.t_conv = take(tcur, S * L * 3 * (int64_t)padn(cp) * cp);
+  w.t_res = take(tcur, S * L * (int64_t)padn(cp) * cp);
+  w.t_skip = take(tcur, L * (int64_t)padn(cp) * cp);
+  w.t_final = take(tcur, (int64_t)padn(cp) * cp);
+  w.skip_bsum = take(fcur, cp);
+}
+
+void layout_tf(TfP& w, int64_t& cur, int64_t& tcur) {
+  const int64_t D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner), d = w.depth;
+  int64_t o = 0;
+  w.o_qkv = take(o, padn(3 * hd) * Dp); w.o_out = take(o, Dn * hd);
+  w.o_ffin = take(o, 2 * ip * Dp); w.o_ffin_b = take(o, 2 * ip);
+  w.o_ffconv = take(o, 3 * in_n * ip); w.o_ffconv_b = take(o, ip);
+  w.o_ffout = take(o, Dn * ip); w.o_ffout_b = take(o, Dp);
+  w.o_g1 = take(o, D); w.o_g2 = take(o, D);
+  w.layer_stride = o;
+  w.layer0 = take(cur, d * o);
+  w.pred_gamma = take(cur, D);
+  w.pred_W = take(cur, Dn * Dp);
+  w.t_qkv = take(tcur, d * (int64_t)padn(Dp) * 3 * hd);
+  w.t_out = take(tcur, d * (int64_t)padn(hd) * Dp);
+  w.t_ffin = take(tcur, d * (int64_t)padn(Dp) * 2 * ip);
+  w.t_ffconv = take(tcur, d * 3 * (int64_t)padn(ip) * ip);
+  w.t_ffout = take(tcur, d * (int64_t)padn(ip) * Dp);
+  w.t_pred = take(tcur, (int64_t)padn(Dp) * Dp);
+}
+
+}  // namespace
+
+struct DnVaeTrain {
+  DnVaeConfig cfg;
+  int n_wave;
+  WaveP enc[4], dec[4];
+  TfP tf;
+  int64_t lm_W, lm_b, t_lm;
+  int64_t n_params;   // elements of master / work / grads
+  int64_t n_trans;    // elements (arithmetic dtype) of the transposed region of aux
+  int64_t n_fderived; // floats of the derived-fp32 region of aux (behind the transposed region)
+  float* master;
+  void* work;
+  char* aux;
+  float* grads;
+};
+
+namespace {
+
+struct Ctx {
+  const DnVaeTrain* m;
+  int dtype, es, B, T, M;
+  hipStream_t s;
+  void* wg_scratch;     // weight-gradient operands + partial sums
+  float* red_scratch;   // column-sum / norm-backward partials
+  const void* W(int64_t off) const { return static_cast<const char*>(m->work) + off * es; }
+  const float* P(int64_t off) const { return m->master + off; }       // fp32 vectors (biases, gammas)
+  float* G(int64_t off) const { return m->grads + off; }
+  const void* Wt(int64_t off) const { return m->aux + off * es; }
+  float* F(int64_t off) const { return reinterpret_cast<float*>(m->aux + r64(m->n_trans) * es) + off; }
+};
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct WgPlan {
+  int Tp, k_slices, chunk, rows_w, N;
+  int64_t cols_total;
+  size_t b_dyT, b_xT, b_part;
+  size_t total() const { return b_dyT + b_xT + b_part + 768; }
+};
+
+WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, int es) {
+  WgPlan p;
+  p.Tp = round_up(T + max_shift, 64);
+  p.rows_w = padn(cin);
+  p.N = n_taps * p.rows_w;
+  const int64_t cols = (int64_t)B * p.Tp;
+  const int64_t tiles = (int64_t)((cout + 255) / 256) * ((p.N + 255) / 256);
+  int ks = 1;
+  while (ks < 64 && tiles * ks < 256 && cols / (ks * 2) >= 256) ks *= 2;  // fill the chip; K-slices of >= 4 K-tiles
+  p.k_slices = ks;
+  p.cols_total = (cols + (int64_t)64 * ks - 1) / ((int64_t)64 * ks) * ((int64_t)64 * ks);
+  p.chunk = (int)(p.cols_total / ks);
+  p.b_dyT = ((size_t)ks * cout * p.chunk * es + 255) & ~size_t(255);
+  p.b_xT = ((size_t)ks * p.N * p.chunk * es + 255) & ~size_t(255);
+  p.b_part = (size_t)ks * cout * p.N * 4;
+  return p;
+}
+
+struct WgTap { const void* x; int ldx; int shift; };
+
+template <typename T>
+void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int front, const WgPlan& pl, void* dst, int rows, int rows_total,
+                             int row0, hipStream_t s) {
+  dim3 grid((unsigned)((pl.cols_total + 63) / 64), (unsigned)((rows + 63) / 64));
+  hipLaunchKernelGGL((dn::transpose_slices_kernel<T>), grid, dim3(256), 0, s, static_cast<const T*>(src), ld, B, Tn, C, front, pl.Tp,
+                     pl.cols_total, static_cast<T*>(dst), rows, rows_total, row0, pl.chunk);
+}
+
+// grad[tap][Np][Kp] += dY^T . shift_tap(X_tap); dY [M, lddy] (cout valid columns), X_tap [M, ldx] (cin valid columns)
+int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad) {
+  int max_shift = 0;
+  for (int j = 0; j < n_taps; ++j) max_shift = taps[j].shift > max_shift ? taps[j].shift : max_shift;
+  const WgPlan pl = plan_wgrad(cin, cout, n_taps, max_shift, c.B, c.T, c.es);
+  char* base = static_cast<char*>(c.wg_scratch);
+  void* dyT = base;
+  void* xT = base + pl.b_dyT;
+  float* part = reinterpret_cast<float*>(base + pl.b_dyT + pl.b_xT);
+  if (c.es == 2) {
+    launch_transpose_slices<uint16_t>(dy, lddy, c.B, c.T, cout, 0, pl, dyT, cout, cout, 0, c.s);
+    for (int j = 0; j < n_taps; ++j)
+      launch_transpose_slices<uint16_t>(taps[j].x, taps[j].ldx, c.B, c.T, cin, taps[j].shift, pl, xT, pl.rows_w, pl.N, j * pl.rows_w, c.s);
+  } else {
+    launch_transpose_slices<float>(dy, lddy, c.B, c.T, cout, 0, pl, dyT, cout, cout, 0, c.s);
+    for (int j = 0; j < n_taps; ++j)
+      launch_transpose_slices<float>(taps[j].x, taps[j].ldx, c.B, c.T, cin, taps[j].shift, pl, xT, pl.rows_w, pl.N, j * pl.rows_w, c.s);
+  }
+  DN_CHECK_LAUNCH("weight_grad transposes");
+  DnGemmParams p = gemm_base(c.dtype, cout, pl.N, pl.chunk, cout);
+  p.groups = pl.k_slices;
+  p.terms[0].A = dyT; p.terms[0].lda = pl.chunk; p.terms[0].a_gstride = (int64_t)cout * pl.chunk;
+  p.terms[0].W = xT; p.terms[0].w_gstride = (int64_t)pl.N * pl.chunk;
+  p.out = part; p.ldo = pl.N; p.out_dtype = DN_F32; p.out_gstride = (int64_t)cout * pl.N;
+  DN_TRY(dn_conv_gemm(&p, c.s));
+  return dn_wgrad_reduce(part, pl.k_slices, cout, pl.N, pl.rows_w, n_taps, grad, padn(cout), padk(cin), c.s);
+}
+
+int bias_grad(const Ctx& c, const void* dy, int ld, int dtype, int groups, int rows_per_group, int C, float* grad, int out_ld) {
+  return dn_colsum(dy, ld, dtype, groups, rows_per_group, C, grad, out_ld, 1.0f, 1, c.red_scratch, c.s);
+}
+
+// ------------------------------------------------------------------------------------------ WaveNet
+struct WaveSave {  // activations kept by the forward
+  void *h0, *res, *hpre, *out, *sk;  // res / hpre / out: [S][L][M][cp]
+};
+struct WaveTmp {  // backward temporaries, shared by all WaveNets of a model (sized for the widest)
+  void *d_sk, *d_out0, *d_out1, *d_h, *d_h0;
+};
+
+WaveSave plan_wave_save(const WaveP& w, int M, int es, Arena& ar) {
+  const size_t one = (size_t)M * padk(w.cout) * es, all = one * w.S * w.L;
+  WaveSave b;
+  b.h0 = ar.take(one); b.res = ar.take(all); b.hpre = ar.take(all); b.out = ar.take(all); b.sk = ar.take(one);
+  return b;
+}
+
+// `fin` carries the destination of the final 1x1 conv (out, ldo, out_dtype, N).
+int wave_forward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& sv, DnGemmParams fin) {
+  const int dtype = c.dtype, es = c.es, M = c.M, T = c.T;
+  const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.L, S = w.S;
+  const size_t mat = (size_t)cn * cp;
+  const int64_t plane = (int64_t)M * cp;
+  {  // init conv k=3 (:1014,1029)
+    DnGemmParams p = gemm_base(dtype, M, cp, cinp, T);
+    p.n_terms = 3;
+    for (int j = 0; j < 3; ++j) {
+      p.terms[j].A = in; p.terms[j].lda = cinp; p.terms[j].shift = 2 - j;
+      p.terms[j].W = eoff(c.W(w.init_W), (size_t)j * cn * cinp, es);
+    }
+    p.bias = c.P(w.init_b); p.out = sv.h0; p.ldo = cp;
+    DN_TRY(dn_conv_gemm(&p, c.s));
+  }
+  for (int st = 0; st < S; ++st) {
+    const void* in_s = st == 0 ? sv.h0 : eoff(sv.out, (size_t)(st - 1) * L * plane, es);
+    const int64_t a_gs = st == 0 ? 0 : plane;
+    void* res_s = eoff(sv.res, (size_t)st * L * plane, es);
+    void* h_s = eoff(sv.hpre, (size_t)st * L * plane, es);
+    void* out_s = eoff(sv.out, (size_t)st * L * plane, es);
+    {  // res_conv 1x1 (:510,521)
+      DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+      p.groups = L;
+      p.terms[0].A = in_s; p.terms[0].lda = cp; p.terms[0].a_gstride = a_gs;
+      p.terms[0].W = eoff(c.W(w.res_W), (size_t)st * L * mat, es); p.terms[0].w_gstride = (int64_t)mat;
+      p.bias = c.P(w.res_b) + (size_t)st * L * cp; p.bias_gstride = cp;
+      p.out = res_s; p.ldo = cp; p.out_gstride = plane;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    {  // dilated conv k=3, pre-activation kept (:509,523)
+      DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+      p.groups = L;
+      p.n_terms = 3;
+      for (int j = 0; j < 3; ++j) {
+        p.terms[j].A = in_s; p.terms[j].lda = cp; p.terms[j].a_gstride = a_gs;
+        p.terms[j].shift = 2 - j; p.terms[j].shift_by_group = 1;
+        p.terms[j].W = eoff(c.W(w.conv_W), ((size_t)st * L * 3 + j) * mat, es); p.terms[j].w_gstride = (int64_t)(3 * mat);
+      }
+      p.bias = c.P(w.conv_b) + (size_t)st * L * cp; p.bias_gstride = cp;
+      p.out = h_s; p.ldo = cp; p.out_gstride = plane;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    // tanh(h) * sigmoid(h) + res (:528-530), all L blocks in one pass
+    DN_TRY(dn_gate_forward(h_s, res_s, out_s, dtype, L * M, cp, T, nullptr, 0, 0, c.s));
+  }
+  const void* last = eoff(sv.out, (size_t)(S - 1) * L * plane, es);
+  {  // sum over blocks of skip_conv(out_i) (:511,534,617)
+    DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+    p.n_terms = L;
+    for (int i = 0; i < L; ++i) {
+      p.terms[i].A = eoff(last, (size_t)i * plane, es); p.terms[i].lda = cp;
+      p.terms[i].W = eoff(c.W(w.skip_W), (size_t)i * mat, es);
+    }
+    p.bias = c.F(w.skip_bsum); p.out = sv.sk; p.ldo = cp;
+    DN_TRY(dn_conv_gemm(&p, c.s));
+  }
+  fin.dtype = dtype; fin.M = M; fin.K = cp; fin.T = T; fin.groups = 1; fin.n_terms = 1;
+  fin.terms[0].A = sv.sk; fin.terms[0].lda = cp; fin.terms[0].W = c.W(w.final_W);
+  fin.bias = c.P(w.final_b);
+  return dn_conv_gemm(&fin, c.s);
+}
+
+// d_y: gradient w.r.t. the final conv's output, arithmetic dtype [M, padk(cout)] (pad columns zero).
+// d_x (optional): gradient w.r.t. the WaveNet's input, [M, padk(cin)] in d_x_dtype.
+int wave_backward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& sv, const void* d_y, void* d_x, int d_x_dtype,
+                  const WaveTmp& tb) {
+  const int dtype = c.dtype, es = c.es, M = c.M, T = c.T;
+  const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.L, S = w.S;
+  const size_t mat = (size_t)cn * cp, tmat = (size_t)padn(cp) * cp;
+  const int64_t plane = (int64_t)M * cp;
+  // final conv
+  {
+    WgTap tap{sv.sk, cp, 0};
+    DN_TRY(weight_grad(c, &tap, 1, w.cout, d_y, cp, w.cout, c.G(w.final_W)));
+    DN_TRY(bias_grad(c, d_y, cp, dtype, 1, M, cp, c.G(w.final_b), 0));
+    DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+    p.terms[0].A = d_y; p.terms[0].lda = cp; p.terms[0].W = c.Wt(w.t_final);
+    p.out = tb.d_sk; p.ldo = cp;
+    DN_TRY(dn_conv_gemm(&p, c.s));
+  }
+  const void* last = eoff(sv.out, (size_t)(S - 1) * L * plane, es);
+  {  // skip convs of the last stack: one weight-gradient contraction for all L blocks (dY shared), one bias gradient
+    WgTap taps[DN_MAX_TERMS];
+    for (int i = 0; i < L; ++i) taps[i] = WgTap{eoff(last, (size_t)i * plane, es), cp, 0};
+    DN_TRY(weight_grad(c, taps, L, w.cout, tb.d_sk, cp, w.cout, c.G(w.skip_W)));
+    // every skip bias sees the same gradient: column sums once, then added to each of the L rows
+    float* tmp = c.red_scratch + 1024 * 1024;  // behind the partial sums of dn_colsum
+    DN_TRY(dn_colsum(tb.d_sk, cp, dtype, 1, M, cp, tmp, 0, 1.0f, 0, c.red_scratch, c.s));
+    DN_TRY(dn_add_broadcast(tmp, c.G(w.skip_b), cp, cp, L, c.s));
+    DnGemmParams p = gemm_base(dtype, M, cp, cp, T);  // d out_i = d sk . W_skip_i
+    p.groups = L;
+    p.terms[0].A = tb.d_sk; p.terms[0].lda = cp; p.terms[0].a_gstride = 0;
+    p.terms[0].W = c.Wt(w.t_skip); p.terms[0].w_gstride = (int64_t)tmat;
+    p.out = tb.d_out0; p.ldo = cp; p.out_gstride = plane;
+    DN_TRY(dn_conv_gemm(&p, c.s));
+  }
+  void* d_out = tb.d_out0;
+  void* d_next = tb.d_out1;
+  for (int st = S - 1; st >= 0; --st) {
+    const void* in_s = st == 0 ? sv.h0 : eoff(sv.out, (size_t)(st - 1) * L * plane, es);
+    const void* h_s = eoff(sv.hpre, (size_t)st * L * plane, es);
+    // d h = d out * gate'(h) (:528)
+    DN_TRY(dn_gate_backward(d_out, h_s, tb.d_h, dtype, L * M, cp, T, nullptr, 0, 0, nullptr, 0, c.s));
+    DN_TRY(bias_grad(c, d_out, cp, dtype, L, M, cp, c.G(w.res_b) + (size_t)st * L * cp, cp));
+    DN_TRY(bias_grad(c, tb.d_h, cp, dtype, L, M, cp, c.G(w.conv_b) + (size_t)st * L * cp, cp));
+    for (int i = 0; i < L; ++i) {
+      const void* x_i = st == 0 ? in_s : eoff(in_s, (size_t)i * plane, es);
+      WgTap r{x_i, cp, 0};
+      DN_TRY(weight_grad(c, &r, 1, w.cout, eoff(d_out, (size_t)i * plane, es), cp, w.cout, c.G(w.res_W) + ((size_t)st * L + i) * mat));
+      WgTap taps[3];
+      for (int j = 0; j < 3; ++j) taps[j] = WgTap{x_i, cp, (2 - j) << i};
+      DN_TRY(weight_grad(c, taps, 3, w.cout, eoff(tb.d_h, (size_t)i * plane, es), cp, w.cout,
+                         c.G(w.conv_W) + ((size_t)st * L + i) * 3 * mat));
+    }
+    {  // d in_i = d out_i . W_res_i + sum_j d h_i[t + (2-j) 2^i] . W_conv_i,j   (one grouped contraction, 4 terms)
+      DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
+      p.groups = L;
+      p.n_terms = 4;
+      p.terms[0].A = d_out; p.terms[0].lda = cp; p.terms[0].a_gstride = plane;
+      p.terms[0].W = eoff(c.Wt(w.t_res), (size_t)st * L * tmat, es); p.terms[0].w_gstride = (int64_t)tmat;
+      for (int j = 0; j < 3; ++j) {
+        DnGemmTerm& t = p.terms[1 + j];
+        t.A = tb.d_h; t.lda = cp; t.a_gstride = plane;
+        t.shift = -(2 - j); t.shift_by_group = 1;
+        t.W = eoff(c.Wt(w.t_conv), ((size_t)st * L * 3 + j) * tmat, es); t.w_gstride = (int64_t)(3 * tmat);
+      }
+      p.out = d_next; p.ldo = cp; p.out_gstride = plane;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    void* t = d_out; d_out = d_next; d_next = t;
+  }
+  // stack 0 fed one tensor to all blocks (:570-571): its gradient is the sum over blocks
+  DN_TRY(dn_sum_groups(d_out, plane, L, tb.d_h0, dtype, plane, c.s));
+  {
+    WgTap taps[3];
+    for (int j = 0; j < 3; ++j) taps[j] = WgTap{in, cinp, 2 - j};
+    DN_TRY(weight_grad(c, taps, 3, w.cin, tb.d_h0, cp, w.cout, c.G(w.init_W)));
+    DN_TRY(bias_grad(c, tb.d_h0, cp, dtype, 1, M, cp, c.G(w.init_b), 0));
+  }
+  if (!d_x) return DN_OK;
+  DnGemmParams p = gemm_base(dtype, M, cinp, cp, T);
+  p.n_terms = 3;
+  for (int j = 0; j < 3; ++j) {
+    p.terms[j].A = tb.d_h0; p.terms[j].lda = cp; p.terms[j].shift = -(2 - j);
+    p.terms[j].W = eoff(c.Wt(w.t_init), (size_t)j * padn(cinp) * cp, es);
+  }
+  p.out = d_x; p.ldo = cinp; p.out_dtype = d_x_dtype;
+  return dn_conv_gemm(&p, c.s);
+}
+
+// ------------------------------------------------------------------------------------------ transformer (learned-gamma norms)
+struct TfSave {  // per layer l: x [depth+1][M][Dp] fp32, xmid [depth][M][Dp] fp32, and the operand copies
+  float *x, *xmid, *lse;
+  void *xn1, *qkv, *ao, *xn2, *pre, *gg, *fc, *xnp;
+};
+struct TfTmp {
+  float* dx;       // [M][Dp] fp32 residual-stream gradient (updated in place)
+  void *dx_act, *d_fc, *d_gg, *d_pre, *d_xn, *d_ao, *d_qkv;
+  float* delta;
+};
+
+TfSave plan_tf_save(const TfP& w, int B, int T, int es, Arena& ar) {
+  const size_t M = (size_t)B * T, Dp = padk(w.dim), hd = w.heads * w.dim_head, ip = padk(w.inner), d = w.depth;
+  TfSave s;
+  s.x = (float*)ar.take((d + 1) * M * Dp * 4);
+  s.xmid = (float*)ar.take(d * M * Dp * 4);
+  s.lse = (float*)ar.take(d * (size_t)B * w.heads * T * 4);
+  s.xn1 = ar.take(d * M * Dp * es); s.qkv = ar.take(d * M * 3 * hd * es); s.ao = ar.take(d * M * hd * es);
+  s.xn2 = ar.take(d * M * Dp * es); s.pre = ar.take(d * M * 2 * ip * es); s.gg = ar.take(d * M * ip * es);
+  s.fc = ar.take(d * M * ip * es); s.xnp = ar.take(M * Dp * es);
+  return s;
+}
+
+TfTmp plan_tf_tmp(const TfP& w, int B, int T, int es, Arena& ar) {
+  const size_t M = (size_t)B * T, Dp = padk(w.dim), hd = w.heads * w.dim_head, ip = padk(w.inner);
+  TfTmp t;
+  t.dx = (float*)ar.take(M * Dp * 4);
+  t.dx_act = ar.take(M * Dp * es); t.d_fc = ar.take(M * ip * es); t.d_gg = ar.take(M * ip * es); t.d_pre = ar.take(M * 2 * ip * es);
+  t.d_xn = ar.take(M * Dp * es); t.d_ao = ar.take(M * hd * es); t.d_qkv = ar.take(M * 3 * hd * es);
+  t.delta = (float*)ar.take((size_t)B * w.heads * T * 4);
+  return t;
+}
+
+// x[0] holds the input residual stream; `pred` receives to_pred's output (fp32 [M, pred_ld]).
+int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave& sv, float* pred, int pred_ld) {
+  const int dtype = c.dtype, es = c.es, B = c.B, T = c.T, M = c.M;
+  const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
+  const size_t MD = (size_t)M * Dp;
+  for (int l = 0; l < w.depth; ++l) {
+    float* x = sv.x + l * MD;
+    float* xmid = sv.xmid + l * MD;
+    float* xnext = sv.x + (l + 1) * MD;
+    void* xn1 = eoff(sv.xn1, l * MD, es);
+    void* qkv = eoff(sv.qkv, (size_t)l * M * 3 * hd, es);
+    void* ao = eoff(sv.ao, (size_t)l * M * hd, es);
+    void* xn2 = eoff(sv.xn2, l * MD, es);
+    void* pre = eoff(sv.pre, (size_t)l * M * 2 * ip, es);
+    void* gg = eoff(sv.gg, (size_t)l * M * ip, es);
+    void* fc = eoff(sv.fc, (size_t)l * M * ip, es);
+    DN_TRY(dn_rmsnorm(x, Dp, xn1, Dp, dtype, M, D, T, c.P(w.g1(l)), nullptr, 0, 0, c.s));
+    {  // to_q ; to_kv (:930-931,945)
+      DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
+      p.terms[0].A = xn1; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.qkv_W(l));
+      p.out = qkv; p.ldo = 3 * hd;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    {
+      DnAttnParams a;
+      memset(&a, 0, sizeof(a));
+      a.q = qkv; a.k = eoff(qkv, hd, es); a.v = eoff(qkv, 2 * hd, es); a.out = ao;
+      a.ldq = a.ldk = a.ldv = 3 * hd; a.ldo = hd;
+      a.B = B; a.T = T; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = lengths;
+      a.scale = 1.0f / sqrtf((float)w.dim_head);
+      a.lse = sv.lse + (size_t)l * B * w.heads * T;
+      DN_TRY(dn_attention(&a, c.s));
+    }
+    {  // to_out + residual (:932,692)
+      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
+      p.terms[0].A = ao; p.terms[0].lda = hd; p.terms[0].W = c.W(w.out_W(l));
+      p.epilogue = DN_EPI_RESADD; p.res = x; p.ldr = Dp; p.out = xmid; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    DN_TRY(dn_rmsnorm(xmid, Dp, xn2, Dp, dtype, M, D, T, c.P(w.g2(l)), nullptr, 0, 0, c.s));
+    {  // Linear(D -> 2*inner), packed [8 value ; 8 gate] columns, pre-activation kept (:899)
+      DnGemmParams p = gemm_base(dtype, M, 2 * ip, Dp, T);
+      p.terms[0].A = xn2; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.ffin_W(l));
+      p.bias = c.P(w.ffin_b(l)); p.out = pre; p.ldo = 2 * ip;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    DN_TRY(dn_geglu_forward(pre, gg, dtype, M, ip, c.s));
+    {  // CausalConv1d(inner, inner, 3) (:894)
+      DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
+      p.n_terms = 3;
+      for (int j = 0; j < 3; ++j) {
+        p.terms[j].A = gg; p.terms[j].lda = ip; p.terms[j].shift = 2 - j;
+        p.terms[j].W = eoff(c.W(w.ffconv_W(l)), (size_t)j * in_n * ip, es);
+      }
+      p.bias = c.P(w.ffconv_b(l)); p.out = fc; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+    {  // Linear(inner -> D) + residual (:902,704)
+      DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
+      p.terms[0].A = fc; p.terms[0].lda = ip; p.terms[0].W = c.W(w.ffout_W(l));
+      p.bias = c.P(w.ffout_b(l));
+      p.epilogue = DN_EPI_RESADD; p.res = xmid; p.ldr = Dp; p.out = xnext; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    }
+  }
+  // to_pred = RMSNorm(gamma) + Linear(D, D, no bias) (:676-679)
+  DN_TRY(dn_rmsnorm(sv.x + w.depth * MD, Dp, sv.xnp, Dp, dtype, M, D, T, c.P(w.pred_gamma), nullptr, 0, 0, c.s));
+  DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
+  p.terms[0].A = sv.xnp; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.pred_W);
+  p.out = pred; p.ldo = pred_ld; p.out_dtype = DN_F32;
+  return dn_conv_gemm(&p, c.s);
+}
+
+// data gradient of a Linear: out[M, Kp] = dY[M, K = padk(N)] . W  (Wt = the transposed packed weight [padn(Kp)][padk(N)])
+int linear_dgrad(const Ctx& c, const void* dy, int lddy, int Kc, const void* wt, void* out, int n_out, int out_dtype) {
+  DnGemmParams p = gemm_base(c.dtype, c.M, n_out, Kc, c.T);
+  p.terms[0].A = dy; p.terms[0].lda = lddy; p.terms[0].W = wt;
+  p.out = out; p.ldo = n_out; p.out_dtype = out_dtype;
+  return dn_conv_gemm(&p, c.s);
+}
+
+// to_pred backward: d_pred (arithmetic dtype [M, Dp]) -> tb.dx / tb.dx_act = gradient w.r.t. x[depth]
+int tf_backward_head(const Ctx& c, const TfP& w, const TfSave& sv, const void* d_pred, const TfTmp& tb) {
+  const int D = w.dim, Dp = padk(D);
+  const size_t MD = (size_t)c.M * Dp;
+  WgTap tap{sv.xnp, Dp, 0};
+  DN_TRY(weight_grad(c, &tap, 1, D, d_pred, Dp, D, c.G(w.pred_W)));
+  DN_TRY(linear_dgrad(c, d_pred, Dp, Dp, c.Wt(w.t_pred), tb.d_xn, Dp, c.dtype));
+  return dn_rmsnorm_backward(sv.x + w.depth * MD, Dp, tb.d_xn, Dp, c.dtype, c.B, c.T, D, c.P(w.pred_gamma), nullptr, 0, 0, nullptr, tb.dx,
+                             tb.dx_act, c.dtype, Dp, c.G(w.pred_gamma), nullptr, 0, c.red_scratch, c.s);
+}
+
+// one layer: tb.dx / tb.dx_act hold d x[l+1] on entry, d x[l] on exit
+int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths, const TfSave& sv, const TfTmp& tb) {
+  const int dtype = c.dtype, es = c.es, B = c.B, T = c.T, M = c.M;
+  const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
+  const size_t MD = (size_t)M * Dp;
+  const float* x = sv.x + l * MD;
+  const float* xmid = sv.xmid + l * MD;
+  const void* xn1 = eoff(sv.xn1, l * MD, es);
+  const void* qkv = eoff(sv.qkv, (size_t)l * M * 3 * hd, es);
+  const void* ao = eoff(sv.ao, (size_t)l * M * hd, es);
+  const void* xn2 = eoff(sv.xn2, l * MD, es);
+  const void* pre = eoff(sv.pre, (size_t)l * M * 2 * ip, es);
+  const void* gg = eoff(sv.gg, (size_t)l * M * ip, es);
+  const void* fc = eoff(sv.fc, (size_t)l * M * ip, es);
+  {  // Linear(inner -> D) (:902)
+    WgTap tap{fc, ip, 0};
+    DN_TRY(weight_grad(c, &tap, 1, w.inner, tb.dx_act, Dp, D, c.G(w.ffout_W(l))));
+    DN_TRY(bias_grad(c, tb.dx, Dp, DN_F32, 1, M, Dp, c.G(w.ffout_b(l)), 0));
+    DN_TRY(linear_dgrad(c, tb.dx_act, Dp, Dp, eoff(c.Wt(w.t_ffout), (size_t)l * padn(ip) * Dp, es), tb.d_fc, ip, dtype));
+  }
+  {  // CausalConv1d(inner, inner, 3) (:894)
+    WgTap taps[3];
+    for (int j = 0; j < 3; ++j) taps[j] = WgTap{gg, ip, 2 - j};
+    DN_TRY(weight_grad(c, taps, 3, w.inner, tb.d_fc, ip, w.inner, c.G(w.ffconv_W(l))));
+    DN_TRY(bias_grad(c, tb.d_fc, ip, dtype, 1, M, ip, c.G(w.ffconv_b(l)), 0));
+    DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
+    p.n_terms = 3;
+    for (int j = 0; j < 3; ++j) {
+      p.terms[j].A = tb.d_fc; p.terms[j].lda = ip; p.terms[j].shift = -(2 - j);
+      p.terms[j].W = eoff(c.Wt(w.t_ffconv), ((size_t)l * 3 + j) * padn(ip) * ip, es);
+    }
+    p.out = tb.d_gg; p.ldo = ip;
+    DN_TRY(dn_conv_gemm(&p, c.s));
+  }
+  DN_TRY(dn_geglu_backward(tb.d_gg, pre, tb.d_pre, dtype, M, ip, c.s));  // (:881-884)
+  {  // Linear(D -> 2*inner) (:899), packed columns
+    WgTap tap{xn2, Dp, 0};
+    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_pre, 2 * ip, 2 * ip, c.G(w.ffin_W(l))));
+    DN_TRY(bias_grad(c, tb.d_pre, 2 * ip, dtype, 1, M, 2 * ip, c.G(w.ffin_b(l)), 0));
+    DN_TRY(linear_dgrad(c, tb.d_pre, 2 * ip, 2 * ip, eoff(c.Wt(w.t_ffin), (size_t)l * padn(Dp) * 2 * ip, es), tb.d_xn, Dp, dtype));
+  }
+  // ff_norm (:703): d xmid = d x[l+1] + norm'(xmid) d xn2
+  DN_TRY(dn_rmsnorm_backward(xmid, Dp, tb.d_xn, Dp, dtype, B, T, D, c.P(w.g2(l)), nullptr, 0, 0, tb.dx, tb.dx, tb.dx_act, dtype,
+                             Dp, c.G(w.g2(l)), nullptr, 0, c.red_scratch, c.s));
+  {  // to_out (:932)
+    WgTap tap{ao, hd, 0};
+    DN_TRY(weight_grad(c, &tap, 1, hd, tb.dx_act, Dp, D, c.G(w.out_W(l))));
+    DN_TRY(linear_dgrad(c, tb.dx_act, Dp, Dp, eoff(c.Wt(w.t_out), (size_t)l * padn(hd) * Dp, es), tb.d_ao, hd, dtype));
+  }
+  {  // Attend (:299-343)
+    DnAttnBwdParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = qkv; a.k = eoff(qkv, hd, es); a.v = eoff(qkv, 2 * hd, es); a.out = ao; a.dout = tb.d_ao;
+    a.dq = tb.d_qkv; a.dk = eoff(tb.d_qkv, hd, es); a.dv = eoff(tb.d_qkv, 2 * hd, es);
+    a.ldq = a.ldk = a.ldv = 3 * hd; a.ldo = hd; a.lddo = hd; a.lddq = a.lddk = a.lddv = 3 * hd;
+    a.B = B; a.T = T; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = lengths;
+    a.scale = 1.0f / sqrtf((float)w.dim_head);
+    a.lse = sv.lse + (size_t)l * B * w.heads * T; a.delta = tb.delta;
+    DN_TRY(dn_attention_backward(&a, c.s));
+  }
+  {  // to_q ; to_kv (:930-931)
+    WgTap tap{xn1, Dp, 0};
+    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_qkv, 3 * hd, 3 * hd, c.G(w.qkv_W(l))));
+    DN_TRY(linear_dgrad(c, tb.d_qkv, 3 * hd, 3 * hd, eoff(c.Wt(w.t_qkv), (size_t)l * padn(Dp) * 3 * hd, es), tb.d_xn, Dp, dtype));
+  }
+  // attn_norm (:691)
+  return dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, c.P(w.g1(l)), nullptr, 0, 0, tb.dx, tb.dx, tb.dx_act, dtype, Dp,
+                             c.G(w.g1(l)), nullptr, 0, c.red_scratch, c.s);
+}
+
+// ------------------------------------------------------------------------------------------ workspace plan
+struct VaePlan {
+  void* feat_act;
+  void* enc_mid[4];   // encoder WaveNet outputs that feed the next one (arithmetic dtype)
+  WaveSave enc[4], dec[4];
+  float *params, *z, *kl_rows;
+  void* z_act;
+  void* dec_mid[4];
+  TfSave tf;
+  float *rec, *logits, *lsce_rows, *sq_rows, *sums;
+  void *rec_act, *dlogits;
+  // backward
+  WaveTmp wt;
+  TfTmp tt;
+  float* d_rec;
+  void *d_rec_act, *d_mid0, *d_mid1, *d_params;
+  float* dz;
+  void* wg_scratch;
+  float* red_scratch;
+};
+
+size_t max_wgrad_bytes(const DnVaeTrain* m, int B, int T) {
+  const int es = esize(m->cfg.dtype);
+  size_t mx = 0;
+  auto upd = [&](int cin, int cout, int taps, int max_shift) {
+    const size_t b = plan_wgrad(cin, cout, taps, max_shift, B, T, es).total();
+    mx = b > mx ? b : mx;
+  };
+  for (int n = 0; n < m->n_wave; ++n)
+    for (const WaveP* w : {&m->enc[n], &m->dec[n]}) {
+      upd(w->cin, w->cout, 3, 2);
+      upd(w->cout, w->cout, 3, 2 << (w->L - 1));
+      upd(w->cout, w->cout, w->L, 0);
+    }
+  const TfP& t = m->tf;
+  const int hd = t.heads * t.dim_head, ip = padk(t.inner);
+  upd(t.dim, 3 * hd, 1, 0); upd(hd, t.dim, 1, 0); upd(t.dim, 2 * ip, 1, 0); upd(t.inner, t.inner, 3, 2); upd(t.inner, t.dim, 1, 0);
+  upd(t.dim, t.dim, 1, 0); upd(t.dim, m->cfg.vocab, 1, 0);
+  return mx;
+}
+
+VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar) {
+  const int es = esize(m->cfg.dtype), D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, V = m->cfg.vocab;
+  const size_t M = (size_t)B * T;
+  VaePlan p;
+  memset(&p, 0, sizeof(p));
+  p.feat_act = ar.take(M * Dp * es);
+  int widest = 0;
+  for (int n = 0; n < m->n_wave; ++n) {
+    widest = widest > m->enc[n].cout ? widest : m->enc[n].cout;
+    widest = widest > m->dec[n].cout ? widest : m->dec[n].cout;
+    p.enc[n] = plan_wave_save(m->enc[n], (int)M, es, ar);
+    p.dec[n] = plan_wave_save(m->dec[n], (int)M, es, ar);
+    p.enc_mid[n] = ar.take(M * padk(m->enc[n].cout) * es);
+    p.dec_mid[n] = ar.take(M * padk(m->dec[n].cout) * es);
+  }
+  p.params = (float*)ar.take(M * 2 * z * 4);
+  p.z = (float*)ar.take(M * padk(z) * 4);
+  p.z_act = ar.take(M * padk(z) * es);
+  p.kl_rows = (float*)ar.take(M * 4);
+  p.tf = plan_tf_save(m->tf, B, T, es, ar);
+  p.rec = (float*)ar.take(M * Dp * 4);
+  p.rec_act = ar.take(M * Dp * es);
+  p.logits = (float*)ar.take(M * V * 4);
+  p.lsce_rows = (float*)ar.take(M * 4 * 4);
+  p.sq_rows = (float*)ar.take(M * 4);
+  p.sums = (float*)ar.take(64 * 4);
+  p.dlogits = ar.take(M * padn(V) * es);
+  const size_t wide = M * padk(widest) * es;
+  int Lmax = 1;
+  for (int n = 0; n < m->n_wave; ++n) Lmax = Lmax > m->enc[n].L ? Lmax : m->enc[n].L;
+  p.wt.d_sk = ar.take(wide); p.wt.d_out0 = ar.take(wide * Lmax); p.wt.d_out1 = ar.take(wide * Lmax); p.wt.d_h = ar.take(wide * Lmax);
+  p.wt.d_h0 = ar.take(wide);
+  p.tt = plan_tf_tmp(m->tf, B, T, es, ar);
+  p.d_rec = (float*)ar.take(M * Dp * 4);
+  p.d_rec_act = ar.take(M * Dp * es);
+  p.d_mid0 = ar.take(wide); p.d_mid1 = ar.take(wide);
+  p.d_params = ar.take(M * padk(2 * z) * es);
+  p.dz = (float*)ar.take(M * padk(z) * 4);
+  p.wg_scratch = ar.take(max_wgrad_bytes(m, B, T));
+  p.red_scratch = (float*)ar.take(((size_t)1024 * 1024 + 4096) * 4 + dn_rmsnorm_backward_scratch_bytes(B, T, D));
+  return p;
+}
+
+Ctx make_ctx(const DnVaeTrain* m, int B, int T, const VaePlan& pl, hipStream_t s) {
+  Ctx c;
+  c.m = m; c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
+  c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  return c;
+}
+
+int check_batch(const DnVaeTrain* m, const DnVaeTrainBatch* b, void* ws, size_t ws_bytes, VaePlan* pl, const char* who) {
+  DN_CHECK_ARG(m && b && ws, "%s: null argument", who);
+  DN_CHECK_ARG(m->master && m->work && m->aux && m->grads, "%s: dn_vae_train_bind has not been called", who);
+  DN_CHECK_ARG(b->feat && b->units && b->lengths && b->noise && b->stats, "%s: null batch tensor", who);
+  DN_CHECK_ARG(b->B > 0 && b->T > 2 && b->ntokens > 0, "%s: B=%d T=%d ntokens=%d", who, b->B, b->T, b->ntokens);
+  DN_CHECK_ARG(((uintptr_t)ws & 255) == 0, "%s: workspace must be 256-byte aligned", who);
+  Arena ar{(char*)ws, 0, ws_bytes};
+  *pl = plan_vae_train(m, b->B, b->T, ar);
+  if (ar.off > ws_bytes) {
+    dn_set_error("%s: workspace %zu < required %zu (dn_vae_train_workspace_bytes)", who, ws_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  return DN_OK;
+}
+
+}  // namespace
+
+// =========================================================================================== C ABI
+extern "C" int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out) {
+  DN_CHECK_ARG(cfg && out, "dn_vae_train_create: null argument");
+  DN_CHECK_ARG(cfg->n_mults >= 1 && cfg->n_mults <= 4, "dn_vae_train_create: n_mults=%d", cfg->n_mults);
+  DN_CHECK_ARG(cfg->dtype == DN_F32 || cfg->dtype == DN_BF16, "dn_vae_train_create: bad dtype");
+  DN_CHECK_ARG(cfg->dim % 8 == 0 && (cfg->heads * cfg->dim_head) % 64 == 0 && cfg->z % 4 == 0 && cfg->vocab % 4 == 0 && cfg->vocab <= 1024,
+               "dn_vae_train_create: dim %% 8, heads*dim_head %% 64, z %% 4, vocab %% 4 (<= 1024) required");
+  DN_CHECK_ARG(cfg->layers >= 1 && cfg->layers <= DN_MAX_TERMS && cfg->stacks >= 1, "dn_vae_train_create: stacks/layers");
+  DnVaeTrain* m = new (std::nothrow) DnVaeTrain();
+  DN_CHECK_ARG(m != nullptr, "dn_vae_train_create: out of host memory");
+  memset(m, 0, sizeof(*m));
+  m->cfg = *cfg;
+  m->n_wave = cfg->n_mults;
+  int64_t cur = 0, tcur = 0, fcur = 0;
+  int width = cfg->dim;
+  for (int n = 0; n < m->n_wave; ++n) {  // latent_module.py:1053-1065
+    WaveP& w = m->enc[n];
+    w.cin = width; w.cout = width / cfg->mults[n]; w.S = cfg->stacks; w.L = cfg->layers;
+    width = w.cout;
+    layout_wave(w, cur, tcur, fcur);
+  }
+  if (width != 2 * cfg->z) {
+    delete m;
+    dn_set_error("dn_vae_train_create: encoder width %d != 2*z (%d)", width, 2 * cfg->z);
+    return DN_EINVAL;
+  }
+  for (int n = 0; n < m->n_wave; ++n) {  // :1067-1081
+    WaveP& w = m->dec[n];
+    const int mult = cfg->mults[m->n_wave - 1 - n];
+    w.cout = width * mult; w.cin = n == 0 ? width / 2 : width; w.S = cfg->stacks; w.L = cfg->layers;
+    width = w.cout;
+    layout_wave(w, cur, tcur, fcur);
+  }
+  if (width != cfg->dim) {
+    delete m;
+    dn_set_error("dn_vae_train_create: decoder width %d != dim %d", width, cfg->dim);
+    return DN_EINVAL;
+  }
+  m->tf.dim = cfg->dim; m->tf.depth = cfg->depth; m->tf.heads = cfg->heads; m->tf.dim_head = cfg->dim_head;
+  m->tf.inner = (int)((double)cfg->dim * 4 * 2 / 3);
+  layout_tf(m->tf, cur, tcur);
+  const int64_t Dp = padk(cfg->dim), Vn = padn(cfg->vocab);
+  m->lm_W = take(cur, Vn * Dp); m->lm_b = take(cur, Vn);
+  m->t_lm = take(tcur, (int64_t)padn(Dp) * padk(cfg->vocab));
+  m->n_params = cur; m->n_trans = tcur; m->n_fderived = fcur;
+  *out = m;
+  return DN_OK;
+}
+
+extern "C" void dn_vae_train_destroy(DnVaeTrain* m) { delete m; }
+
+extern "C" int64_t dn_vae_train_param_count(const DnVaeTrain* m) { return m ? m->n_params : 0; }
+
+extern "C" size_t dn_vae_train_aux_bytes(const DnVaeTrain* m) {
+  return m ? (size_t)r64(m->n_trans) * esize(m->cfg.dtype) + (size_t)m->n_fderived * 4 + 256 : 0;
+}
+
+// offsets (elements) of the packed tensors inside the flat buffers, in the order of diffnorm_amd/packing.py::pack_vae_train:
+// per WaveNet (encoders, then decoders) init_W, init_b, conv_W, conv_b, res_W, res_b, skip_W, skip_b[L], final_W, final_b;
+// per transformer layer qkv_W, out_W, ffin_W, ffin_b, ffconv_W, ffconv_b, ffout_W, ffout_b, g1, g2; then pred_gamma, pred_W;
+// lm_W, lm_b.
+extern "C" int dn_vae_train_offsets(const DnVaeTrain* m, int64_t* offsets, int32_t capacity) {
+  DN_CHECK_ARG(m && offsets, "dn_vae_train_offsets: null argument");
+  const int n = 2 * m->n_wave * 10 + 10 * m->tf.depth + 2 + 2;
+  DN_CHECK_ARG(capacity >= n, "dn_vae_train_offsets: capacity %d < %d", capacity, n);
+  int k = 0;
+  auto wave = [&](const WaveP& w) {
+    for (int64_t o : {w.init_W, w.init_b, w.conv_W, w.conv_b, w.res_W, w.res_b, w.skip_W, w.skip_b, w.final_W, w.final_b}) offsets[k++] = o;
+  };
+  for (int i = 0; i < m->n_wave; ++i) wave(m->enc[i]);
+  for (int i = 0; i < m->n_wave; ++i) wave(m->dec[i]);
+  const TfP& t = m->tf;
+  for (int l = 0; l < t.depth; ++l)
+    for (int64_t o : {t.qkv_W(l), t.out_W(l), t.ffin_W(l), t.ffin_b(l), t.ffconv_W(l), t.ffconv_b(l), t.ffout_W(l), t.ffout_b(l), t.g1(l),
+                      t.g2(l)})
+      offsets[k++] = o;
+  offsets[k++] = t.pred_gamma; offsets[k++] = t.pred_W;
+  offsets[k++] = m->lm_W; offsets[k++] = m->lm_b;
+  return n;
+}
+
+// Range of the flat gradient buffer that backward stage `stage` completes (stages as in dn_vae_train_backward).
+extern "C" int dn_vae_train_stage_range(const DnVaeTrain* m, int32_t stage, int64_t* offset, int64_t* count) {
+  DN_CHECK_ARG(m && offset && count, "dn_vae_train_stage_range: null argument");
+  const int depth = m->tf.depth;
+  DN_CHECK_ARG(stage >= 0 && stage <= depth + 2, "dn_vae_train_stage_range: stage %d", stage);
+  int64_t lo, hi;
+  if (stage == 0) {
+    lo = m->tf.pred_gamma; hi = m->n_params;
+  } else if (stage <= depth) {
+    lo = m->tf.layer0 + (int64_t)(depth - stage) * m->tf.layer_stride; hi = lo + m->tf.layer_stride;
+  } else if (stage == depth + 1) {
+    lo = m->dec[0].init_W; hi = m->tf.layer0;
+  } else {
+    lo = 0; hi = m->dec[0].init_W;
+  }
+  *offset = lo; *count = hi - lo;
+  return DN_OK;
+}
+
+extern "C" int dn_vae_train_bind(DnVaeTrain* m, float* master, void* work, void* aux, float* grads) {
+  DN_CHECK_ARG(m && master && work && aux && grads, "dn_vae_train_bind: null argument");
+  for (const void* p : {(const void*)master, (const void*)work, (const void*)aux, (const void*)grads})
+    DN_CHECK_ARG(((uintptr_t)p & 255) == 0, "dn_vae_train_bind: buffers must be 256-byte aligned");
+  DN_CHECK_ARG(m->cfg.dtype == DN_BF16 || (const void*)work == (const void*)master, "dn_vae_train_bind: in f32 mode work must be master");
+  m->master = master; m->work = work; m->aux = (char*)aux; m->grads = grads;
+  return DN_OK;
+}
+
+// aux <- work: the transposed matrices of the data-gradient contractions and the summed skip biases.  Call after every update.
+extern "C" int dn_vae_train_refresh(DnVaeTrain* m, void* stream) {
+  DN_CHECK_ARG(m && m->work && m->aux, "dn_vae_train_refresh: not bound");
+  const int dtype = m->cfg.dtype, es = esize(dtype);
+  hipStream_t s = (hipStream_t)stream;
+  // matrix [Np][Kp] (Np = padn(N)) -> [padn(Kp)][padk(N)]
+  auto tr_strided = [&](int64_t off, int64_t src_stride, int64_t toff, int count, int N, int Kp) -> int {
+    return dn_transpose_weights(static_cast<const char*>(m->work) + off * es, dtype, count, src_stride, padk(N), Kp, m->aux + toff * es,
+                                (int64_t)padn(Kp) * padk(N), padk(N), padn(Kp), s);
+  };
+  auto tr = [&](int64_t off, int64_t toff, int count, int N, int Kp) -> int { return tr_strided(off, (int64_t)padn(N) * Kp, toff, count, N, Kp); };
+  float* fder = reinterpret_cast<float*>(m->aux + r64(m->n_trans) * es);
+  for (int n = 0; n < 2 * m->n_wave; ++n) {
+    const WaveP& w = n < m->n_wave ? m->enc[n] : m->dec[n - m->n_wave];
+    const int cinp = padk(w.cin), cp = padk(w.cout);
+    DN_TRY(tr(w.init_W, w.t_init, 3, w.cout, cinp));
+    DN_TRY(tr(w.conv_W, w.t_conv, w.S * w.L * 3, w.cout, cp));
+    DN_TRY(tr(w.res_W, w.t_res, w.S * w.L, w.cout, cp));
+    DN_TRY(tr(w.skip_W, w.t_skip, w.L, w.cout, cp));
+    DN_TRY(tr(w.final_W, w.t_final, 1, w.cout, cp));
+    DN_TRY(dn_sum_groups(m->master + w.skip_b, cp, w.L, fder + w.skip_bsum, DN_F32, cp, s));
+  }
+  const TfP& t = m->tf;
+  const int Dp = padk(t.dim), hd = t.heads * t.dim_head, ip = padk(t.inner);
+  DN_TRY(tr_strided(t.qkv_W(0), t.layer_stride, t.t_qkv, t.depth, 3 * hd, Dp));
+  DN_TRY(tr_strided(t.out_W(0), t.layer_stride, t.t_out, t.depth, t.dim, hd));
+  DN_TRY(tr_strided(t.ffin_W(0), t.layer_stride, t.t_ffin, t.depth, 2 * ip, Dp));
+  for (int l = 0; l < t.depth; ++l)
+    DN_TRY(tr(t.ffconv_W(l), t.t_ffconv + (int64_t)l * 3 * padn(ip) * ip, 3, t.inner, ip));
+  DN_TRY(tr_strided(t.ffout_W(0), t.layer_stride, t.t_ffout, t.depth, t.dim, ip));
+  DN_TRY(tr(t.pred_W, t.t_pred, 1, t.dim, Dp));
+  return tr(m->lm_W, m->t_lm, 1, m->cfg.vocab, Dp);
+}
+
+extern "C" size_t dn_vae_train_workspace_bytes(const DnVaeTrain* m, int32_t B, int32_t T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  Arena ar{nullptr, 0, 0};
+  (void)plan_vae_train(m, B, T, ar);
+  return ar.off + 256;
+}
+
+// SpeechVAEEncoderDecoder.forward (:1118-1142) + the criterion's loss terms; keeps every activation in the workspace.
+extern "C" int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* b, void* workspace, size_t workspace_bytes, void* stream) {
+  VaePlan pl;
+  DN_TRY(check_batch(m, b, workspace, workspace_bytes, &pl, "dn_vae_train_forward"));
+  hipStream_t s = (hipStream_t)stream;
+  const Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  const int dtype = c.dtype, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, zp = padk(z), V = m->cfg.vocab;
+  DN_TRY(dn_convert_rows(b->feat, DN_F32, D, pl.feat_act, dtype, Dp, M, D, s));
+  const void* cur = pl.feat_act;
+  for (int n = 0; n < m->n_wave; ++n) {  // encoder WaveNets (:1120-1122)
+    const WaveP& w = m->enc[n];
+    const bool lastw = n == m->n_wave - 1;
+    DnGemmParams fin = gemm_base(dtype, M, lastw ? w.cout : padk(w.cout), padk(w.cout), T);
+    if (lastw) {
+      fin.out = pl.params; fin.ldo = w.cout; fin.out_dtype = DN_F32;
+    } else {
+      fin.out = pl.enc_mid[n]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
+    }
+    DN_TRY(wave_forward(c, w, cur, pl.enc[n], fin));
+    cur = pl.enc_mid[n];
+  }
+  // posterior sample + KL rows (:1124-1127)
+  DN_TRY(dn_posterior_sample(pl.params, 2 * z, b->noise, z, pl.z, pl.z_act, dtype, zp, M, z, T, b->lengths, pl.kl_rows, s));
+  cur = pl.z_act;
+  for (int n = 0; n < m->n_wave; ++n) {  // decoder WaveNets (:1130-1131); the last opens the fp32 residual stream
+    const WaveP& w = m->dec[n];
+    const bool lastw = n == m->n_wave - 1;
+    DnGemmParams fin = gemm_base(dtype, M, padk(w.cout), padk(w.cout), T);
+    if (lastw) {
+      fin.out = pl.tf.x; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    } else {
+      fin.out = pl.dec_mid[n]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
+    }
+    DN_TRY(wave_forward(c, w, cur, pl.dec[n], fin));
+    cur = pl.dec_mid[n];
+  }
+  DN_TRY(tf_forward(c, m->tf, b->lengths, pl.tf, pl.rec, Dp));  // decoded_feature (:1133)
+  DN_TRY(dn_convert_rows(pl.rec, DN_F32, Dp, pl.rec_act, dtype, Dp, M, D, s));
+  {  // decoder_lm (:1141)
+    DnGemmParams p = gemm_base(dtype, M, V, Dp, T);
+    p.terms[0].A = pl.rec_act; p.terms[0].lda = Dp; p.terms[0].W = c.W(m->lm_W);
+    p.bias = c.P(m->lm_b); p.out = pl.logits; p.ldo = V; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  if (b->logits_out) DN_TRY(dn_convert_rows(pl.logits, DN_F32, V, b->logits_out, DN_F32, V, M, V, s));
+  if (b->recon_out) DN_TRY(dn_convert_rows(pl.rec, DN_F32, Dp, b->recon_out, DN_F32, D, M, D, s));
+  // losses (speech_vae_decoder_loss.py:60-83): LS-CE rows (+ d logits, kept for the backward), squared error, KL
+  const float g_ls = b->loss_scale * b->w_lsce / (float)b->ntokens;
+  DN_TRY(dn_lsce_loss_grad(pl.logits, V, b->units, M, V, b->label_smoothing, g_ls, pl.lsce_rows, pl.dlogits, dtype, padn(V), s));
+  DN_TRY(dn_masked_mse_grad(pl.rec, Dp, b->feat, D, M, D, T, b->lengths, 0.f, pl.sq_rows, nullptr, 0, 0, nullptr, dtype, 0, s));
+  DN_TRY(dn_colsum(pl.lsce_rows, 4, DN_F32, 1, M, 4, pl.sums, 0, 1.0f, 0, pl.red_scratch, s));
+  DN_TRY(dn_vec_sum(pl.sq_rows, M, pl.sums + 4, 0, pl.red_scratch, s));
+  DN_TRY(dn_vec_sum(pl.kl_rows, M, pl.sums + 5, 0, pl.red_scratch, s));
+  const int n_valid = b->ntokens;  // frames counted by the masked MSE = sum of the lengths
+  hipLaunchKernelGGL(dn::vae_loss_kernel, dim3(1), dim3(1), 0, s, pl.sums, b->stats, b->w_lsce, b->w_mse, b->w_kl, b->label_smoothing, V,
+                     1.0f / (float)b->ntokens, 1.0f / ((float)n_valid * (float)D), 1.0f / ((float)b->B * (float)z * (float)T));
+  DN_CHECK_LAUNCH("dn_vae_train_forward");
+  return DN_OK;
+}
+
+// Backward of the step whose activations dn_vae_train_forward left in the workspace; gradients are ADDED to the bound flat
+// gradient buffer.  Stages (so the caller can start the all-reduce of a finished range while the rest still runs):
+//   0 = losses' gradients + decoder_lm + to_pred;  1 .. depth = transformer layers depth-1 .. 0;  depth+1 = decoder WaveNets +
+//   posterior;  depth+2 = encoder WaveNets.  The gradient ranges finish in reverse parameter order.
+extern "C" int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* b, int32_t first_stage, int32_t last_stage, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  VaePlan pl;
+  DN_TRY(check_batch(m, b, workspace, workspace_bytes, &pl, "dn_vae_train_backward"));
+  hipStream_t s = (hipStream_t)stream;
+  const Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  const int dtype = c.dtype, es = c.es, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, zp = padk(z), V = m->cfg.vocab;
+  const int depth = m->tf.depth;
+  DN_CHECK_ARG(first_stage >= 0 && last_stage <= depth + 2 && first_stage <= last_stage, "dn_vae_train_backward: stages [%d, %d]", first_stage,
+               last_stage);
+  for (int stage = first_stage; stage <= last_stage; ++stage) {
+    if (stage == 0) {
+      // decoder_lm: dW, db, d rec = d logits . W_lm
+      WgTap tap{pl.rec_act, Dp, 0};
+      DN_TRY(weight_grad(c, &tap, 1, D, pl.dlogits, padn(V), V, c.G(m->lm_W)));
+      DN_TRY(bias_grad(c, pl.dlogits, padn(V), dtype, 1, M, V, c.G(m->lm_b), 0));
+      DN_TRY(linear_dgrad(c, pl.dlogits, padn(V), padk(V), c.Wt(m->t_lm), pl.d_rec, Dp, DN_F32));
+      // + masked MSE gradient (:1135-1138): 2 w / (n_valid * D) * (rec - feat)
+      const float g_mse = b->loss_scale * b->w_mse * 2.0f / ((float)b->ntokens * (float)D);
+      DN_TRY(dn_masked_mse_grad(pl.rec, Dp, b->feat, D, M, D, T, b->lengths, g_mse, nullptr, pl.d_rec, Dp, 1, pl.d_rec_act, dtype, Dp, s));
+      DN_TRY(tf_backward_head(c, m->tf, pl.tf, pl.d_rec_act, pl.tt));
+    } else if (stage <= depth) {
+      DN_TRY(tf_backward_layer(c, m->tf, depth - stage, b->lengths, pl.tf, pl.tt));
+    } else if (stage == depth + 1) {
+      // decoder WaveNets, last to first; tt.dx_act = gradient of the residual stream's first state
+      const void* d_y = pl.tt.dx_act;
+      void* mids[2] = {pl.d_mid0, pl.d_mid1};
+      for (int n = m->n_wave - 1; n >= 0; --n) {
+        const WaveP& w = m->dec[n];
+        const void* in = n == 0 ? pl.z_act : pl.dec_mid[n - 1];
+        void* d_x = n == 0 ? (void*)pl.dz : mids[n & 1];
+        DN_TRY(wave_backward(c, w, in, pl.dec[n], d_y, d_x, n == 0 ? DN_F32 : dtype, pl.wt));
+        d_y = d_x;
+      }
+      // posterior sample + KL (:1124-1127): kl.mean() over the batch of per-sample means over (z, T)
+      const float klw = b->loss_scale * b->w_kl / ((float)b->B * (float)z * (float)T);
+      DN_TRY(dn_posterior_backward(pl.params, 2 * z, b->noise, z, pl.dz, zp, pl.d_params, dtype, padk(2 * z), M, z, T, b->lengths, klw, s));
+    } else {
+      const void* d_y = pl.d_params;
+      void* mids[2] = {pl.d_mid0, pl.d_mid1};
+      for (int n = m->n_wave - 1; n >= 0; --n) {
+        const WaveP& w = m->enc[n];
+        const void* in = n == 0 ? pl.feat_act : pl.enc_mid[n - 1];
+        void* d_x = n == 0 ? nullptr : mids[n & 1];
+        DN_TRY(wave_backward(c, w, in, pl.enc[n], d_y, d_x, dtype, pl.wt));
+        d_y = d_x;
+      }
+    }
+  }
+  (void)es;
+  return DN_OK;
+}

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
   const int b = m / T, t = m - b * T;
   const bool valid = lengths ? t < lengths[b] : true;
   float sq = 0.f;
-  const int wide = max(ldd, dpred_act ? ld_act : 0);
+  const int wide = max(C, max(dpred ? ldd : 0, dpred_act ? ld_act : 0));
   for (int c = lane * 4; c < wide; c += 256) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C && valid) {
@@ -391,6 +391,28 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ small helpers
+constexpr int kVecSumBlocks = 256;
+__global__ __launch_bounds__(256) void vec_sum_partial_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ partial) {
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += v[i];
+  s = wave_sum64(s);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(256) void vec_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int accumulate) {
+  float s = partial[threadIdx.x];  // kVecSumBlocks == blockDim
+  s = wave_sum64(s);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+
 // dst[g][r][c] = sum_{k < count} src[k][g][r][c]-style group sum: dst[i] = sum_k src[k * stride + i]
 __global__ __launch_bounds__(256) void sum_groups_kernel(const void* __restrict__ src, int64_t stride, int count, void* __restrict__ dst,
                                                          int dtype, int64_t n) {
@@ -608,6 +630,14 @@ extern "C" int dn_masked_mse_grad(const float* pred, int32_t ldp, const float* t
   hipLaunchKernelGGL(masked_mse_kernel, dim3((M + 3) / 4), dim3(256), 0, S_(stream), pred, ldp, target, ldt, M, C, T, lengths, grad_scale,
                      sq_rows, dpred, ldd, accumulate, dpred_act, act_dtype, ld_act);
   DN_CHECK_LAUNCH("dn_masked_mse_grad");
+  return DN_OK;
+}
+
+extern "C" int dn_vec_sum(const float* v, int64_t n, float* out, int32_t accumulate, float* scratch, void* stream) {
+  DN_CHECK_ARG(v && out && scratch && n > 0, "dn_vec_sum: bad args");
+  hipLaunchKernelGGL(vec_sum_partial_kernel, dim3(kVecSumBlocks), dim3(256), 0, S_(stream), v, n, scratch);
+  hipLaunchKernelGGL(vec_sum_final_kernel, dim3(1), dim3(256), 0, S_(stream), scratch, out, accumulate);
+  DN_CHECK_LAUNCH("dn_vec_sum");
   return DN_OK;
 }
 

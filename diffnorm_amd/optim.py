@@ -75,7 +75,9 @@ class Adam:
                                      int(accumulate), _stream()), "dn_grad_sumsq")
         return self._scratch[1024:]
 
-    def step(self, grad: torch.Tensor) -> torch.Tensor:
+    def step(self, grad: torch.Tensor, grad_scale: float = 1.0, grad_scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`grad_scale` (host) and `grad_scale_dev` (device scalar) are the trainer's multiply_grads factor (fairseq/trainer.py:
+        918-933), applied before the norm and the clip; returns the norm of the SCALED gradient (a device scalar)."""
         lib = _lib.load()
         g = _flat_f32(grad, "grad")
         if g.numel() != self.params.numel():
@@ -83,7 +85,9 @@ class Adam:
         sumsq = self.grad_sumsq(g)
         self.step_count += 1
         hp = _lib.AdamParams(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
-                             max_norm=self.clip_norm, step=self.step_count)
+                             max_norm=self.clip_norm, step=self.step_count, grad_scale=grad_scale,
+                             grad_scale_dev=_lib.ptr(grad_scale_dev))
         _lib.check(lib.dn_adam_step(self.params.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                     g.numel(), C.byref(hp), sumsq.data_ptr(), _lib.ptr(self.bf16_copy), _stream()), "dn_adam_step")
-        return sumsq.sqrt()[0]
+        norm = sumsq.sqrt()[0] * grad_scale
+        return norm * grad_scale_dev.reshape(-1)[0] if grad_scale_dev is not None else norm

@@ -221,3 +221,164 @@ def unkblock(t: torch.Tensor) -> torch.Tensor:
     """Inverse of kblock: [.., K/32, rows, 32] -> [.., rows, K]."""
     *lead, kb, rows, _ = t.shape
     return t.transpose(-3, -2).reshape(*lead, rows, kb * 32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ training layout (SURVEY 8 f2)
+# The flat fp32 parameter / gradient buffers of the training engine (csrc/train_engine.hip) hold the same packed tensors as
+# above (fp32; no K-blocked copies; the L skip-conv biases separately; the transformer's tensors layer-major).  An entry
+# knows how to build its packed tensor from a state dict in the reference layout and how to write it back -- the latter is
+# what turns the flat gradient buffer into per-parameter gradients under the reference's names, and the flat master buffer
+# into a checkpoint the reference can load.
+class _Entry:
+    def __init__(self, name, shape, pack, unpack):
+        self.name, self.shape, self.pack, self.unpack = name, tuple(shape), pack, unpack
+
+
+def _unmat(p: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    return p[:n, :k].clone()
+
+
+def _wavenet_entries(prefix: str, cin: int, cout: int, S: int, L: int) -> List[_Entry]:
+    cinp, cp, cn = padk(cin), padk(cout), padn(cout)
+    f32 = _lib.DN_F32
+    blocks = [(s, i) for s in range(S) for i in range(L)]
+    bk = lambda s, i: f"{prefix}stacks.{s}.blocks.{i}."
+    last = lambda i: f"{prefix}stacks.{S - 1}.blocks.{i}.skip_conv."
+
+    def conv_unpack(p, sd, key, c_in):  # [k, cn, Kp] -> [cout, cin, k]
+        sd[key] = p[:, :cout, :c_in].permute(1, 2, 0).contiguous()
+
+    def stack_unpack(p, sd, fmt, fn):
+        for n, (s, i) in enumerate(blocks):
+            fn(p[n], sd, fmt(s, i))
+
+    return [
+        _Entry(prefix + "init_W", (3, cn, cinp), lambda sd: _conv(sd[prefix + "init_conv.weight"], f32),
+               lambda p, sd: conv_unpack(p, sd, prefix + "init_conv.weight", cin)),
+        _Entry(prefix + "init_b", (cp,), lambda sd: _vec(sd[prefix + "init_conv.bias"], cp),
+               lambda p, sd: sd.__setitem__(prefix + "init_conv.bias", p[:cout].clone())),
+        _Entry(prefix + "conv_W", (S * L, 3, cn, cp), lambda sd: torch.stack([_conv(sd[bk(s, i) + "conv.weight"], f32) for s, i in blocks]),
+               lambda p, sd: stack_unpack(p, sd, lambda s, i: bk(s, i) + "conv.weight", lambda q, d, k: conv_unpack(q, d, k, cout))),
+        _Entry(prefix + "conv_b", (S * L, cp), lambda sd: torch.stack([_vec(sd[bk(s, i) + "conv.bias"], cp) for s, i in blocks]),
+               lambda p, sd: stack_unpack(p, sd, lambda s, i: bk(s, i) + "conv.bias", lambda q, d, k: d.__setitem__(k, q[:cout].clone()))),
+        _Entry(prefix + "res_W", (S * L, cn, cp), lambda sd: torch.stack([_mat(sd[bk(s, i) + "res_conv.weight"][:, :, 0], f32) for s, i in blocks]),
+               lambda p, sd: stack_unpack(p, sd, lambda s, i: bk(s, i) + "res_conv.weight",
+                                          lambda q, d, k: d.__setitem__(k, _unmat(q, cout, cout).unsqueeze(-1)))),
+        _Entry(prefix + "res_b", (S * L, cp), lambda sd: torch.stack([_vec(sd[bk(s, i) + "res_conv.bias"], cp) for s, i in blocks]),
+               lambda p, sd: stack_unpack(p, sd, lambda s, i: bk(s, i) + "res_conv.bias", lambda q, d, k: d.__setitem__(k, q[:cout].clone()))),
+        _Entry(prefix + "skip_W", (L, cn, cp), lambda sd: torch.stack([_mat(sd[last(i) + "weight"][:, :, 0], f32) for i in range(L)]),
+               lambda p, sd: [sd.__setitem__(last(i) + "weight", _unmat(p[i], cout, cout).unsqueeze(-1)) for i in range(L)]),
+        _Entry(prefix + "skip_b", (L, cp), lambda sd: torch.stack([_vec(sd[last(i) + "bias"], cp) for i in range(L)]),
+               lambda p, sd: [sd.__setitem__(last(i) + "bias", p[i, :cout].clone()) for i in range(L)]),
+        _Entry(prefix + "final_W", (cn, cp), lambda sd: _mat(sd[prefix + "final_conv.weight"][:, :, 0], f32),
+               lambda p, sd: sd.__setitem__(prefix + "final_conv.weight", _unmat(p, cout, cout).unsqueeze(-1))),
+        _Entry(prefix + "final_b", (cp,), lambda sd: _vec(sd[prefix + "final_conv.bias"], cp),
+               lambda p, sd: sd.__setitem__(prefix + "final_conv.bias", p[:cout].clone())),
+    ]
+
+
+def _tf_layer_entries(prefix: str, l: int, dim: int, heads: int, dim_head: int) -> List[_Entry]:
+    inner = int(dim * 4 * 2 / 3)
+    ip, Dp, Dn, hd, in_n = padk(inner), padk(dim), padn(dim), heads * dim_head, padn(inner)
+    f32 = _lib.DN_F32
+    p_ = f"{prefix}layers.{l}."
+    rows = _geglu_rows(inner)
+    keep = rows >= 0
+
+    def ffin_pack(sd):
+        w = sd[p_ + "5.0.weight"].float()
+        out = torch.zeros(2 * ip, Dp)
+        out[keep, :dim] = w[rows[keep]]
+        return out
+
+    def ffin_unpack(p, sd):
+        w = torch.zeros(2 * inner, dim)
+        w[rows[keep]] = p[keep, :dim]
+        sd[p_ + "5.0.weight"] = w
+
+    def ffin_b_pack(sd):
+        out = torch.zeros(2 * ip)
+        out[keep] = sd[p_ + "5.0.bias"].float()[rows[keep]]
+        return out
+
+    def ffin_b_unpack(p, sd):
+        b = torch.zeros(2 * inner)
+        b[rows[keep]] = p[keep]
+        sd[p_ + "5.0.bias"] = b
+
+    def qkv_unpack(p, sd):
+        sd[p_ + "1.to_q.weight"] = p[:hd, :dim].clone()
+        sd[p_ + "1.to_kv.weight"] = p[hd:3 * hd, :dim].clone()
+
+    return [
+        _Entry(p_ + "qkv_W", (padn(3 * hd), Dp), lambda sd: _mat(torch.cat([sd[p_ + "1.to_q.weight"], sd[p_ + "1.to_kv.weight"]], dim=0), f32),
+               qkv_unpack),
+        _Entry(p_ + "out_W", (Dn, hd), lambda sd: _mat(sd[p_ + "1.to_out.weight"], f32),
+               lambda p, sd: sd.__setitem__(p_ + "1.to_out.weight", _unmat(p, dim, hd))),
+        _Entry(p_ + "ffin_W", (2 * ip, Dp), ffin_pack, ffin_unpack),
+        _Entry(p_ + "ffin_b", (2 * ip,), ffin_b_pack, ffin_b_unpack),
+        _Entry(p_ + "ffconv_W", (3, in_n, ip), lambda sd: _conv(sd[p_ + "5.2.1.weight"], f32),
+               lambda p, sd: sd.__setitem__(p_ + "5.2.1.weight", p[:, :inner, :inner].permute(1, 2, 0).contiguous())),
+        _Entry(p_ + "ffconv_b", (ip,), lambda sd: _vec(sd[p_ + "5.2.1.bias"], ip),
+               lambda p, sd: sd.__setitem__(p_ + "5.2.1.bias", p[:inner].clone())),
+        _Entry(p_ + "ffout_W", (Dn, ip), lambda sd: _mat(sd[p_ + "5.3.weight"], f32),
+               lambda p, sd: sd.__setitem__(p_ + "5.3.weight", _unmat(p, dim, inner))),
+        _Entry(p_ + "ffout_b", (Dp,), lambda sd: _vec(sd[p_ + "5.3.bias"], Dp),
+               lambda p, sd: sd.__setitem__(p_ + "5.3.bias", p[:dim].clone())),
+        _Entry(p_ + "g1", (dim,), lambda sd: sd[p_ + "0.gamma"].float().clone(), lambda p, sd: sd.__setitem__(p_ + "0.gamma", p.clone())),
+        _Entry(p_ + "g2", (dim,), lambda sd: sd[p_ + "4.gamma"].float().clone(), lambda p, sd: sd.__setitem__(p_ + "4.gamma", p.clone())),
+    ]
+
+
+def vae_train_entries(dim: int, mults: List[int], depth: int, heads: int, dim_head: int, stacks: int, layers: int,
+                      vocab: int) -> List[_Entry]:
+    """Table of the VAE training engine's packed tensors, in the order of dn_vae_train_offsets."""
+    f32 = _lib.DN_F32
+    Dp, Dn, Vn = padk(dim), padn(dim), padn(vocab)
+    ents: List[_Entry] = []
+    cur = dim
+    for n, m in enumerate(mults):
+        ents += _wavenet_entries(f"encoder_wave.{n}.", cur, cur // m, stacks, layers)
+        cur //= m
+    first = True
+    for n, m in enumerate(reversed(mults)):
+        tgt = cur * m
+        cin = cur // 2 if first else cur
+        first = False
+        ents += _wavenet_entries(f"decoder_wave.{n}.", cin, tgt, stacks, layers)
+        cur = tgt
+    for l in range(depth):
+        ents += _tf_layer_entries("decoder_tf.", l, dim, heads, dim_head)
+    ents += [
+        _Entry("decoder_tf.pred_gamma", (dim,), lambda sd: sd["decoder_tf.to_pred.0.gamma"].float().clone(),
+               lambda p, sd: sd.__setitem__("decoder_tf.to_pred.0.gamma", p.clone())),
+        _Entry("decoder_tf.pred_W", (Dn, Dp), lambda sd: _mat(sd["decoder_tf.to_pred.1.weight"], f32),
+               lambda p, sd: sd.__setitem__("decoder_tf.to_pred.1.weight", _unmat(p, dim, dim))),
+        _Entry("decoder_lm.W", (Vn, Dp), lambda sd: _mat(sd["decoder_lm.weight"], f32),
+               lambda p, sd: sd.__setitem__("decoder_lm.weight", _unmat(p, vocab, dim))),
+        _Entry("decoder_lm.b", (Vn,), lambda sd: _vec(sd["decoder_lm.bias"], Vn),
+               lambda p, sd: sd.__setitem__("decoder_lm.bias", p[:vocab].clone())),
+    ]
+    return ents
+
+
+def pack_flat(sd: SD, entries: List[_Entry], offsets: List[int], total: int) -> torch.Tensor:
+    """State dict (reference layout) -> flat fp32 buffer of `total` elements."""
+    flat = torch.zeros(total, dtype=torch.float32)
+    for e, off in zip(entries, offsets):
+        t = e.pack(sd).float()
+        assert tuple(t.shape) == e.shape, (e.name, tuple(t.shape), e.shape)
+        flat[off: off + t.numel()] = t.reshape(-1)
+    return flat
+
+
+def unpack_flat(flat: torch.Tensor, entries: List[_Entry], offsets: List[int]) -> SD:
+    """Flat buffer (parameters or gradients) -> tensors under the reference's state-dict names and shapes."""
+    flat = flat.detach().float().cpu()
+    sd: SD = {}
+    for e, off in zip(entries, offsets):
+        n = 1
+        for s in e.shape:
+            n *= s
+        e.unpack(flat[off: off + n].view(e.shape), sd)
+    return sd

@@ -1,0 +1,309 @@
+"""Training step of the speech VAE on the HIP path (SURVEY 8 f2 + (e)-training, BASELINE config 4): host side.
+
+`VaeTrainEngine` owns the flat device buffers of the C-ABI training engine (csrc/train_engine.hip: master fp32 / work copy /
+aux / gradients, all in the packed layout) and exposes forward + staged backward; `GradientReducer` is the one exchange step
+of data-parallel training -- the bucketed all-reduce of the flat gradient buffer (RCCL over xGMI through torch.distributed;
+the buckets are the ranges the backward stages complete, launched on a side stream as soon as their stage has been enqueued,
+so they overlap the rest of the backward pass) plus one small statistics all-reduce; `VaeTrainer.train_step` drives them the
+way fairseq's trainer drives a step (fairseq/trainer.py:784-960: forward/backward per micro-batch, gradient reduction,
+multiply_grads(world / sample_size), clip_grad_norm, lr schedule, Adam).
+
+PyTorch supplies device memory, streams and torch.distributed; every arithmetic pass is a kernel of libdiffnorm_hip.so.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, optim, packing
+from .engine import _dtype_code, _require_cuda
+
+
+def _aligned_empty(nbytes: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(owner, 256-byte aligned uint8 view of nbytes)."""
+    raw = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+    off = (-raw.data_ptr()) % 256
+    return raw, raw[off: off + nbytes]
+
+
+class VaeTrainEngine:
+    """SpeechVAEEncoderDecoder training on the GPU (reference latent_module.py:1118-1142 + speech_vae_decoder_loss.py:45-95)."""
+
+    LOSS_WEIGHTS = (0.1, 10.0, 1e-4)  # LS-CE, MSE, KL (speech_vae_decoder_loss.py:80-83)
+
+    def __init__(self, state_dict, dim: int = 768, latent_dim: int = 128, dtype="bf16", device="cuda:0", depth: int = 6,
+                 heads: int = 8, dim_head: int = 96, stacks: int = 2, layers: int = 3, vocab: int = 1004):
+        self.device = _require_cuda(device)
+        self.lib = _lib.load()
+        self.dim, self.vocab, self.depth = dim, vocab, depth
+        self.mults = packing.vae_mults(latent_dim)
+        z = dim
+        for m in self.mults:
+            z //= m
+        self.z = z // 2
+        self.dtype = _dtype_code(dtype)
+        mults = (C.c_int32 * 4)(*(self.mults + [0] * (4 - len(self.mults))))
+        cfg = _lib.VaeConfig(dim, self.z, depth, heads, dim_head, stacks, layers, vocab, len(self.mults), mults, self.dtype)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.dn_vae_train_create(C.byref(cfg), C.byref(self.handle)), "dn_vae_train_create")
+        self.n_params = int(self.lib.dn_vae_train_param_count(self.handle))
+        self.entries = packing.vae_train_entries(dim, self.mults, depth, heads, dim_head, stacks, layers, vocab)
+        offs = (C.c_int64 * len(self.entries))()
+        n = _lib.check(self.lib.dn_vae_train_offsets(self.handle, offs, len(self.entries)), "dn_vae_train_offsets")
+        assert n == len(self.entries), (n, len(self.entries))
+        self.offsets = list(offs)
+        with torch.cuda.device(self.device):
+            self._own = []
+            raw, view = _aligned_empty(self.n_params * 4, self.device)
+            self._own.append(raw)
+            self.master = view.view(torch.float32)
+            raw, view = _aligned_empty(self.n_params * 4, self.device)
+            self._own.append(raw)
+            self.grads = view.view(torch.float32)
+            if self.dtype == _lib.DN_BF16:
+                raw, view = _aligned_empty(self.n_params * 2, self.device)
+                self._own.append(raw)
+                self.work = view.view(torch.bfloat16)
+            else:
+                self.work = self.master
+            raw, self.aux = _aligned_empty(int(self.lib.dn_vae_train_aux_bytes(self.handle)), self.device)
+            self._own.append(raw)
+        _lib.check(self.lib.dn_vae_train_bind(self.handle, self.master.data_ptr(), self.work.data_ptr(), self.aux.data_ptr(),
+                                              self.grads.data_ptr()), "dn_vae_train_bind")
+        self._ws: Optional[torch.Tensor] = None
+        self._batch = None
+        self._keep = None
+        self.load_state_dict(state_dict)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.dn_vae_train_destroy(self.handle)
+            self.handle = None
+
+    # ---- parameters ----------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Reference-layout state dict (keys without the `encoder.` prefix) -> the flat master buffer."""
+        flat = packing.pack_flat(sd, self.entries, self.offsets, self.n_params)
+        self.master.copy_(flat.to(self.device))
+        self.sync_work()
+
+    def sync_work(self):
+        """work / aux <- master (after loading or an external update of the master buffer)."""
+        if self.work is not self.master:
+            self.work.copy_(self.master)  # fp32 -> bf16, round to nearest even (the same rounding dn_adam_step applies)
+        self.refresh()
+
+    def refresh(self):
+        """aux <- work: call after every optimizer step (dn_adam_step has already written the bf16 work copy)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_vae_train_refresh(self.handle, _lib.current_stream()), "dn_vae_train_refresh")
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return packing.unpack_flat(self.master, self.entries, self.offsets)
+
+    def grad_dict(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's parameter names and shapes."""
+        return packing.unpack_flat(self.grads, self.entries, self.offsets)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def stage_ranges(self) -> List[Tuple[int, int]]:
+        """(offset, count) of the gradient range each backward stage completes, stage 0 first."""
+        out = []
+        off, cnt = C.c_int64(), C.c_int64()
+        for st in range(self.depth + 3):
+            _lib.check(self.lib.dn_vae_train_stage_range(self.handle, st, C.byref(off), C.byref(cnt)), "dn_vae_train_stage_range")
+            out.append((off.value, cnt.value))
+        return out
+
+    @property
+    def n_stages(self) -> int:
+        return self.depth + 3
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def _workspace(self, B: int, T: int):
+        need = int(self.lib.dn_vae_train_workspace_bytes(self.handle, B, T))
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        p = self._ws.data_ptr()
+        a = (p + 255) & ~255
+        return a, self._ws.numel() - (a - p)
+
+    def forward(self, feat: torch.Tensor, units: torch.Tensor, lengths: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                ntokens: Optional[int] = None, weights: Sequence[float] = LOSS_WEIGHTS, label_smoothing: float = 0.1,
+                loss_scale: float = 1.0, want_logits: bool = False, want_recon: bool = False):
+        """feat [B,T,dim] fp32, units [B,T] (dictionary indices, 0 = pad), lengths [B] -> stats fp32 [8] on the device:
+        loss, nll_loss, mse_loss, kl_loss, acc, n_valid, lsce/ntokens, 0.  Activations stay in the workspace for `backward`."""
+        B, T, _ = feat.shape
+        dev = self.device
+        feat = feat.to(dev, torch.float32).contiguous()
+        units = units.to(dev, torch.int32).contiguous()
+        lengths = lengths.to(dev, torch.int32).contiguous()
+        if noise is None:  # CPU generator, [B, z, T] like upstream (distributions.py:38-40)
+            noise = torch.randn(B, self.z, T).transpose(1, 2)
+        noise = noise.to(dev, torch.float32).contiguous()
+        if ntokens is None:
+            ntokens = int(lengths.sum().item())
+        stats = torch.empty(8, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, T, self.vocab, dtype=torch.float32, device=dev) if want_logits else None
+        recon = torch.empty(B, T, self.dim, dtype=torch.float32, device=dev) if want_recon else None
+        b = _lib.VaeTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), noise.data_ptr(), B, T, int(ntokens),
+                               float(weights[0]), float(weights[1]), float(weights[2]), float(label_smoothing), float(loss_scale),
+                               stats.data_ptr(), _lib.ptr(logits), _lib.ptr(recon))
+        self._batch, self._keep = b, (feat, units, lengths, noise, stats, logits, recon)
+        wp, wn = self._workspace(B, T)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.dn_vae_train_forward(self.handle, C.byref(b), wp, wn, _lib.current_stream()), "dn_vae_train_forward")
+        return (stats, logits, recon) if (want_logits or want_recon) else stats
+
+    def backward(self, first_stage: int = 0, last_stage: Optional[int] = None):
+        """Backward stages of the last `forward`; gradients are added to `self.grads`."""
+        assert self._batch is not None, "backward() needs a forward() first"
+        last_stage = self.n_stages - 1 if last_stage is None else last_stage
+        B, T = self._batch.B, self._batch.T
+        wp, wn = self._workspace(B, T)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_vae_train_backward(self.handle, C.byref(self._batch), first_stage, last_stage, wp, wn,
+                                                      _lib.current_stream()), "dn_vae_train_backward")
+
+
+def plan_buckets(ranges: Sequence[Tuple[int, int]], min_elems: int) -> List[Tuple[int, int, int]]:
+    """Merges consecutive backward-stage ranges (each ends where the previous one starts: the backward walks the buffer from
+    its end) into buckets of at least `min_elems` elements.  -> [(last_stage_of_bucket, offset, count)], in completion order."""
+    buckets, hi, lo, n = [], None, None, 0
+    for stage, (off, cnt) in enumerate(ranges):
+        if cnt == 0:
+            continue
+        if hi is None:
+            hi = off + cnt
+        assert off + cnt == (lo if lo is not None else hi), "stage ranges must be contiguous, descending"
+        lo, n = off, n + cnt
+        if n >= min_elems:
+            buckets.append((stage, lo, n))
+            hi, lo, n = None, None, 0
+    if n:
+        buckets.append((len(ranges) - 1, lo, n))
+    return buckets
+
+
+class GradientReducer:
+    """Bucketed sum-all-reduce of a flat gradient buffer, overlapped with the backward pass.
+
+    Replaces the DDP reducer of the reference's training stack (fairseq/models/distributed_fairseq_model.py:59-84: torch DDP with
+    25 MB buckets; fairseq/trainer.py:912-916).  One process per GPU; backend "nccl" is RCCL on ROCm.  xGMI is point-to-point, a
+    ring all-reduce is bound by one link, so the buckets are few and large (the ranges the backward stages complete, merged up to
+    `bucket_mb`); each is issued on a side stream right after its stage has been enqueued on the compute stream.
+    On CPU tensors (gloo; the CPU tests) the same bucket plan runs synchronously."""
+
+    def __init__(self, grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, bucket_mb: float = 64.0):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.grads, self.group = grads, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = plan_buckets(ranges, int(bucket_mb * (1 << 20) / 4))
+        self.cuda = grads.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=grads.device) if self.cuda else None
+        self._handles = []
+        self._timing: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.measure = False
+
+    def bucket_after_stage(self, stage: int) -> Optional[int]:
+        for i, (last, _, _) in enumerate(self.buckets):
+            if last == stage:
+                return i
+        return None
+
+    def reduce_bucket(self, i: int):
+        """Call after the last stage of bucket i has been enqueued on the current stream."""
+        if self.world == 1:
+            return
+        _, off, cnt = self.buckets[i]
+        view = self.grads[off: off + cnt]
+        if not self.cuda:
+            self.dist.all_reduce(view, group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            if self.measure:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._handles.append(self.dist.all_reduce(view, group=self.group, async_op=True))
+            if self.measure:
+                self._handles[-1].wait()
+                e1.record()
+                self._timing.append((e0, e1))
+
+    def finish(self):
+        """The compute stream waits for every outstanding bucket."""
+        if self.world == 1:
+            return
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def all_reduce_ms(self) -> float:
+        """Sum of the measured bucket all-reduce times since the last call (needs `measure = True`; synchronises)."""
+        if not self._timing:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._timing)
+        self._timing = []
+        return ms
+
+
+class VaeTrainer:
+    """One process's half of fairseq's Trainer.train_step (fairseq/trainer.py:784-960) for --task speech_decoder --criterion
+    speech_vae_decoder_loss on the HIP engine: per micro-batch forward + backward, gradient all-reduce (sum), the statistics
+    all-reduce, multiply_grads(world / sample_size) -- here 1 / sample_size on the summed gradient --, clip_grad_norm, the
+    inverse_sqrt learning rate of update `num_updates`, Adam.  No host synchronisation inside a step."""
+
+    def __init__(self, engine: VaeTrainEngine, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-8, weight_decay: float = 0.0,
+                 clip_norm: float = 2.0, warmup_updates: int = 10000, warmup_init_lr: float = 1e-7, group=None,
+                 bucket_mb: float = 64.0):
+        self.engine = engine
+        self.adam = optim.Adam(engine.master, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm,
+                               bf16_copy=engine.work if engine.work is not engine.master else None)
+        self.schedule = optim.InverseSquareRootSchedule(lr, warmup_updates, warmup_init_lr)
+        self.reducer = GradientReducer(engine.grads, engine.stage_ranges(), group=group, bucket_mb=bucket_mb)
+        self.group = group
+        self.num_updates = 0
+
+    def train_step(self, samples: Sequence[dict], noises: Optional[Sequence[torch.Tensor]] = None):
+        """samples: the micro-batches of one update (update_freq), each the criterion's sample dict.
+        -> (stats [8] of the last micro-batch weighted like the criterion's logging output, grad_norm) as device tensors."""
+        eng, red = self.engine, self.reducer
+        eng.zero_grad()
+        totals = torch.zeros(10, dtype=torch.float32, device=eng.device)  # sum_i nsent_i * stats_i [0:8], nsentences, ntokens
+        for k, sample in enumerate(samples):
+            lens = sample["reduce_target_lengths"]
+            stats = eng.forward(sample["reduce_target"], sample["reduce_target_unit"], lens,
+                                noise=None if noises is None else noises[k], ntokens=int(sample["ntokens"]))
+            nsent = float(sample["nsentences"])
+            totals[:8] += stats * nsent
+            totals[8] += nsent
+            totals[9] += float(sample["ntokens"])
+            if k + 1 < len(samples):
+                eng.backward()
+                continue
+            for stage in range(eng.n_stages):  # last micro-batch: ranges enter the all-reduce as they complete
+                eng.backward(stage, stage)
+                b = red.bucket_after_stage(stage)
+                if b is not None:
+                    red.reduce_bucket(b)
+        if red.world > 1:
+            red.dist.all_reduce(totals, group=self.group)  # the one small statistics exchange (replaces all_gather_list of dicts)
+        red.finish()
+        inv_sample_size = 1.0 / totals[8:9]  # sample_size = sum of nsentences over ranks and micro-batches (criterion :84)
+        self.adam.set_lr(self.schedule.step_update(self.num_updates))
+        grad_norm = self.adam.step(eng.grads, grad_scale=1.0, grad_scale_dev=inv_sample_size)
+        eng.refresh()
+        self.num_updates += 1
+        logged = totals[:8] / totals[8]  # sample-size-weighted means, as reduce_metrics (:97-112)
+        return logged, grad_norm

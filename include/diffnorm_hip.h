@@ -249,6 +249,11 @@ typedef struct {
   double max_norm;  /* --clip-norm; <= 0 or sumsq == NULL: no clipping                                          */
   int32_t step;     /* 1 for the first update (fairseq/optim/adam.py:212)                                       */
   int32_t pad_;
+  double grad_scale; /* the trainer's multiply_grads (fairseq/trainer.py:918-933: world / sample_size after DDP's mean, i.e.
+                        1 / sample_size on a summed gradient): applied to every gradient before the norm and the update;
+                        0 is read as 1                                                                            */
+  const float* grad_scale_dev; /* optional device scalar multiplied into grad_scale (a sample size that only exists on the
+                                  device after the statistics all-reduce), NULL = 1                                */
 } DnAdamParams;
 
 /* Operand preparation for the weight gradient of a causal conv / Linear (the contraction over frames): bf16 [B*T, ld]
@@ -261,8 +266,8 @@ int dn_transpose_pad(const void* src, int32_t ld, int32_t B, int32_t T, int32_t 
                      int32_t rows, int32_t rows_total, int32_t row0, int32_t chunk, void* stream);
 
 /* One fairseq Adam update (fairseq/optim/adam.py:159-239) of n fp32 parameters in place, with the gradient scaled by
- * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) first (fairseq/utils.py:392-396; the gradient buffer itself is left
- * unscaled); param_bf16 != NULL also receives the updated parameters in bf16 (the forward kernels' operand type). */
+ * s = grad_scale and then by min(1, max_norm / (s * sqrt(sumsq[0]) + 1e-6)) first (fairseq/trainer.py:918-933, fairseq/utils.py:
+ * 392-396; sumsq is the sum of squares of the UNSCALED buffer, which is itself left untouched); param_bf16 != NULL also receives the updated parameters in bf16 (the forward kernels' operand type). */
 int dn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const DnAdamParams* hp,
                  const float* sumsq, void* param_bf16, void* stream);
 
@@ -344,6 +349,9 @@ int dn_masked_mse_grad(const float* pred, int32_t ldp, const float* target, int3
                        const int32_t* lengths, float grad_scale, float* sq_rows, float* dpred, int32_t ldd, int32_t accumulate,
                        void* dpred_act, int32_t act_dtype, int32_t ld_act, void* stream);
 
+/* out[0] (+)= sum_i v[i] (fixed two-stage order); scratch: 256 floats. */
+int dn_vec_sum(const float* v, int64_t n, float* out, int32_t accumulate, float* scratch, void* stream);
+
 /* dst[i] = sum_{k < count} src[k * stride + i], i < n (the gradients a tensor receives from several consumers). */
 int dn_sum_groups(const void* src, int64_t stride, int32_t count, void* dst, int32_t dtype, int64_t n, void* stream);
 
@@ -419,6 +427,51 @@ size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t sta
 int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step,
                  int32_t max_evals, const float* coef, int32_t timesteps, int32_t flags, void* workspace,
                  size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ VAE training step (BASELINE config 4) */
+/* speech_vae_decoder_loss training (reference SpeechVAEEncoderDecoder.forward latent_module.py:1118-1142 + the criterion
+ * fairseq/criterions/speech_vae_decoder_loss.py:45-95) on flat buffers in the PACKED parameter layout (csrc/engine.h: rows
+ * padded to 128, K to 64, GEGLU interleave, conv taps as matrices; transformer tensors layer-major; zero pads stay zero under
+ * Adam without weight decay):
+ *   master fp32 [n]  what dn_adam_step updates          work [n] in cfg.dtype  (bf16: dn_adam_step's bf16 copy; f32: == master)
+ *   grads  fp32 [n]  dn_vae_train_backward ADDS into it  aux  bytes            transposed matrices + summed skip biases,
+ *                                                                              rebuilt by dn_vae_train_refresh after an update
+ * diffnorm_amd/packing.py::pack_vae_train converts a state dict in the reference layout to / from this layout. */
+typedef struct DnVaeTrain DnVaeTrain;
+typedef struct {
+  const float* feat;        /* [B, T, dim] fp32 target features (also the encoder input)                               */
+  const int32_t* units;     /* [B, T] dictionary indices (unit + 4), 0 = pad                                           */
+  const int32_t* lengths;   /* [B]                                                                                     */
+  const float* noise;       /* [B, T, z] posterior noise (distributions.py:38-40 draws it on the CPU generator)        */
+  int32_t B, T;
+  int32_t ntokens;          /* sample["ntokens"] = sum of lengths                                                      */
+  float w_lsce, w_mse, w_kl; /* criterion weights: 0.1, 10, 1e-4 (speech_vae_decoder_loss.py:80-83)                     */
+  float label_smoothing;    /* 0.1                                                                                     */
+  float loss_scale;         /* multiplies every gradient (1 normally)                                                   */
+  float* stats;             /* fp32 [8] out: loss, nll_loss, mse_loss, kl_loss, acc, n_valid, lsce/ntokens, 0            */
+  float* logits_out;        /* optional fp32 [B, T, vocab]                                                             */
+  float* recon_out;         /* optional fp32 [B, T, dim]                                                               */
+} DnVaeTrainBatch;
+
+int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out);
+void dn_vae_train_destroy(DnVaeTrain* m);
+int64_t dn_vae_train_param_count(const DnVaeTrain* m);   /* n: elements of master / work / grads                       */
+size_t dn_vae_train_aux_bytes(const DnVaeTrain* m);
+/* element offsets of the packed tensors in table order (2 * n_wave * 10 + 10 * depth + 4 entries); returns the count   */
+int dn_vae_train_offsets(const DnVaeTrain* m, int64_t* offsets, int32_t capacity);
+/* [offset, offset + count) of the gradient buffer that backward stage `stage` completes                               */
+int dn_vae_train_stage_range(const DnVaeTrain* m, int32_t stage, int64_t* offset, int64_t* count);
+int dn_vae_train_bind(DnVaeTrain* m, float* master, void* work, void* aux, float* grads);  /* 256-byte aligned buffers   */
+int dn_vae_train_refresh(DnVaeTrain* m, void* stream);
+size_t dn_vae_train_workspace_bytes(const DnVaeTrain* m, int32_t B, int32_t T);
+/* forward + losses; every activation the backward needs stays in the workspace                                          */
+int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* batch, void* workspace, size_t workspace_bytes, void* stream);
+/* backward stages first_stage .. last_stage of the step dn_vae_train_forward just ran on this workspace: 0 = loss gradients +
+ * decoder_lm + to_pred, 1 .. depth = transformer layers depth-1 .. 0, depth+1 = decoder WaveNets + posterior, depth+2 =
+ * encoder WaveNets.  Gradient ranges complete in reverse parameter order (dn_vae_train_stage_range), so the caller can start
+ * the all-reduce of a finished range while later stages still run.                                                       */
+int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* batch, int32_t first_stage, int32_t last_stage, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 const char* dn_last_error(void);
 int dn_version(void);

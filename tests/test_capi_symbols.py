@@ -53,12 +53,15 @@ def test_struct_layout_matches_header(lib, tmp_path):
                                            "lengths", "norm_out", "norm_ld", "norm_dtype", "norm_D", "norm_gb_ld", "norm_gamma",
                                            "norm_gb", "norm_gb_half", "out_layout", "norm_split", "norm_ssq_ld", "norm_ssq", "row_ssq",
                                            "row_ssq_ld", "row_ssq_parts", "row_D", "row_bias_ld", "row_bias"]),
-        "DnAdamParams": (_lib.AdamParams, ["lr", "beta1", "beta2", "eps", "weight_decay", "max_norm", "step"]),
+        "DnAdamParams": (_lib.AdamParams, ["lr", "beta1", "beta2", "eps", "weight_decay", "max_norm", "step", "grad_scale",
+                                           "grad_scale_dev"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
                                            "dtype", "lengths", "scale", "lse"]),
         "DnAttnBwdParams": (_lib.AttnBwdParams, ["q", "k", "v", "out", "dout", "dq", "dk", "dv", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq",
                                                  "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
                                                  "delta"]),
+        "DnVaeTrainBatch": (_lib.VaeTrainBatch, ["feat", "units", "lengths", "noise", "B", "T", "ntokens", "w_lsce", "w_mse", "w_kl",
+                                                 "label_smoothing", "loss_scale", "stats", "logits_out", "recon_out"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
                                          "dtype", "max_pos"]),
         "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",
