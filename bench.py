@@ -30,6 +30,10 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/gu
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample = BASELINE configs[2] (denoising-steps/s, the headline metric); train = configs[3] "
+                         "(speech_vae_decoder_loss training step, samples/s + all-reduce ms)")
+    ap.add_argument("--max-tokens", type=int, default=15000, help="train: per-GPU token budget of a batch (scripts/vae/train.sh:8)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
@@ -163,43 +167,11 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def main():
-    args = parse()
-    env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
-        sys.exit(launch_ranks(args))
-    if int(env_world or "1") != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
-                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus N`")
+def run_sampling(args, ctx):
+    """BASELINE configs[2]: the DDIM reverse chain (denoising-steps/s)."""
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
-    if world > 1:
-        # RCCL ("nccl") is the contract; DN_BENCH_BACKEND=gloo only rehearses the N > 1 control flow with several ranks
-        # sharing one GPU (RCCL refuses duplicate devices).  The data path has no collective either way.
-        backend = os.environ.get("DN_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=backend)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    rccl_ranks = 1
-    if world > 1:  # the ranks the collective backend actually connected: must be the N that was asked for
-        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        if rccl_ranks != args.gpus:
-            sys.exit(f"bench.py: {rccl_ranks} ranks joined the process group, --gpus {args.gpus} expected")
-
+    rank, world, dev, rccl_ranks, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["rccl_ranks"], ctx["dist"]
     from diffnorm_amd import _lib, engine, ops, packing, scheduler, synthetic
 
     cfg = synthetic.eps_config()
@@ -296,6 +268,153 @@ def main():
             result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B), args.cpu_threads)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
+
+
+def make_train_batches(n, max_tokens, dim, vocab, seed, dev):
+    """Synthetic (feat, unit) batches of BASELINE configs[3] / SURVEY 8(d) config 4: lengths U[64, 512], feat ~ N(0,1), units
+    U{4..1003}; a batch = the longest-first prefix of 64 drawn utterances that fits `max_tokens` padded frames, its size rounded
+    down to a multiple of 8 (fairseq's required_batch_size_multiple).  Everything is resident on the device."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        lens = torch.randint(64, 513, (64,), generator=g).sort(descending=True).values
+        T = int(lens[0])
+        B = max(8, min(64, max_tokens // T) // 8 * 8)
+        lens = lens[:B]
+        mask = torch.arange(T).view(1, -1) < lens.view(-1, 1)
+        feat = torch.randn(B, T, dim, generator=g) * mask.unsqueeze(-1)
+        unit = torch.randint(4, vocab, (B, T), generator=g) * mask
+        out.append({"reduce_target": feat.to(dev), "reduce_target_unit": unit.to(dev, torch.int32),
+                    "reduce_target_lengths": lens.to(dev, torch.int32), "ntokens": int(lens.sum()), "nsentences": B, "frames": B * T})
+    return out
+
+
+def vae_train_flops(B, T, ntokens):
+    """Algorithmic FLOPs of one speech_vae_decoder_loss update on a [B, T] batch (MAC = 2): forward = encode + decode
+    (4,849,664 and 272,271,360 + 18,432 T per frame) + the LM head; backward = 2x the contraction work of the
+    forward (data + weight gradient), the attention backward 2.5x its forward."""
+    M = B * T
+    fwd_lin = M * (4849664 + 272271360)  # per-frame contraction work without the T-dependent attention part
+    attn = M * 18432 * T
+    return 3.0 * fwd_lin + 3.5 * attn
+
+
+def run_training(args, ctx):
+    """BASELINE configs[3]: speech_vae_decoder_loss training, one update per step: forward, backward, bucketed gradient
+    all-reduce (RCCL), clip + Adam, refresh.  value = sentences / s over all ranks (weak scaling: every rank has its own
+    `--max-tokens` batch)."""
+    import torch
+
+    rank, world, dev, rccl_ranks, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["rccl_ranks"], ctx["dist"]
+    from diffnorm_amd import synthetic, training
+
+    sd = synthetic.random_vae_state_dict(768, 128, seed=1)
+    eng = training.VaeTrainEngine(sd, dim=768, latent_dim=128, dtype=args.dtype, device=dev)
+    tr = training.VaeTrainer(eng, lr=5e-4, betas=(0.9, 0.98), clip_norm=2.0, warmup_updates=10000, warmup_init_lr=1e-7)
+    K, W = args.steps, args.warmup
+    batches = make_train_batches(4, args.max_tokens, 768, 1004, 100 + rank, dev)
+    stream = torch.cuda.Stream(device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        return tr.train_step([batches[i % len(batches)]], noises=[("philox", 7 + rank, i << 24)])
+
+    with torch.cuda.stream(stream):
+        for i in range(max(W, len(batches))):  # warm-up visits every batch shape once (workspace growth, kernel attributes)
+            logged, norm = step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            logged, norm = step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        sent = sum(batches[i % len(batches)]["nsentences"] for i in range(K))
+        toks = sum(batches[i % len(batches)]["ntokens"] for i in range(K))
+        frames = sum(batches[i % len(batches)]["frames"] for i in range(K))
+        flops = sum(vae_train_flops(b["nsentences"], b["frames"] // b["nsentences"], b["ntokens"]) for b in (batches[i % len(batches)] for i in range(K)))
+        assert torch.isfinite(logged).all().item() and torch.isfinite(norm).item(), "training diverged"
+        # all-reduce time of one update (buckets timed with events on the side stream; 0 on one GPU)
+        ar_ms = 0.0
+        if world > 1:
+            tr.reducer.measure = True
+            step(0)
+            ar_ms = tr.reducer.all_reduce_ms()
+            tr.reducer.measure = False
+    vals = torch.tensor([dt, float(sent), float(toks), float(frames), flops, ar_ms], dtype=torch.float64, device=dev if world > 1 and dist.get_backend() == "nccl" else "cpu")
+    if world > 1:
+        tmax = vals[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vals)
+        vals[0] = tmax[0]
+        vals[5] /= world
+    dt, sent, toks, frames, flops, ar_ms = (float(v) for v in vals)
+    if rank == 0:
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        result = {
+            "metric": "training samples/sec (speech_vae_decoder_loss)", "value": sent / dt, "unit": "samples/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[3]: speech_vae_decoder_loss update of SpeechVAEEncoderDecoder(768, latent 128) on synthetic "
+                                   f"(feat, unit) pairs, lengths U[64,512], --max-tokens {args.max_tokens} per GPU, Adam(0.9,0.98) clip 2.0, "
+                                   f"random-init weights", "max_tokens_per_gpu": args.max_tokens, "parallelism": f"dp{world} (RCCL gradient all-reduce, "
+                                   f"{len(tr.reducer.buckets)} buckets)"},
+            "tokens_per_s": toks / dt, "padded_frames_per_s": frames / dt, "all_reduce_ms_per_update": ar_ms,
+            "gradient_bytes": eng.n_params * 4, "step_tflops_per_gpu": flops / dt / 1e12 / world,
+            "step_mfma_frac": flops / dt / 1e12 / world / peak,
+            "loss": float(logged[0]), "grad_norm": float(norm),
+        }
+        print(json.dumps(result), flush=True)
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(env_world or "1") != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus N`")
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
+    if world > 1:
+        # RCCL ("nccl") is the contract; DN_BENCH_BACKEND=gloo only rehearses the N > 1 control flow with several ranks
+        # sharing one GPU (RCCL refuses duplicate devices).  The data path has no collective either way.
+        backend = os.environ.get("DN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    rccl_ranks = 1
+    if world > 1:  # the ranks the collective backend actually connected: must be the N that was asked for
+        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != args.gpus:
+            sys.exit(f"bench.py: {rccl_ranks} ranks joined the process group, --gpus {args.gpus} expected")
+
+    ctx = dict(rank=rank, world=world, dev=dev, rccl_ranks=rccl_ranks, dist=dist if world > 1 else None)
+    if args.mode == "train":
+        run_training(args, ctx)
+    else:
+        run_sampling(args, ctx)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

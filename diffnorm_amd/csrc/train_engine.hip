@@ -26,31 +26,49 @@ using namespace dn;
 namespace dn {
 
 // dst[(j / chunk)][row0 + c][j % chunk] = src[b*T + t, c] with j = b*Tp + front + t; zero for pad frames, rows >= C and the
-// tail columns [B*Tp, cols_total) that round the frame index up to whole K-slices.
+// tail columns [B*Tp, cols_total) that round the frame index up to whole K-slices.  64 frames x 64 channels per workgroup
+// through LDS with 16-byte global accesses on both sides: loads run along the channels of one frame, stores along the frames
+// of one channel (a 64-frame tile never straddles a K-slice: chunk % 64 == 0).  src rows are 16-byte aligned with ld a
+// multiple of the access width and >= C rounded up to it (activation buffers: ld = padk(C)).
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_slices_kernel(const T* __restrict__ src, int ld, int B, int Tn, int C, int front, int Tp,
                                                                int64_t cols_total, T* __restrict__ dst, int rows, int rows_total, int row0,
                                                                int chunk) {
-  __shared__ T tile[64][66];
+  constexpr int V = 16 / (int)sizeof(T);   // elements per 16-byte access
+  constexpr int LDT = 64 + V;              // LDS row: 64 frames + one access of padding (rows stay 16-byte aligned)
+  constexpr int CPR = 64 / V;              // 16-byte pieces per 64-element row
+  __shared__ __attribute__((aligned(16))) T tile[64][LDT];  // [channel][frame]
+  // 8-frame blocks of a channel row are XOR-swizzled by the channel's 8-block, so the scalar writes of one access (lanes 8
+  // channels apart) land in different banks; 16-byte reads stay contiguous
+  auto swz = [](int c, int f) { return (((f >> 3) ^ ((c >> 3) & 7)) << 3) | (f & 7); };
   const int64_t cols = (int64_t)B * Tp;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {  // load: row r = frame, piece q = channels c0 + q*V ..
+    const int r = i / CPR, q = i - r * CPR;
     const int64_t j = j0 + r;
-    T v = T(0);
+    union { uint4 u; T e[V]; } v;
+    v.u = make_uint4(0, 0, 0, 0);
     if (j < cols) {
       const int b = (int)(j / Tp), t = (int)(j - (int64_t)b * Tp) - front;
-      const int c = c0 + tx;
-      if (t >= 0 && t < Tn && c < C) v = src[((int64_t)b * Tn + t) * ld + c];
+      const int c = c0 + q * V;
+      if (t >= 0 && t < Tn && c < C) {
+        v.u = *reinterpret_cast<const uint4*>(src + ((int64_t)b * Tn + t) * ld + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (c + e >= C) v.e[e] = T(0);
+      }
     }
-    tile[r][tx] = v;
+#pragma unroll
+    for (int e = 0; e < V; ++e) tile[q * V + e][swz(q * V + e, r)] = v.e[e];
   }
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {  // store: row r = channel, piece q = frames j0 + q*V ..
+    const int r = i / CPR, q = i - r * CPR;
     const int c = c0 + r;
-    const int64_t j = j0 + tx;
-    if (c < rows && j < cols_total) dst[((j / chunk) * rows_total + row0 + c) * chunk + j % chunk] = tile[tx][r];
+    const int64_t j = j0 + q * V;
+    if (c < rows && j < cols_total)
+      *reinterpret_cast<uint4*>(dst + ((j / chunk) * rows_total + row0 + c) * chunk + j % chunk) = *reinterpret_cast<const uint4*>(&tile[r][swz(r, q * V)]);
   }
 }
 
@@ -193,7 +211,9 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
   const int64_t cols = (int64_t)B * p.Tp;
   const int64_t tiles = (int64_t)((cout + 255) / 256) * ((p.N + 255) / 256);
   int ks = 1;
-  while (ks < 64 && tiles * ks < 256 && cols / (ks * 2) >= 256) ks *= 2;  // fill the chip; K-slices of >= 4 K-tiles
+  // fill the chip with K-slices of >= 4 K-tiles; a contraction with >= 160 output tiles runs unsliced and accumulates
+  // straight into the gradient (no partial sums to write, re-read and reduce)
+  while (ks < 64 && tiles * ks < (ks == 1 ? 160 : 256) && cols / (ks * 2) >= 256) ks *= 2;
   p.k_slices = ks;
   p.cols_total = (cols + (int64_t)64 * ks - 1) / ((int64_t)64 * ks) * ((int64_t)64 * ks);
   p.chunk = (int)(p.cols_total / ks);
@@ -232,6 +252,16 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
       launch_transpose_slices<float>(taps[j].x, taps[j].ldx, c.B, c.T, cin, taps[j].shift, pl, xT, pl.rows_w, pl.N, j * pl.rows_w, c.s);
   }
   DN_CHECK_LAUNCH("weight_grad transposes");
+  if (pl.k_slices == 1) {  // one group per tap, each accumulating into its own matrix of the packed gradient
+    const int Np = padn(cout), Kp = padk(cin);
+    DnGemmParams p = gemm_base(c.dtype, cout, Kp, pl.chunk, cout);
+    p.groups = n_taps;
+    p.terms[0].A = dyT; p.terms[0].lda = pl.chunk; p.terms[0].a_gstride = 0;
+    p.terms[0].W = xT; p.terms[0].w_gstride = (int64_t)pl.rows_w * pl.chunk;
+    p.epilogue = DN_EPI_RESADD; p.res = grad; p.ldr = Kp; p.res_gstride = (int64_t)Np * Kp;
+    p.out = grad; p.ldo = Kp; p.out_dtype = DN_F32; p.out_gstride = (int64_t)Np * Kp;
+    return dn_conv_gemm(&p, c.s);
+  }
   DnGemmParams p = gemm_base(c.dtype, cout, pl.N, pl.chunk, cout);
   p.groups = pl.k_slices;
   p.terms[0].A = dyT; p.terms[0].lda = pl.chunk; p.terms[0].a_gstride = (int64_t)cout * pl.chunk;

@@ -223,17 +223,33 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
 }
 
-// out[g, c] (+)= sum_{j < per_group} partial[(g * per_group + j), c]   (fixed order)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int part_ld, int per_group, int C,
-                                                           float* __restrict__ out, int out_ld, float scale, int accumulate) {
+// out[g, c] (+)= scale * sum_{j < per_group} partial[(g * per_group + j), c].  A workgroup (1024 threads) owns 64 columns of one
+// group; its sixteen waves take the rows j = w, w + 16, ... (coalesced 256-byte reads) and their sums are added in a fixed order.
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int part_ld, int per_group, int C,
+                                                            float* __restrict__ out, int out_ld, float scale, int accumulate) {
+  __shared__ float red[16][64];
   const int g = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int j = 0; j < per_group; ++j) s += partial[((int64_t)g * per_group + j) * part_ld + c];
-  s *= scale;
-  float* o = out + (int64_t)g * out_ld + c;
-  *o = accumulate ? *o + s : s;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float* p = partial + (int64_t)g * per_group * part_ld + c;
+    int j = ty;
+    for (; j + 16 < per_group; j += 32) {
+      s0 += p[(int64_t)j * part_ld];
+      s1 += p[(int64_t)(j + 16) * part_ld];
+    }
+    if (j < per_group) s0 += p[(int64_t)j * part_ld];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][tx];
+    float* o = out + (int64_t)g * out_ld + c;
+    *o = accumulate ? *o + t * scale : t * scale;
+  }
 }
 
 // partial[blk, c] = sum over the block's row range of src[m, c]; rows [g * rows_per_group, (g+1) * rows_per_group) form
@@ -542,7 +558,7 @@ extern "C" int dn_geglu_backward(const void* dout, const void* pre, void* dpre, 
 // rows handled by one workgroup of the norm backward: enough workgroups for the chip, partial rows kept small
 static inline int norm_rows_per_block(int B, int T) {
   int rpb = 64;
-  while (rpb > 8 && (int64_t)B * ((T + rpb - 1) / rpb) < 1024) rpb >>= 1;
+  while (rpb > 8 && (int64_t)B * ((T + rpb - 1) / rpb) < 512) rpb >>= 1;
   return rpb;
 }
 
@@ -565,12 +581,12 @@ extern "C" int dn_rmsnorm_backward(const float* x, int32_t ldx, const void* dy, 
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, ldx, dy, lddy, dy_dtype, B, T, D, gamma, gamma_beta,
                      gb_ld, part_ld / 2, dres, dx, dx_act, act_dtype, ld_act, rpb, bps, want ? scratch : nullptr, part_ld);
   if (dgamma)  // learned gamma: all workgroups reduce into one row
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256, 1), dim3(256), 0, S_(stream), scratch, part_ld, B * bps, D, dgamma, 0,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64, 1), dim3(1024), 0, S_(stream), scratch, part_ld, B * bps, D, dgamma, 0,
                        1.0f, 1);
   if (dgamma_beta) {  // adaptive: per-sample rows [d g_c | d b_c]
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256, B), dim3(256), 0, S_(stream), scratch, part_ld, bps, D, dgamma_beta,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64, B), dim3(1024), 0, S_(stream), scratch, part_ld, bps, D, dgamma_beta,
                        dgb_ld, 1.0f, 1);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256, B), dim3(256), 0, S_(stream), scratch + part_ld / 2, part_ld, bps, D,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64, B), dim3(1024), 0, S_(stream), scratch + part_ld / 2, part_ld, bps, D,
                        dgamma_beta + gb_half, dgb_ld, 1.0f, 1);
   }
   DN_CHECK_LAUNCH("dn_rmsnorm_backward");
@@ -594,7 +610,7 @@ extern "C" int dn_colsum(const void* src, int32_t ld, int32_t dtype, int32_t gro
   const int chunks = colsum_chunks(groups, rows_per_group);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 4 + 255) / 256, groups * chunks), dim3(256), 0, S_(stream), src, ld, dtype,
                      rows_per_group, chunks, C, scratch, C);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256, groups), dim3(256), 0, S_(stream), scratch, C, chunks, C, out, out_ld,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, S_(stream), scratch, C, chunks, C, out, out_ld,
                      scale, accumulate);
   DN_CHECK_LAUNCH("dn_colsum");
   return DN_OK;

@@ -143,6 +143,11 @@ class VaeTrainEngine:
         lengths = lengths.to(dev, torch.int32).contiguous()
         if noise is None:  # CPU generator, [B, z, T] like upstream (distributions.py:38-40)
             noise = torch.randn(B, self.z, T).transpose(1, 2)
+        elif isinstance(noise, tuple):  # ("philox", seed, offset): the build's own device generator (throughput runs)
+            from . import ops
+
+            with torch.cuda.device(dev):
+                noise = ops.randn((B, T, self.z), seed=int(noise[1]), offset=int(noise[2]), device=dev)
         noise = noise.to(dev, torch.float32).contiguous()
         if ntokens is None:
             ntokens = int(lengths.sum().item())
