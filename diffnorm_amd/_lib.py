@@ -92,7 +92,7 @@ class VaeTrainBatch(C.Structure):
     _fields_ = [("feat", C.c_void_p), ("units", C.c_void_p), ("lengths", C.c_void_p), ("noise", C.c_void_p), ("B", C.c_int32),
                 ("T", C.c_int32), ("ntokens", C.c_int32), ("w_lsce", C.c_float), ("w_mse", C.c_float), ("w_kl", C.c_float),
                 ("label_smoothing", C.c_float), ("loss_scale", C.c_float), ("stats", C.c_void_p), ("logits_out", C.c_void_p),
-                ("recon_out", C.c_void_p)]
+                ("recon_out", C.c_void_p), ("ext_dlogits", C.c_void_p)]
 
 
 # every symbol include/diffnorm_hip.h declares: name -> (restype, argtypes)

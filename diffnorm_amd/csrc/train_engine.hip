@@ -972,6 +972,7 @@ extern "C" int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* b, in
   for (int stage = first_stage; stage <= last_stage; ++stage) {
     if (stage == 0) {
       // decoder_lm: dW, db, d rec = d logits . W_lm
+      if (b->ext_dlogits) DN_TRY(dn_convert_rows(b->ext_dlogits, DN_F32, V, pl.dlogits, dtype, padn(V), M, V, s));
       WgTap tap{pl.rec_act, Dp, 0};
       DN_TRY(weight_grad(c, &tap, 1, D, pl.dlogits, padn(V), V, c.G(m->lm_W)));
       DN_TRY(bias_grad(c, pl.dlogits, padn(V), dtype, 1, M, V, c.G(m->lm_b), 0));

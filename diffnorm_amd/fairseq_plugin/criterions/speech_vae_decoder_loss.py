@@ -27,6 +27,17 @@ class SpeechVAEDecoderLoss(FairseqCriterion):
         model_kwargs = dict(src_feature=sample["net_input"]["src_tokens"], src_lengths=sample["net_input"]["src_lengths"],
                             tgt_lengths=sample["reduce_target_lengths"], unk_token=self.task.tgt_dict.unk_index)
         unit = sample["reduce_target_unit"]
+        if sample.get("posterior_noise") is not None:  # parity runs inject the draw the reference makes on the CPU generator
+            model_kwargs["noise"] = sample["posterior_noise"]
+        if getattr(getattr(model, "encoder", None), "_train_engine", None) is not None:
+            # HIP training engine: LS-CE, masked MSE and KL and their gradients are kernels of the engine (the same algebra as
+            # below, :60-83); the loss tensor is autograd-connected to the flat parameter through the HIP backward
+            stats, _ = model(sample["reduce_target"], unit, return_stats=True, ntokens=sample["ntokens"], **model_kwargs)
+            host = stats.tolist()  # one read for the logging output, like upstream's utils.item calls
+            sample_size = sample["nsentences"]
+            logging_output = {"loss": host[0], "nll_loss": host[1], "mse_loss": host[2], "kl_loss": host[3], "acc": host[4],
+                              "ntokens": sample["ntokens"], "nsentences": sample["nsentences"], "sample_size": sample_size}
+            return stats[0], sample_size, logging_output
         mse_loss, lm_pred, kl_loss = model(sample["reduce_target"], unit, **model_kwargs)
         lprobs = model.get_normalized_probs([lm_pred], log_probs=True)
         lprobs = lprobs.view(-1, lprobs.size(-1))

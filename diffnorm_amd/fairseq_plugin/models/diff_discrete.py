@@ -18,9 +18,9 @@ def _load_speech_decoder(args):
 
         models, _, _ = fairseq.checkpoint_utils.load_model_ensemble_and_task([path])
         return models[0]
-    vae = SpeechVAEEncoderDecoder(dim=768, latent_dim=args.latent_dim, dtype=dtype)
+    vae = SpeechVAEEncoderDecoder(dim=getattr(args, "feature_dim", 768), latent_dim=args.latent_dim, dtype=dtype)
     if path:
-        state = torch.load(path, map_location="cpu")
+        state = torch.load(path, map_location="cpu", weights_only=False)
         sd = state["model"] if "model" in state else state
         vae.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
     return types.SimpleNamespace(encoder=vae)
@@ -51,7 +51,11 @@ class DiffDiscreteModel(FairseqEncoderModel):
         speech_decoder.encoder.eval()
         for p in speech_decoder.encoder.parameters():
             p.requires_grad = False
-        encoder = LatentDiscreteModel(speech_decoder, 512, args.latent_dim, timesteps=getattr(args, "diffusion_timesteps", 200),
+        # upstream passes the --latent_dim flag as the denoiser's channel count (:84), which equals the VAE's latent width at
+        # the recipe's feature dim 768; asking the VAE keeps other feature dims (tests) consistent
+        vae = speech_decoder.encoder
+        z = vae.latent_channels() if hasattr(vae, "latent_channels") else args.latent_dim
+        encoder = LatentDiscreteModel(speech_decoder, getattr(args, "denoiser_dim", 512), z, timesteps=getattr(args, "diffusion_timesteps", 200),
                                       multitask=args.multitask, dtype=getattr(args, "hip_dtype", "bf16"))
         return cls(args, encoder)
 

@@ -15,7 +15,8 @@ class SpeechVAEDecoder(FairseqEncoderModel):
     def forward(self, target_feature, target_unit, **model_kwargs):
         """-> (mse_loss, lm_logits [B,T,1004], kl_loss) (reference :35-44)."""
         tgt_mask = lengths_to_mask(model_kwargs["tgt_lengths"], target_feature.shape[1])
-        return self.encoder(target_feature, target_unit, tgt_mask)
+        extra = {k: model_kwargs[k] for k in ("noise", "ntokens", "return_stats") if model_kwargs.get(k) is not None}
+        return self.encoder(target_feature, target_unit, tgt_mask, **extra)
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
         logits = net_output[0]
@@ -23,7 +24,8 @@ class SpeechVAEDecoder(FairseqEncoderModel):
 
     @classmethod
     def build_model(cls, args, task):
-        encoder = SpeechVAEEncoderDecoder(dim=768, latent_dim=args.latent_dim, dtype=getattr(args, "hip_dtype", "bf16"))
+        encoder = SpeechVAEEncoderDecoder(dim=getattr(args, "feature_dim", 768), latent_dim=args.latent_dim,
+                                          dtype=getattr(args, "hip_dtype", "bf16"))
         return cls(args, encoder)
 
     @staticmethod

@@ -3,8 +3,8 @@ criterion construction and the train / valid step contract around the HIP-backed
 
 `load_dataset` reads the reference's manifests (`diffnorm_amd.data`: `{feat_dir}/{split}.manifest.tsv` + `{data}/{split}.tsv`)
 when `--src-feat-dir/--tgt-feat-dir` are given, else serves the synthetic (feat, unit) pairs the BASELINE configs
-use.  `train_step` runs the forward (the loss dict is real);
-backward kernels are scope row f2, so it raises unless `ignore_grad` is set.
+use.  `train_step` is the reference's: criterion forward, then `optimizer.backward(loss)` -- for the speech VAE that is the HIP
+training engine's backward.
 """
 import zlib
 
@@ -110,12 +110,18 @@ class _SpeechTaskBase(FairseqTask):
         return CRITERION_REGISTRY[args.criterion](self)
 
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+        """reference speech_decoder_task.py:212-225: forward through the criterion, `optimizer.backward(loss)`.  The model's
+        VAE is switched to the HIP training engine on first use (its flat master buffer becomes the parameter the optimizer
+        sees); the backward pass behind `loss.backward()` is dn_vae_train_backward."""
         model.train()
+        enc = getattr(model, "encoder", None)
+        if hasattr(enc, "enable_training"):
+            enc.enable_training()
         loss, sample_size, logging_output = criterion(model, sample)
-        if not ignore_grad:
-            raise NotImplementedError("backward kernels for the HIP path are scope row f2 (not built); "
-                                      "train_step supports ignore_grad=True (forward + logging) only")
-        return loss * 0, sample_size, logging_output
+        if ignore_grad:
+            loss = loss * 0
+        optimizer.backward(loss)
+        return loss, sample_size, logging_output
 
     def valid_step(self, sample, model, criterion):
         model.eval()

@@ -124,6 +124,35 @@ class Model(_ParamTree):
         return self.forward(*args, **kwargs)  # no prompt branch: guidance is the identity (:813-826)
 
 
+class _VaeStepFn(torch.autograd.Function):
+    """Autograd node around the HIP training engine: forward = dn_vae_train_forward (activations stay in the engine's
+    workspace), backward = dn_vae_train_backward, which ADDS the parameter gradients into the flat gradient buffer that is
+    `flat_params.grad` (so nothing is returned for the parameter).  Outputs: stats [8] (loss, nll, mse, kl, acc, ...) and the
+    logits.  Two ways to differentiate it: through stats[0], the criterion's own loss (fused LS-CE gradient; the incoming
+    gradient must be 1, or 0 for fairseq's ignore_grad), or through (stats[2], logits, stats[3]) = (mse_loss, lm_logits,
+    kl_loss), the reference model's return values, for a caller that builds its loss itself."""
+
+    @staticmethod
+    def forward(ctx, flat, module, feat, units, lengths, noise, ntokens):
+        eng = module._train_engine
+        stats, logits, _ = eng.forward(feat, units, lengths, noise=noise, ntokens=ntokens, want_logits=True)
+        ctx.module = module
+        return stats.clone(), logits
+
+    @staticmethod
+    def backward(ctx, g_stats, g_logits):
+        eng = ctx.module._train_engine
+        gs = [0.0] * 8 if g_stats is None else [float(v) for v in g_stats.tolist()]  # one host read of 8 floats
+        if gs[0] != 0.0:
+            if gs[0] != 1.0 or any(v != 0.0 for v in gs[1:]):
+                raise NotImplementedError("the fused criterion loss of the HIP VAE is differentiated with gradient 1 (no loss scaling)")
+            eng.backward()
+        elif gs[2] != 0.0 or gs[3] != 0.0 or (g_logits is not None and bool(g_logits.ne(0).any())):  # zero: fairseq's ignore_grad
+            ext = g_logits if g_logits is not None else torch.zeros_like(eng._keep[5])
+            eng.backward(ext_dlogits=ext, d_mse=gs[2], d_kl=gs[3])
+        return None, None, None, None, None, None, None
+
+
 class SpeechVAEEncoderDecoder(_ParamTree):
     """reference latent_module.py:1035-1142 (WaveNet encoder -> diagonal Gaussian -> WaveNet + transformer decoder
     -> 1004-way unit logits).  `latent_dim` is the upstream constructor flag (16 / 32 / 128)."""
@@ -132,12 +161,71 @@ class SpeechVAEEncoderDecoder(_ParamTree):
         super().__init__()
         self.dim, self.latent_dim = dim, latent_dim
         self.arith = dtype
+        self._train_engine = None
         self._adopt(synthetic.random_vae_state_dict(dim, latent_dim, seed=seed))
 
     def max_positions(self):
         return None
 
+    def latent_channels(self) -> int:
+        """Width of the posterior sample: dim / prod(chan_mults) / 2 (:1044-1051, 1067-1070)."""
+        from .packing import vae_mults
+
+        z = self.dim
+        for m in vae_mults(self.latent_dim):
+            z //= m
+        return z // 2
+
+    # ---- training (SURVEY 8 f2): the flat packed master buffer of the HIP training engine becomes THE parameter ----
+    def enable_training(self):
+        """Switches the module to the training engine (diffnorm_amd/training.py): its per-tensor parameters are replaced by
+        one flat `flat_params` Parameter that aliases the engine's fp32 master buffer, with `.grad` aliasing the engine's
+        gradient buffer -- any elementwise optimizer (fairseq's Adam included), gradient clipping by global norm and an
+        explicit flat all-reduce (fairseq's legacy_ddp) work on it unchanged.  `state_dict()` / `load_state_dict()` keep
+        speaking the reference's key layout."""
+        if self._train_engine is not None:
+            return self._train_engine
+        from . import training
+
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        dev = self.device
+        eng = training.VaeTrainEngine(sd, dim=self.dim, latent_dim=self.latent_dim, dtype=self.arith, device=dev)
+        for name in list(self._modules):
+            del self._modules[name]
+        self.flat_params = nn.Parameter(eng.master)
+        self.flat_params.grad = eng.grads
+        self._train_engine = eng
+        self._engine = None
+        return eng
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if self._train_engine is None:
+            return super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        from collections import OrderedDict
+
+        out = OrderedDict() if destination is None else destination
+        for k, v in self._train_engine.state_dict().items():
+            out[prefix + k] = v
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self._train_engine is None:
+            return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        want = set(self._train_engine.state_dict())
+        got = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        missing_keys += [prefix + k for k in want - set(got)]
+        unexpected_keys += [prefix + k for k in set(got) - want]
+        if not (want - set(got)):
+            self._train_engine.load_state_dict({k: got[k] for k in want})
+
     def engine(self) -> engine.VaeEngine:
+        if self._train_engine is not None:  # inference engine rebuilt from the master buffer when an update has happened
+            key = ("train", self._train_engine.update_count)
+            if self._engine is None or self._engine_key != key:
+                self._engine = engine.VaeEngine(self._train_engine.state_dict(), dim=self.dim, latent_dim=self.latent_dim,
+                                                dtype=self.arith, device=self.device)
+                self._engine_key = key
+            return self._engine
         key = self._state_key()
         if self._engine is None or self._engine_key != key:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
@@ -164,8 +252,20 @@ class SpeechVAEEncoderDecoder(_ParamTree):
         recon, logits, _ = self.engine().decode(latent, _mask_to_lengths(mask), want_units=False)
         return recon, logits
 
-    def forward(self, input_feature, input_token, mask, noise=None):
-        """-> (mse_loss, lm_result, kl_loss) (:1118-1142); forward only (backward kernels: scope row f2)."""
+    def forward(self, input_feature, input_token, mask, noise=None, ntokens=None, return_stats=False):
+        """-> (mse_loss, lm_result, kl_loss) (:1118-1142).  After `enable_training()` the three are autograd-connected to
+        `flat_params` through the HIP backward (`_VaeStepFn`); `return_stats=True` returns the engine's statistics vector
+        [loss, nll_loss, mse_loss, kl_loss, acc, ...] instead (the criterion's fused path)."""
+        if self._train_engine is not None:
+            lengths = _mask_to_lengths(mask)
+            if ntokens is None:
+                ntokens = int(lengths.sum())
+            if torch.is_grad_enabled():
+                stats, logits = _VaeStepFn.apply(self.flat_params, self, input_feature, input_token, lengths, noise, ntokens)
+            else:
+                stats, logits, _ = self._train_engine.forward(input_feature, input_token, lengths, noise=noise, ntokens=ntokens,
+                                                              want_logits=True)
+            return (stats, logits) if return_stats else (stats[2], logits, stats[3])
         e = self.engine()
         B, T, _ = input_feature.shape
         lengths = _mask_to_lengths(mask)

@@ -91,3 +91,60 @@ class Adam:
                                     g.numel(), C.byref(hp), sumsq.data_ptr(), _lib.ptr(self.bf16_copy), _stream()), "dn_adam_step")
         norm = sumsq.sqrt()[0] * grad_scale
         return norm * grad_scale_dev.reshape(-1)[0] if grad_scale_dev is not None else norm
+
+
+class FlatOptimizer:
+    """The part of fairseq's FairseqOptimizer contract a training step uses (fairseq/optim/fairseq_optimizer.py: backward,
+    multiply_grads, clip_grad_norm, step, zero_grad, set_lr / get_lr, state_dict) over the flat buffers of a HIP training
+    engine (diffnorm_amd/training.py).  multiply_grads and the clip coefficient are not separate passes over the gradient:
+    they are recorded and applied inside the Adam kernel (fairseq's own note at trainer.py:925-927 allows exactly this)."""
+
+    def __init__(self, engine, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.engine = engine
+        self.adam = Adam(engine.master, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=0.0,
+                         bf16_copy=engine.work if engine.work is not engine.master else None)
+        self._scale, self._scale_dev, self._max_norm = 1.0, None, 0.0
+
+    def backward(self, loss):
+        loss.backward()
+
+    def multiply_grads(self, c):
+        if torch.is_tensor(c):
+            c = c.to(self.engine.device, torch.float32).reshape(1)
+            self._scale_dev = c if self._scale_dev is None else self._scale_dev * c
+        else:
+            self._scale *= float(c)
+
+    def clip_grad_norm(self, max_norm, aggregate_norm_fn=None):
+        """Returns the norm of the (scaled) gradient as a device scalar; the clip itself happens inside `step`."""
+        self._max_norm = float(max_norm)
+        norm = self.adam.grad_sumsq(self.engine.grads).sqrt()[0] * self._scale
+        return norm * self._scale_dev[0] if self._scale_dev is not None else norm
+
+    def step(self, closure=None):
+        self.adam.clip_norm = self._max_norm
+        self.adam.step(self.engine.grads, grad_scale=self._scale, grad_scale_dev=self._scale_dev)
+        self.engine.refresh()
+        self._scale, self._scale_dev = 1.0, None
+
+    def zero_grad(self):
+        self.engine.zero_grad()
+        self._scale, self._scale_dev = 1.0, None
+
+    def set_lr(self, lr):
+        self.adam.set_lr(lr)
+
+    def get_lr(self):
+        return self.adam.get_lr()
+
+    def state_dict(self):
+        """Adam moments in the reference's parameter layout would need the per-tensor optimizer state of fairseq's Adam; the flat
+        moments are stored as they are, with the step count (resuming needs the same packed layout)."""
+        return {"step": self.adam.step_count, "exp_avg": self.adam.exp_avg.detach().cpu(), "exp_avg_sq": self.adam.exp_avg_sq.detach().cpu(),
+                "lr": self.adam.get_lr()}
+
+    def load_state_dict(self, sd):
+        self.adam.step_count = int(sd["step"])
+        self.adam.exp_avg.copy_(sd["exp_avg"])
+        self.adam.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.adam.set_lr(float(sd["lr"]))

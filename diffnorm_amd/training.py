@@ -95,6 +95,7 @@ class VaeTrainEngine:
 
     def refresh(self):
         """aux <- work: call after every optimizer step (dn_adam_step has already written the bf16 work copy)."""
+        self.update_count = getattr(self, "update_count", 0) + 1
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dn_vae_train_refresh(self.handle, _lib.current_stream()), "dn_vae_train_refresh")
 
@@ -156,16 +157,24 @@ class VaeTrainEngine:
         recon = torch.empty(B, T, self.dim, dtype=torch.float32, device=dev) if want_recon else None
         b = _lib.VaeTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), noise.data_ptr(), B, T, int(ntokens),
                                float(weights[0]), float(weights[1]), float(weights[2]), float(label_smoothing), float(loss_scale),
-                               stats.data_ptr(), _lib.ptr(logits), _lib.ptr(recon))
+                               stats.data_ptr(), _lib.ptr(logits), _lib.ptr(recon), None)
         self._batch, self._keep = b, (feat, units, lengths, noise, stats, logits, recon)
         wp, wn = self._workspace(B, T)
         with torch.cuda.device(dev):
             _lib.check(self.lib.dn_vae_train_forward(self.handle, C.byref(b), wp, wn, _lib.current_stream()), "dn_vae_train_forward")
         return (stats, logits, recon) if (want_logits or want_recon) else stats
 
-    def backward(self, first_stage: int = 0, last_stage: Optional[int] = None):
-        """Backward stages of the last `forward`; gradients are added to `self.grads`."""
+    def backward(self, first_stage: int = 0, last_stage: Optional[int] = None, ext_dlogits: Optional[torch.Tensor] = None,
+                 d_mse: Optional[float] = None, d_kl: Optional[float] = None):
+        """Backward stages of the last `forward`; gradients are added to `self.grads`.  `ext_dlogits` [B,T,vocab] (with `d_mse`,
+        `d_kl` = d loss / d mse_loss, d loss / d kl_loss) replaces the fused criterion gradient: the path of a caller that
+        differentiates (mse_loss, logits, kl_loss) itself."""
         assert self._batch is not None, "backward() needs a forward() first"
+        if ext_dlogits is not None:
+            ext_dlogits = ext_dlogits.to(self.device, torch.float32).contiguous()
+            self._ext = ext_dlogits
+            self._batch.ext_dlogits = ext_dlogits.data_ptr()
+            self._batch.w_mse, self._batch.w_kl = float(d_mse), float(d_kl)
         last_stage = self.n_stages - 1 if last_stage is None else last_stage
         B, T = self._batch.B, self._batch.T
         wp, wn = self._workspace(B, T)
@@ -177,17 +186,16 @@ class VaeTrainEngine:
 def plan_buckets(ranges: Sequence[Tuple[int, int]], min_elems: int) -> List[Tuple[int, int, int]]:
     """Merges consecutive backward-stage ranges (each ends where the previous one starts: the backward walks the buffer from
     its end) into buckets of at least `min_elems` elements.  -> [(last_stage_of_bucket, offset, count)], in completion order."""
-    buckets, hi, lo, n = [], None, None, 0
+    buckets, lo, n, prev_lo = [], None, 0, None
     for stage, (off, cnt) in enumerate(ranges):
         if cnt == 0:
             continue
-        if hi is None:
-            hi = off + cnt
-        assert off + cnt == (lo if lo is not None else hi), "stage ranges must be contiguous, descending"
-        lo, n = off, n + cnt
+        assert prev_lo is None or off + cnt == prev_lo, "stage ranges must be contiguous, descending"
+        prev_lo = lo = off
+        n += cnt
         if n >= min_elems:
             buckets.append((stage, lo, n))
-            hi, lo, n = None, None, 0
+            n = 0
     if n:
         buckets.append((len(ranges) - 1, lo, n))
     return buckets
@@ -271,10 +279,12 @@ class VaeTrainer:
 
     def __init__(self, engine: VaeTrainEngine, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-8, weight_decay: float = 0.0,
                  clip_norm: float = 2.0, warmup_updates: int = 10000, warmup_init_lr: float = 1e-7, group=None,
-                 bucket_mb: float = 64.0):
+                 bucket_mb: float = 64.0, adam=None):
         self.engine = engine
-        self.adam = optim.Adam(engine.master, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm,
-                               bf16_copy=engine.work if engine.work is not engine.master else None)
+        # `adam`: anything with set_lr / step(grads, grad_scale, grad_scale_dev) -- the CPU tests of the exchange logic pass a recorder
+        self.adam = adam if adam is not None else optim.Adam(
+            engine.master, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm,
+            bf16_copy=engine.work if engine.work is not engine.master else None)
         self.schedule = optim.InverseSquareRootSchedule(lr, warmup_updates, warmup_init_lr)
         self.reducer = GradientReducer(engine.grads, engine.stage_ranges(), group=group, bucket_mb=bucket_mb)
         self.group = group

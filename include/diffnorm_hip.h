@@ -451,6 +451,9 @@ typedef struct {
   float* stats;             /* fp32 [8] out: loss, nll_loss, mse_loss, kl_loss, acc, n_valid, lsce/ntokens, 0            */
   float* logits_out;        /* optional fp32 [B, T, vocab]                                                             */
   float* recon_out;         /* optional fp32 [B, T, dim]                                                               */
+  const float* ext_dlogits; /* backward only, optional fp32 [B, T, vocab]: d loss / d logits supplied by the caller (a criterion
+                               that differentiates the logits itself) instead of the fused LS-CE gradient; w_mse / w_kl are
+                               then d loss / d mse_loss and d loss / d kl_loss                                          */
 } DnVaeTrainBatch;
 
 int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out);

@@ -61,7 +61,7 @@ def test_struct_layout_matches_header(lib, tmp_path):
                                                  "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
                                                  "delta"]),
         "DnVaeTrainBatch": (_lib.VaeTrainBatch, ["feat", "units", "lengths", "noise", "B", "T", "ntokens", "w_lsce", "w_mse", "w_kl",
-                                                 "label_smoothing", "loss_scale", "stats", "logits_out", "recon_out"]),
+                                                 "label_smoothing", "loss_scale", "stats", "logits_out", "recon_out", "ext_dlogits"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
                                          "dtype", "max_pos"]),
         "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",

@@ -121,3 +121,82 @@ def test_five_update_trajectory_matches_reference_f32(golden):
         assert abs(float(norm) - traj[it, 5]) <= 2e-3 * traj[it, 5], (it, float(norm), traj[it, 5])
         assert abs(tr.adam.get_lr() - traj[it, 6]) <= 1e-12 + 1e-9 * traj[it, 6]
     TO.compare_grads(eng.state_dict(), g, "p_end/", rtol=2e-3)
+
+
+def _plugin_objects(dtype="f32"):
+    import types
+
+    from diffnorm_amd import fairseq_plugin  # noqa: F401  (registers the names)
+    from diffnorm_amd.fairseq_plugin import registry
+
+    args = types.SimpleNamespace(arch="speech_vae_decoder", criterion="speech_vae_decoder_loss", latent_dim=CFG.latent_dim,
+                                 feature_dim=CFG.dim, hip_dtype=dtype, target_code_size=1000, data="")
+    task = registry.TASK_REGISTRY["speech_decoder"].setup_task(args)
+    model = task.build_model(args)
+    sd = O.make_vae_state_dict(CFG, "train")
+    model.load_state_dict({"encoder." + k: v for k, v in sd.items()}, strict=True)
+    model.to(DEV)
+    return task, model, task.build_criterion(args)
+
+
+def _sample(g, noise):
+    feat, units, lens = _batch(g)
+    return {"net_input": {"src_tokens": feat, "src_lengths": lens}, "reduce_target": feat, "reduce_target_unit": units,
+            "reduce_target_lengths": lens, "target": feat, "target_unit": units, "target_lengths": lens, "ntokens": int(lens.sum()),
+            "nsentences": feat.shape[0], "posterior_noise": noise}
+
+
+def test_plugin_train_step_follows_the_reference_trajectory(golden):
+    """task.train_step -> criterion -> model -> HIP engine, driven like fairseq's trainer (multiply_grads, clip_grad_norm, lr,
+    step) through the FlatOptimizer: the same five updates as the reference's own Adam on its own modules."""
+    from diffnorm_amd import optim
+
+    g = golden("vae_train")
+    lr, warm, warm_init, b1, b2, clip = (float(v) for v in g["hyper"])
+    task, model, criterion = _plugin_objects("f32")
+    eng = model.encoder.enable_training()
+    assert [n for n, _ in model.named_parameters()] == ["encoder.flat_params"]
+    assert set(model.state_dict()) == {"encoder." + k for k in O.make_vae_state_dict(CFG, "train")}
+    opt = optim.FlatOptimizer(eng, lr=lr, betas=(b1, b2))
+    sched = optim.InverseSquareRootSchedule(lr, int(warm), warm_init)
+    traj = g["traj"]
+    for it in range(traj.shape[0]):
+        opt.zero_grad()
+        loss, sample_size, log = task.train_step(_sample(g, torch.from_numpy(g[f"traj_noise{it}"])), model, criterion, opt, it)
+        opt.multiply_grads(1.0 / sample_size)  # world / sample_size on one worker (trainer.py:918-933)
+        norm = opt.clip_grad_norm(clip)
+        opt.set_lr(sched.step_update(it))
+        opt.step()
+        for col, k in enumerate(("loss", "nll_loss", "mse_loss", "kl_loss")):
+            assert abs(log[k] - traj[it, col]) <= 2e-3 * max(1.0, abs(traj[it, col])), (it, k, log[k], traj[it, col])
+        assert abs(float(norm) - traj[it, 5]) <= 2e-3 * traj[it, 5]
+        assert sample_size == 3 and abs(float(loss.detach()) - log["loss"]) < 1e-6
+    TO.compare_grads({k[len("encoder."):]: v for k, v in model.state_dict().items()}, g, "p_end/", rtol=2e-3)
+    # ignore_grad (fairseq's dummy batches): forward + logging, no gradient
+    opt.zero_grad()
+    task.train_step(_sample(g, torch.from_numpy(g["post_noise"])), model, criterion, opt, 5, ignore_grad=True)
+    assert float(eng.grads.abs().max()) == 0.0
+
+
+def test_reference_style_criterion_differentiates_the_model_outputs(golden):
+    """A caller that builds its loss from the model's (mse_loss, lm_logits, kl_loss) -- the reference criterion's own code
+    path -- gets the same parameter gradients as the fused criterion: autograd hands d loss / d logits to the HIP backward."""
+    from diffnorm_amd.latent_module import label_smoothed_nll_loss, lengths_to_mask
+
+    g = golden("vae_train")
+    feat, units, lens = _batch(g)
+    noise = torch.from_numpy(g["post_noise"])
+    task, model, criterion = _plugin_objects("f32")
+    eng = model.encoder.enable_training()
+    eng.zero_grad()
+    loss, _, _ = criterion(model, _sample(g, noise))
+    loss.backward()
+    fused = eng.grads.clone()
+    eng.zero_grad()
+    mse, logits, kl = model.encoder(feat, units, lengths_to_mask(lens, feat.shape[1]), noise=noise)
+    lprobs = torch.log_softmax(logits, dim=-1).view(-1, logits.size(-1))
+    tot, _ = label_smoothed_nll_loss(lprobs, units.to(DEV).view(-1), 0.1, ignore_index=0, reduce=True)
+    own = 0.1 * tot / int(lens.sum()) + 10 * mse + 0.0001 * kl
+    assert abs(float(own) - float(loss)) < 1e-4 * float(loss)
+    own.backward()
+    assert float((eng.grads - fused).norm() / fused.norm()) < 1e-5
