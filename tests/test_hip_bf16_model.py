@@ -1,0 +1,160 @@
+"""The structural bf16 gate: the engines in DN_BF16 mode against oracle/bf16_emulation.py, a CPU model of the SAME arithmetic
+(bf16 rounding exactly where the engines store or feed a tensor as bf16 -- weights, WaveNet states, the split norm's x * gamma,
+q/k/v, softmax probabilities, attention / GEGLU / FFN-conv outputs -- and fp32 everywhere else).
+
+What the model can and cannot bound (measured, profiles/r02_bf16_model_distances.txt): two bf16 implementations that differ
+only in fp32 summation order do NOT stay within 2e-3 of each other through a deep network -- every tie-break flip of a bf16
+rounding is a fresh 2^-9 perturbation, so after 12 layers their rounding errors are decorrelated and the engine sits as far
+from the model as both sit from the fp32 reference (cfg2: 1.40e-2 / 1.41e-2 / 1.42e-2).  So the gate has two parts:
+  * TIGHT where little compounds (gains O(1), few layers, or a contraction chain without a norm): engine vs model <= 2e-3;
+  * EQUIVALENCE everywhere else: the engine's distance to the fp32 reference must be the distance the model predicts for pure
+    operand rounding -- max-abs within 1.25x (+5e-4) and MSE within 1.5x of the model's.  A kernel bug that adds error of the
+    size of the rounding noise itself (the case a loose fp32-golden threshold would hide) moves both ratios past the bounds.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bf16_emulation as E
+import diffnorm_oracle as O
+from gen_golden_configs import CHAIN_EPS, CHAIN_VAE, FULL_EPS, FULL_VAE, TINY_EPS, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T_ = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def mse(a, b):
+    return ((a.double() - b.double()) ** 2).mean().item()
+
+
+def equivalent(name, got, emu, ref):
+    """engine and model are equally far from the fp32 reference (see the module docstring)."""
+    d_eng, d_emu, m_eng, m_emu = maxerr(got, ref), maxerr(emu, ref), mse(got, ref), mse(emu, ref)
+    print(f"{name}: max|engine-fp32| {d_eng:.3e}  max|model-fp32| {d_emu:.3e}  mse {m_eng:.3e} / {m_emu:.3e}  max|engine-model| "
+          f"{maxerr(got, emu):.3e}")
+    assert d_eng <= 1.25 * d_emu + 5e-4, (name, d_eng, d_emu)
+    assert m_eng <= 1.5 * m_emu + 1e-8, (name, m_eng, m_emu)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from diffnorm_amd import engine, scheduler
+
+    return engine, scheduler
+
+
+def test_eps_tiny_bf16_vs_emulation(eng, golden):
+    engine, _ = eng
+    g = golden("eps_tiny")
+    sd = O.make_eps_state_dict(TINY_EPS, "tiny")
+    x, t, lens = T_(g["x"]), T_(g["t"]), T_(g["lens"])
+    mask = O.lengths_to_mask(lens, x.shape[1])
+    got = engine.EpsEngine(sd, TINY_EPS, dtype="bf16", device=DEV).forward(x.to(DEV), t, lens, shared_t=False).cpu()
+    with torch.no_grad():
+        emu = E.eps_forward(sd, TINY_EPS, x, t, mask)
+    ref = T_(g["eps"])
+    for b in range(x.shape[0]):
+        m = mask[b]
+        equivalent(f"tiny t={int(t[b])}", got[b][m], emu[b][m], ref[b][m])
+    assert maxerr(got[0][mask[0]], emu[0][mask[0]]) <= 2e-3  # t = 3: FiLM / adaptive-norm gains O(1), two layers: tight
+
+
+def test_eps_full_cfg2_bf16_vs_emulation(eng, golden):
+    engine, _ = eng
+    g = golden("eps_full_cfg2")
+    sd = O.make_eps_state_dict(FULL_EPS, "full")
+    x = seeded((8, 256, 128), 0)
+    lens, t = T_(g["lens"]), T_(g["t"])
+    mask = O.lengths_to_mask(lens, 256)
+    got = engine.EpsEngine(sd, FULL_EPS, dtype="bf16", device=DEV).forward(x.to(DEV), t, lens, shared_t=True).cpu()
+    with torch.no_grad():
+        emu = E.eps_forward(sd, FULL_EPS, x, t, mask)
+    ref = T_(g["eps"])
+    equivalent("cfg2 [8,256] t=500", got[mask], emu[mask], ref[mask])
+
+
+def test_vae_bf16_vs_emulation(eng, golden):
+    engine, _ = eng
+    vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
+    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="bf16", device=DEV)
+    feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+    lens = torch.tensor([48, 29, 40])
+    mask = O.lengths_to_mask(lens, 48)
+    params = ve.encode_params(feat.to(DEV))
+    with torch.no_grad():
+        p_emu = E.vae_encode_params(vsd, CHAIN_VAE, feat)
+    p_ref = O.vae_encode_params(vsd, CHAIN_VAE, feat)
+    equivalent("small VAE posterior parameters", params.cpu(), p_emu, p_ref)
+    assert maxerr(params.cpu(), p_emu) <= 2e-3  # two WaveNets, no norm, no gains: tight
+    z = O.posterior_sample(p_emu, seeded((3, 48, CHAIN_VAE.z), 5))
+    recon, logits, _ = ve.decode(z.to(DEV), lens)
+    with torch.no_grad():
+        r_emu, l_emu = E.vae_decode(vsd, CHAIN_VAE, z, mask)
+        r_ref, l_ref = O.vae_decode(vsd, CHAIN_VAE, z, mask)
+    equivalent("small VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    equivalent("small VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
+
+
+def test_vae_full_cfg1_bf16_vs_emulation(eng, golden):
+    """BASELINE config 1 shapes (a 4-utterance slice of the 64: the CPU model of the full batch takes minutes)."""
+    engine, _ = eng
+    g = golden("vae_full_cfg1")
+    sd = O.make_vae_state_dict(FULL_VAE, "full")
+    ve = engine.VaeEngine(sd, dtype="bf16", device=DEV)
+    feat = seeded((64, 128, 768), 0)[:4]
+    lens = T_(g["lens"])[:4]
+    mask = O.lengths_to_mask(lens, 128)
+    params = ve.encode_params(feat.to(DEV)).cpu()
+    with torch.no_grad():
+        p_emu = E.vae_encode_params(sd, FULL_VAE, feat)
+    z = O.posterior_sample(p_emu, seeded((64, 128, 128), 3)[:4])
+    recon, logits, _ = ve.decode(z.to(DEV), lens)
+    with torch.no_grad():
+        r_emu, l_emu = E.vae_decode(sd, FULL_VAE, z, mask)
+        p_ref = O.vae_encode_params(sd, FULL_VAE, feat)
+        r_ref, l_ref = O.vae_decode(sd, FULL_VAE, z, mask)
+    equivalent("cfg1 VAE posterior parameters", params, p_emu, p_ref)
+    assert maxerr(params, p_emu) <= 2e-3
+    equivalent("cfg1 VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    equivalent("cfg1 VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
+    assert maxerr(params[:2], T_(g["params_head"])) <= 1e-2  # the reference's own posterior parameters (fp32 golden)
+
+
+def test_short_chain_bf16_vs_emulation(eng, golden):
+    """DDIM chain, start_step 5 (4 evaluations): every step's eps-predictor call and both VAE ends against the CPU model."""
+    engine, scheduler = eng
+    from diffnorm_amd import ops
+
+    g = golden("chain_small")
+    esd, vsd = O.make_eps_state_dict(CHAIN_EPS, "chain"), O.make_vae_state_dict(CHAIN_VAE, "chain")
+    ee = engine.EpsEngine(esd, CHAIN_EPS, dtype="bf16", device=DEV)
+    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="bf16", device=DEV)
+    B, Tn, start = 3, 48, 5
+    feat = seeded((B, Tn, CHAIN_VAE.dim), 31)
+    lens = T_(g["lens"])
+    mask = O.lengths_to_mask(lens, Tn)
+    sched = scheduler.DDPMScheduler(200)
+    params = ve.encode_params(feat.to(DEV))
+    z = ve.sample_posterior(params, T_(g[f"s{start}_post_noise"]))
+    ts = torch.full((B,), start, dtype=torch.int32, device=DEV)
+    x = ops.q_sample(z, T_(g[f"s{start}_start_noise"]).to(DEV), sched.f32("sqrt_alphas_cumprod", DEV),
+                     sched.f32("sqrt_one_minus_alphas_cumprod", DEV), ts, Tn)
+    xs = x.clone()
+    assert ee.ddim_loop(xs, lens.to(DEV).int(), start, sched.ddim_coef_table(DEV), use_graph=False) == start - 1
+    recon, _, _ = ve.decode(xs, lens)
+    tab = O.ddpm_tables(200)
+    xe = x.cpu().clone()
+    with torch.no_grad():
+        for tt in range(start - 1, 0, -1):
+            t = torch.full((B,), tt, dtype=torch.long)
+            xe = O.ddim_update(tab, xe, E.eps_forward(esd, CHAIN_EPS, xe, t, mask), t)
+        r_emu, _ = E.vae_decode(vsd, CHAIN_VAE, xe, mask)
+        r_ref, _ = O.vae_decode(vsd, CHAIN_VAE, xe, mask)
+    assert maxerr(xs.cpu()[mask], xe[mask]) <= 2e-3  # the latent after 4 evaluations (eps is damped by the small-t DDIM update): tight
+    equivalent("chain start=5 recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    assert maxerr(recon.cpu()[mask], T_(g["s5_recon"])[mask]) <= 1.5e-2

@@ -31,11 +31,15 @@ def eng():
     return engine, scheduler
 
 
-# bf16 note: with random-init weights the raw integer timestep drives FiLM / adaptive-norm gains of
-# O(10-30) at t >= 500 (|gamma| ~ 0.1 at t = 3), which amplifies the 2^-9 operand rounding of ANY bf16-operand
-# implementation (the CPU oracle with bf16-rounded operands shows the same 0.02-0.13 deviations at t = 500/999).
-# So the 1e-2 max-abs budget is asserted where the gains are O(1) (small t) and as an MSE budget elsewhere;
-# f32 mode carries the strict 1e-3 max-abs check everywhere.
+# bf16 budget, stated once: north_star asks 1e-2 for bf16.  Against the fp32 golden outputs the bf16 engine measures
+#   tiny t = 3: 3.9e-3 | tiny t = 500 / 999: 3.3e-2 / 2.3e-2 | cfg2 (t = 500): max-abs 1.41e-2, eps-MSE 1.08e-5 | chains: 1.06-1.23e-2
+# i.e. the eps-MSE criterion of BASELINE config 2 is met 1000x over and max-abs is met where the FiLM / adaptive-norm gains are O(1)
+# (small t), and MISSED by 1.4x at t = 500 (random-init weights turn the raw integer timestep into gains of 10-30, which amplify
+# the 2^-9 operand rounding).  That the miss is operand rounding and not a kernel defect is what tests/test_hip_bf16_model.py
+# pins: a CPU model with the engine's rounding points lands at the same distance from fp32 (1.42e-2 on cfg2, MSE within 6 %), and
+# its ablation (profiles/r02_bf16_rounding_ablation.txt) shows no single rounding point dominating -- weights 1.2e-2 alone, every
+# activation kept fp32 still 1.0e-2 -- so only a split-operand mode (3 MFMAs per product) would close it.  The thresholds below
+# are the measured values + 15 %, not a loose band; f32 mode carries the strict 1e-3 check everywhere.
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
 def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
     engine, _ = eng
@@ -51,9 +55,9 @@ def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
         # padded frames are computed like upstream too (dense), so the whole tensor matches
         assert maxerr(got, ref) < tol * 3
     else:
-        assert maxerr(got[0][mask[0]], ref[0][mask[0]]) < tol  # t = 3
-        assert ((got - ref)[mask] ** 2).mean().item() < 1e-3     # t = 500 / 999 included
-        assert maxerr(got[mask], ref[mask]) < 0.3
+        assert maxerr(got[0][mask[0]], ref[0][mask[0]]) < tol  # t = 3: inside north_star's 1e-2
+        assert ((got - ref)[mask] ** 2).mean().item() < 1e-4     # t = 500 / 999 included (measured 3.4e-5)
+        assert maxerr(got[mask], ref[mask]) < 3.9e-2            # measured 3.3e-2 at t = 500 (see the note above)
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
@@ -152,8 +156,8 @@ def test_eps_full_cfg2_vs_reference_golden(eng, golden, dtype, tol):
     print(f"cfg2 {dtype}: max abs {err:.3e}  mse {mse:.3e}  ref rms {ref[mask].pow(2).mean().sqrt().item():.3f}")
     if dtype == "f32":
         assert err < tol and mse < tol
-    else:  # eps-MSE is BASELINE config 2's criterion; max-abs sits at 1-2e-2 at t = 500 (see note above)
-        assert mse < 1e-4 and err < 3e-2
+    else:  # eps-MSE is BASELINE config 2's criterion (1e-2): measured 1.08e-5; max-abs measured 1.41e-2 = 1.4x the 1e-2 budget (note above)
+        assert mse < 2e-5 and err < 1.65e-2
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
@@ -188,7 +192,7 @@ def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
             recon, logits, u = ve.decode(xs, lens)
             err = maxerr(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask])
             print(f"chain start={start} {dtype} graph={use_graph}: recon max abs err {err:.3e}")
-            assert err < tol * 5  # (start-1) sequential evaluations accumulate
+            assert err < (5e-3 if dtype == "f32" else 1.45e-2)  # measured: f32 2.4e-6; bf16 1.06e-2 / 1.19e-2 / 1.23e-2 (start 1 / 5 / 50)
             got_units = torch.cat([u[i, : int(lens[i])] for i in range(B)]).cpu().numpy()
             agree = (got_units == g[f"s{start}_units"]).mean()
             assert agree >= (0.99 if dtype == "f32" else 0.9), agree
