@@ -43,8 +43,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="one stream per chain instead of two forked half-batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on host threads of the CPU baseline (host share of one GPU)")
+    ap.add_argument("--cpu-sample-batch", type=int, default=0, help="CPU baseline on a slice of this many sequences (0 = the whole batch)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cap on host threads of the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--no-full-chain", action="store_true", help="skip the end-to-end 998-evaluation chain leg")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 legs (20 steps + the full chain for the unit agreement)")
     return ap.parse_args()
 
 
@@ -117,14 +119,28 @@ def usable_cores(cap):
     return max(1, min(n, cap))
 
 
+def host_cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
 def cpu_baseline(sd, cfg, B, T, timesteps, sample_b, max_threads):
-    """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/golden) on the host cores."""
+    """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/golden) on the node's own host cores: every core
+    this process may use (affinity mask / cgroup quota; `max_threads` <= 0 = no further cap), un-sliced [B, T] steps of the same
+    workload -- one warm-up step, then steps until ~10 s have passed (at least one).  `sample_b` < B times a slice instead."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
 
     import diffnorm_oracle as O
 
-    cores = usable_cores(max_threads)
+    cores = usable_cores(max_threads if max_threads > 0 else 1 << 30)
     torch.set_num_threads(cores)
     ocfg = O.EpsConfig(dim=cfg.dim, latent_dim=cfg.latent_dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head,
                        wavenet_layers=cfg.wavenet_layers, wavenet_stacks=cfg.wavenet_stacks, dim_cond_mult=cfg.dim_cond_mult)
@@ -147,9 +163,12 @@ def cpu_baseline(sd, cfg, B, T, timesteps, sample_b, max_threads):
             if dt > 10.0 or n >= 64:
                 break
     steps_per_s = n / dt * (sample_b / B)  # sequences are independent: a B-sequence step costs B/sample_b as much
-    return {"value": steps_per_s, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} step(s) of [{sample_b},{T},{cfg.latent_dim}] (a {sample_b}/{B} slice of the batch; "
-                      f"rate scaled by {sample_b}/{B}) in {dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
+    model, total = host_cpu_info()
+    sliced = "" if sample_b == B else f" (a {sample_b}/{B} slice of the batch; rate scaled by {sample_b}/{B})"
+    return {"value": steps_per_s, "unit": "denoising-steps/s", "cores": cores, "kind": "port", "host_cores_total": total,
+            "cpu_model": model,
+            "sample": f"{n} un-sliced step(s) of [{sample_b},{T},{cfg.latent_dim}]{sliced} in {dt:.1f} s, torch {torch.__version__} fp32, "
+                      f"{cores} of the host's {total} logical cores (affinity / cgroup limit of this process)"}
 
 
 def launch_ranks(args):
@@ -165,6 +184,65 @@ def launch_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
+
+
+def full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched):
+    """Secondary figures of the same workload (rank 0, N = 1): the config AS STATED end to end -- feats [B,T,768] -> VAE encode ->
+    noise at start_step 999 -> 998 evaluations -> VAE decode -> units, wall clock including the per-chain set-up -- in the headline
+    dtype, and (unless --no-f32) the exact-fp32 mode: 20 mid-chain steps and the same full chain for the unit agreement."""
+    import torch
+
+    from diffnorm_amd import engine, ops, synthetic
+
+    out = {}
+    vsd = synthetic.random_vae_state_dict(768, 128, seed=1)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(B, T, 768, generator=g).to(dev)
+    lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
+    post = ops.randn((B, T, 128), seed=99, device=dev)
+    start_noise = ops.randn((B, T, 128), seed=98, device=dev)
+    start = args.timesteps - 1
+    t_start = torch.full((B,), start, dtype=torch.int32, device=dev)
+    sa, s1 = sched.f32("sqrt_alphas_cumprod", dev), sched.f32("sqrt_one_minus_alphas_cumprod", dev)
+
+    def chain(eps_eng, vae_eng):
+        with torch.cuda.stream(stream):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            z = vae_eng.encode(feat, post)
+            x = ops.q_sample(z, start_noise, sa, s1, t_start, T)
+            n = eps_eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, split=not args.no_split)
+            recon, _, units = vae_eng.decode(x, lengths, want_logits=False)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, n, x, units
+
+    vae = engine.VaeEngine(vsd, dtype=args.dtype, device=dev)
+    chain(eng, vae)  # first call pays graph capture / workspace growth: the timed call below is a steady-state chain
+    wall, n, x_main, units_main = chain(eng, vae)
+    out["full_chain"] = {"dtype": args.dtype, "evaluations": n, "wall_s": wall, "steps_per_s_incl_setup_and_vae": n / wall,
+                         "what": f"feats [{B},{T},768] -> VAE encode -> start_step {start} -> {n} eps-predictor evaluations + DDIM updates "
+                                 f"-> VAE decode -> units (conditioning table, graph launch and both VAE ends inside the clock)"}
+    del vae
+    if args.no_f32 or args.dtype == "f32":
+        return out
+    eng32 = engine.EpsEngine(sd, cfg, dtype="f32", device=dev)
+    vae32 = engine.VaeEngine(vsd, dtype="f32", device=dev)
+    with torch.cuda.stream(stream):
+        x = ops.randn((B, T, cfg.latent_dim), seed=1234, device=dev)
+        eng32.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=3, split=not args.no_split)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng32.ddim_loop(x, lengths, start - 3, coef, use_graph=not args.no_graph, max_evals=20, split=not args.no_split, keep_table=True)
+        torch.cuda.synchronize()
+        out["f32_steps_per_s"] = 20 / (time.perf_counter() - t0)
+    wall32, n32, x32, units32 = chain(eng32, vae32)
+    valid = torch.ones_like(units_main, dtype=torch.bool)
+    out["f32_full_chain_wall_s"] = wall32
+    out["bf16_vs_f32_after_full_chain"] = {
+        "unit_agreement": float((units_main == units32)[valid].float().mean()),
+        "latent_rel_rms_diff": float((x_main - x32).pow(2).mean().sqrt() / x32.pow(2).mean().sqrt()),
+        "what": f"same features, posterior and start noise through all {n32} evaluations in {args.dtype} and in exact fp32"}
+    return out
 
 
 def run_sampling(args, ctx):
@@ -264,8 +342,11 @@ def run_sampling(args, ctx):
         if sb is not None and (B, T, args.dtype) == (32, 512, "bf16"):
             result["hbm_bytes_per_step"] = sb
             result["hbm_gbps_per_gpu"] = sb * K / dt / 1e9
+        if world == 1 and not args.no_full_chain:
+            result.update(full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched))
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B), args.cpu_threads)
+            result["cpu_baseline"] = cpu_baseline(sd, cfg, B, T, args.timesteps, min(args.cpu_sample_batch, B) if args.cpu_sample_batch > 0 else B,
+                                                  args.cpu_threads)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
 

@@ -75,7 +75,12 @@ class GaussianStep(C.Structure):
                 ("eta", C.c_float)]
 
 
-GD_COLS = 9
+GD_COLS = 12
+
+
+class GaussianMoments(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "model_out", "x_start", "t", "table", "mean", "variance", "log_variance", "pred_xstart",
+                                          "vb", "reverse_sample")] + [(n, C.c_int32) for n in ("N", "inner", "learned_range", "clip_denoised")]
 
 
 class EpsConfig(C.Structure):
@@ -143,6 +148,7 @@ SYMBOLS = {
     "dn_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dn_gaussian_step": (C.c_int, [C.POINTER(GaussianStep), _vp]),
+    "dn_gaussian_moments": (C.c_int, [C.POINTER(GaussianMoments), _vp]),
     "dn_posterior_sample": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_argmax_units": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_randn": (C.c_int, [_vp, _i64, _u64, _u64, _vp]),

@@ -305,6 +305,62 @@ __global__ __launch_bounds__(256) void gaussian_step_kernel(const DnGaussianStep
   }
 }
 
+// p_mean_variance / q_posterior_mean_variance / ddim_reverse_sample / the VB term, one thread per element (header: DnGaussianMoments)
+__global__ __launch_bounds__(256) void gaussian_moments_kernel(const DnGaussianMoments p) {
+  const int64_t total = (int64_t)p.N * p.inner;
+  const int cmul = p.learned_range ? 2 : 1;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / p.inner);
+    const int64_t rem = i - (int64_t)n * p.inner;
+    const int tn = p.t[n];
+    const float* tb = p.table + (int64_t)tn * DN_GD_COLS;
+    const float xv = p.x[i];
+    if (!p.model_out) {  // q(x_{t-1} | x_t, x_0)
+      const float xs = p.x_start[i];
+      if (p.mean) p.mean[i] = __fadd_rn(__fmul_rn(tb[2], xs), __fmul_rn(tb[3], xv));
+      if (p.variance) p.variance[i] = tb[10];
+      if (p.log_variance) p.log_variance[i] = tb[5];
+      continue;
+    }
+    const float eps = p.model_out[(int64_t)n * p.inner * cmul + rem];
+    float x0 = __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));
+    if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    float logvar = tb[4], var = tb[11];
+    if (p.learned_range) {
+      const float v = p.model_out[(int64_t)n * p.inner * 2 + p.inner + rem];
+      const float frac = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);
+      logvar = __fadd_rn(__fmul_rn(frac, tb[6]), __fmul_rn(__fsub_rn(1.0f, frac), tb[5]));
+      var = expf(logvar);
+    }
+    const float mean = __fadd_rn(__fmul_rn(tb[2], x0), __fmul_rn(tb[3], xv));
+    if (p.mean) p.mean[i] = mean;
+    if (p.variance) p.variance[i] = var;
+    if (p.log_variance) p.log_variance[i] = logvar;
+    if (p.pred_xstart) p.pred_xstart[i] = x0;
+    if (p.reverse_sample) {  // (:583-596)
+      const float e2 = __fdiv_rn(__fsub_rn(__fmul_rn(tb[0], xv), x0), tb[1]);
+      const float abn = tb[9];
+      p.reverse_sample[i] = __fadd_rn(__fmul_rn(x0, sqrtf(abn)), __fmul_rn(sqrtf(__fsub_rn(1.0f, abn)), e2));
+    }
+    if (p.vb && p.x_start) {
+      const float xs = p.x_start[i];
+      float v;
+      if (tn != 0) {  // normal_kl(true_mean, true_log_variance_clipped, mean, log_variance), diffusion_utils.py:10-34
+        const float tm = __fadd_rn(__fmul_rn(tb[2], xs), __fmul_rn(tb[3], xv));
+        const float lv1 = tb[5], d = tm - mean;
+        v = 0.5f * (-1.0f + logvar - lv1 + expf(lv1 - logvar) + d * d * expf(-logvar));
+      } else {  // -discretized_gaussian_log_likelihood(x_start, means = mean, log_scales = 0.5 * log_variance)
+        const float c = xs - mean, inv = expf(-0.5f * logvar);
+        auto cdf = [](float z) { return 0.5f * (1.0f + tanhf(0.79788456080286535588f * (z + 0.044715f * z * z * z))); };
+        const float cp = cdf(inv * (c + 1.0f / 255.0f)), cm = cdf(inv * (c - 1.0f / 255.0f));
+        const float lp = xs < -0.999f ? logf(fmaxf(cp, 1e-12f)) : (xs > 0.999f ? logf(fmaxf(1.0f - cm, 1e-12f)) : logf(fmaxf(cp - cm, 1e-12f)));
+        v = -lp;
+      }
+      p.vb[i] = v * 1.44269504088896340736f;  // / ln 2: bits
+    }
+  }
+}
+
 static inline int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -390,5 +446,13 @@ extern "C" int dn_gaussian_step(const DnGaussianStep* p, void* stream) {
   DN_CHECK_ARG(p->N > 0 && p->inner > 0 && (p->sampler == 0 || p->sampler == 1), "dn_gaussian_step: bad shape / sampler");
   hipLaunchKernelGGL(gaussian_step_kernel, dim3(ew_grid((int64_t)p->N * p->inner)), dim3(256), 0, (hipStream_t)stream, *p);
   DN_CHECK_LAUNCH("dn_gaussian_step");
+  return DN_OK;
+}
+
+extern "C" int dn_gaussian_moments(const DnGaussianMoments* p, void* stream) {
+  DN_CHECK_ARG(p && p->x && p->t && p->table && (p->model_out || p->x_start), "dn_gaussian_moments: null argument");
+  DN_CHECK_ARG(p->N > 0 && p->inner > 0, "dn_gaussian_moments: bad shape");
+  hipLaunchKernelGGL(gaussian_moments_kernel, dim3(ew_grid((int64_t)p->N * p->inner)), dim3(256), 0, (hipStream_t)stream, *p);
+  DN_CHECK_LAUNCH("dn_gaussian_moments");
   return DN_OK;
 }

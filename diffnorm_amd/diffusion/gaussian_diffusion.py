@@ -1,8 +1,9 @@
 """`GaussianDiffusion` with the reference's names and argument meaning (reference
 fairseq/models/text_to_speech/diffusion/gaussian_diffusion.py:144-786), its per-element arithmetic in the HIP kernels
-`dn_q_sample` and `dn_gaussian_step`.  The float64 schedule tables live on the host exactly like upstream; what the
-device sees is their fp32 cast (what `_extract_into_tensor` produces).  Scope: eps-prediction (the only mean type
-`create_diffusion` builds besides START_X), FIXED_LARGE / FIXED_SMALL / LEARNED_RANGE variances, MSE losses.
+`dn_q_sample`, `dn_gaussian_step` and `dn_gaussian_moments`.  The float64 schedule tables live on the host exactly like upstream;
+what the device sees is their fp32 cast (what `_extract_into_tensor` produces).  Scope: eps-prediction (the only mean type
+`create_diffusion` builds besides START_X), FIXED_LARGE / FIXED_SMALL / LEARNED_RANGE variances, MSE and KL losses incl. the
+learned-variance VB term.
 `model` is any callable (x, t, **kw) -> tensor with channels on dim 1, returning fp32 CUDA tensors."""
 import ctypes as C
 import enum
@@ -60,9 +61,12 @@ class GaussianDiffusion(ScheduleTables):
     def _table(self, device):
         key = str(device)
         if key not in self._dev_tables:
+            fixed_var = (np.append(self.posterior_variance[1], self.betas[1:]) if self.model_var_type == ModelVarType.FIXED_LARGE
+                         else self.posterior_variance)  # (:300-310)
             cols = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
                     self.posterior_mean_coef2, self._fixed_log_variance(), self.posterior_log_variance_clipped,
-                    np.log(self.betas), self.alphas_cumprod, self.alphas_cumprod_prev]
+                    np.log(self.betas), self.alphas_cumprod, self.alphas_cumprod_prev,
+                    np.append(self.alphas_cumprod[1:], 0.0), self.posterior_variance, fixed_var]
             tab = torch.from_numpy(np.stack(cols, axis=1).astype(np.float32)).contiguous().to(device)
             sa, s1 = self.f32("sqrt_alphas_cumprod", device), self.f32("sqrt_one_minus_alphas_cumprod", device)
             self._dev_tables[key] = (tab, sa, s1)
@@ -125,7 +129,8 @@ class GaussianDiffusion(ScheduleTables):
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False):
         """(:459-511)."""
-        device = device or "cuda:0"
+        if device is None:  # upstream takes the model's device (:484-485); a callable has none: follow the noise, else cuda
+            device = noise.device if noise is not None else torch.device("cuda", torch.cuda.current_device())
         img = noise if noise is not None else torch.randn(*shape, device=device)
         for i in list(range(self.num_timesteps))[::-1]:
             t = torch.tensor([i] * shape[0], device=device)
@@ -143,17 +148,99 @@ class GaussianDiffusion(ScheduleTables):
             final = sample
         return final["sample"]
 
+    # ---- moments (dn_gaussian_moments)
+    def _moments(self, x, t, model_out=None, x_start=None, clip_denoised=True, want=()):
+        lib = _lib.load()
+        x = x.float().contiguous()
+        tab, _, _ = self._table(x.device)
+        outs = {k: torch.empty_like(x) for k in want}
+        mo = model_out.float().contiguous() if model_out is not None else None
+        xs = x_start.float().contiguous() if x_start is not None else None
+        learned = self.model_var_type == ModelVarType.LEARNED_RANGE and mo is not None
+        t32 = self._t32(t, x.device)
+        g = lambda k: _lib.ptr(outs.get(k))
+        p = _lib.GaussianMoments(x.data_ptr(), _lib.ptr(mo), _lib.ptr(xs), t32.data_ptr(), tab.data_ptr(), g("mean"), g("variance"),
+                                 g("log_variance"), g("pred_xstart"), g("vb"), g("reverse_sample"), x.shape[0], x[0].numel(),
+                                 int(learned), int(clip_denoised))
+        _lib.check(lib.dn_gaussian_moments(C.byref(p), _lib.current_stream()), "dn_gaussian_moments")
+        return outs
+
+    def _model_out(self, model, x, t, model_kwargs):
+        out = model(x, t, **(model_kwargs or {}))
+        extra = None
+        if isinstance(out, tuple):
+            out, extra = out
+        B, Cc = x.shape[:2]
+        learned = self.model_var_type == ModelVarType.LEARNED_RANGE
+        assert out.shape == ((B, Cc * 2, *x.shape[2:]) if learned else x.shape)
+        return out, extra
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """q(x_{t-1} | x_t, x_0) (:232-252) -> (mean, variance, log_variance_clipped), each shaped like x_t."""
+        assert x_start.shape == x_t.shape
+        o = self._moments(x_t, t, x_start=x_start, want=("mean", "variance", "log_variance"))
+        return o["mean"], o["variance"], o["log_variance"]
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """p(x_{t-1} | x_t) and the x_0 prediction (:254-332)."""
+        if denoised_fn is not None:
+            raise NotImplementedError("denoised_fn is not on the DiffNorm path")
+        out, extra = self._model_out(model, x, t, model_kwargs)
+        o = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("mean", "variance", "log_variance", "pred_xstart"))
+        o["extra"] = extra
+        return o
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        """(:334-339)."""
+        keep = self.model_var_type
+        self.model_var_type = ModelVarType.FIXED_SMALL  # eps carries no variance channels here
+        try:
+            return self._moments(x_t, t, model_out=eps, clip_denoised=False, want=("pred_xstart",))["pred_xstart"]
+        finally:
+            self.model_var_type = keep
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        """x_{t+1} along the deterministic DDIM path (:562-598)."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn hooks are not on the DiffNorm path")
+        out, _ = self._model_out(model, x, t, model_kwargs)
+        o = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("reverse_sample", "pred_xstart"))
+        return {"sample": o["reverse_sample"], "pred_xstart": o["pred_xstart"]}
+
+    def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None):
+        """One term of the variational bound in bits per dimension (:682-713): per-sample means of the kernel's per-element
+        KL / decoder-NLL values."""
+        out, _ = self._model_out(model, x_t, t, model_kwargs)
+        o = self._moments(x_t, t, model_out=out, x_start=x_start, clip_denoised=clip_denoised, want=("vb", "pred_xstart"))
+        return {"output": mean_flat(o["vb"]), "pred_xstart": o["pred_xstart"]}
+
     def training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
-        """MSE branch of (:715-786) for eps-prediction; the learned-variance VB term is not built."""
-        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
-            raise NotImplementedError(self.loss_type)
-        if self.model_var_type == ModelVarType.LEARNED_RANGE:
-            raise NotImplementedError("variational-bound term of learned variances is outside the DiffNorm path")
+        """(:715-786) for eps-prediction: MSE / RESCALED_MSE (with the VB term of a learned variance, computed on the model's
+        output as the reference computes it on the detached mean) and KL / RESCALED_KL.  Forward values (the HIP path of
+        this scheduler has no autograd; the DiffNorm training loss is LatentDiscreteModel.forward)."""
         noise = torch.randn_like(x_start) if noise is None else noise
         x_t = self.q_sample(x_start, t, noise=noise)
+        terms = {}
+        if self.loss_type.is_vb():
+            terms["loss"] = self._vb_terms_bpd(model, x_start, x_t, t, clip_denoised=False, model_kwargs=model_kwargs)["output"]
+            if self.loss_type == LossType.RESCALED_KL:
+                terms["loss"] = terms["loss"] * self.num_timesteps
+            return terms
         out = model(x_t, t, **(model_kwargs or {}))
         misc = None
         if isinstance(out, tuple):
             out, misc = out
-        mse = mean_flat((noise.to(out.device) - out) ** 2)
-        return {"misc": misc, "mse": mse, "loss": mse}
+        terms["misc"] = misc
+        out = out.float()
+        if self.model_var_type == ModelVarType.LEARNED_RANGE:
+            Cc = x_t.shape[1]
+            assert out.shape == (x_t.shape[0], Cc * 2, *x_t.shape[2:])
+            frozen = out.detach()
+            terms["vb"] = self._vb_terms_bpd(lambda *a, **k: frozen, x_start, x_t, t, clip_denoised=False)["output"]
+            if self.loss_type == LossType.RESCALED_MSE:
+                terms["vb"] = terms["vb"] * (self.num_timesteps / 1000.0)
+            out = out[:, :Cc]
+        terms["mse"] = mean_flat((noise.to(out.device) - out) ** 2)
+        terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
+        return terms

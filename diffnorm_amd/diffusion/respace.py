@@ -63,5 +63,8 @@ class SpacedDiffusion(GaussianDiffusion):
     def _step(self, model, *args, **kwargs):
         return super()._step(self._wrap_model(model), *args, **kwargs)
 
+    def _model_out(self, model, *args, **kwargs):  # p_mean_variance / ddim_reverse_sample / _vb_terms_bpd (reference :90-93)
+        return super()._model_out(self._wrap_model(model), *args, **kwargs)
+
     def training_losses(self, model, *args, **kwargs):
         return super().training_losses(self._wrap_model(model), *args, **kwargs)

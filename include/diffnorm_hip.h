@@ -203,7 +203,7 @@ int dn_q_sample(const float* x, const float* noise, float* out, void* out_act, i
  * FIXED_LARGE / FIXED_SMALL (table column 4) or LEARNED_RANGE variance (model_out has 2x channels on dim 1), then
  * sampler 0: mean + 1[t!=0]*exp(.5 logvar)*noise, sampler 1: DDIM with `eta`.  Tensors are fp32 [N, inner] (inner = C*L
  * contiguous; model_out [N, 2*inner] when learned_range).  table: fp32 [T, DN_GD_COLS].                              */
-#define DN_GD_COLS 9
+#define DN_GD_COLS 12
 typedef struct {
   const float* x; const float* model_out; const float* noise; /* noise may be NULL (treated as 0) */
   float* sample; float* pred_xstart;                          /* pred_xstart may be NULL */
@@ -213,6 +213,24 @@ typedef struct {
   float eta;
 } DnGaussianStep;
 int dn_gaussian_step(const DnGaussianStep* p, void* stream);
+
+/* The moments and loss terms of GaussianDiffusion for an eps-predicting model, elementwise over fp32 [N, inner] tensors (every
+ * output pointer optional):
+ *   model_out != NULL: p_mean_variance (diffusion/gaussian_diffusion.py:254-332) -> mean, variance, log_variance, pred_xstart
+ *     (_predict_xstart_from_eps :334-339, clipped to +-1 when clip_denoised); reverse_sample = the DDIM reverse-ODE step
+ *     (ddim_reverse_sample :562-598); with x_start also vb = the per-element term of _vb_terms_bpd (:682-713) in bits:
+ *     KL(q(x_{t-1}|x_t,x_0) || p) for t > 0, the discretised-Gaussian decoder NLL (diffusion_utils.py:66-88) at t = 0.
+ *   model_out == NULL, x_start != NULL: q_posterior_mean_variance (:232-252) -> mean, variance, log_variance.
+ * Table columns (fp32 casts of the float64 schedule): 0 sqrt_recip_abar, 1 sqrt_recipm1_abar, 2 post_coef1, 3 post_coef2,
+ * 4 fixed log variance, 5 posterior_log_variance_clipped (= min_log), 6 log beta (= max_log), 7 abar, 8 abar_prev, 9 abar_next,
+ * 10 posterior_variance, 11 fixed variance.                                                                              */
+typedef struct {
+  const float* x; const float* model_out; const float* x_start;
+  const int32_t* t; const float* table;
+  float *mean, *variance, *log_variance, *pred_xstart, *vb, *reverse_sample;
+  int32_t N, inner, learned_range, clip_denoised;
+} DnGaussianMoments;
+int dn_gaussian_moments(const DnGaussianMoments* p, void* stream);
 
 /* DiagonalGaussianDistribution (distributions.py:24-41, 62-74): params fp32 [M, ldp] = [mean ; logvar];
  * z = mean + exp(0.5*clamp(logvar,-30,20))*noise; kl_rows (optional, fp32 [M]) = 0.5*sum_c(mean^2+var-1-logvar)

@@ -580,6 +580,51 @@ class GaussianDiffusionOracle:
             x = self.p_sample(model, x, t, noises[i], clip_denoised)["sample"]
         return x
 
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True):
+        """gaussian_diffusion.py:562-598 (eta = 0): x_{t+1} along the deterministic path."""
+        out = self.p_mean_variance(model, x, t, clip_denoised)
+        a = self.tab.at
+        eps = (a("sqrt_recip_alphas_cumprod", t, x.ndim) * x - out["pred_xstart"]) / a("sqrt_recipm1_alphas_cumprod", t, x.ndim)
+        abn = a(np.append(self.tab.alphas_cumprod[1:], 0.0), t, x.ndim)  # alphas_cumprod_next (:166)
+        return {"sample": out["pred_xstart"] * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps, "pred_xstart": out["pred_xstart"]}
+
+    def vb_terms_bpd(self, model, x0, xt, t, clip_denoised=True):
+        """gaussian_diffusion.py:682-713 with diffusion_utils.py:10-88: KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) in bits per
+        dimension, the discretised-Gaussian decoder NLL at t = 0."""
+        true_mean, _, true_logvar = self.q_posterior(x0, xt, t)
+        out = self.p_mean_variance(model, xt, t, clip_denoised)
+        lv1, lv2 = true_logvar + torch.zeros_like(xt), out["log_variance"]
+        kl = 0.5 * (-1.0 + lv2 - lv1 + torch.exp(lv1 - lv2) + ((true_mean - out["mean"]) ** 2) * torch.exp(-lv2))
+        kl = kl.flatten(1).mean(dim=1) / np.log(2.0)
+        cdf = lambda v: 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (v + 0.044715 * torch.pow(v, 3))))
+        centered = x0 - out["mean"]
+        inv_stdv = torch.exp(-0.5 * lv2)
+        cdf_plus, cdf_min = cdf(inv_stdv * (centered + 1.0 / 255.0)), cdf(inv_stdv * (centered - 1.0 / 255.0))
+        log_probs = torch.where(x0 < -0.999, torch.log(cdf_plus.clamp(min=1e-12)),
+                                torch.where(x0 > 0.999, torch.log((1.0 - cdf_min).clamp(min=1e-12)),
+                                            torch.log((cdf_plus - cdf_min).clamp(min=1e-12))))
+        nll = (-log_probs).flatten(1).mean(dim=1) / np.log(2.0)
+        return {"output": torch.where(t == 0, nll, kl), "pred_xstart": out["pred_xstart"]}
+
+    def training_losses(self, model, x0, t, noise, loss_type="mse"):
+        """gaussian_diffusion.py:715-786, EPSILON mean type.  loss_type in {"mse", "rescaled_mse", "kl", "rescaled_kl"}; with a
+        learned variance the MSE types add the VB term computed on the (detached) mean prediction."""
+        xt = self.q_sample(x0, t, noise)
+        if loss_type in ("kl", "rescaled_kl"):
+            loss = self.vb_terms_bpd(model, x0, xt, t, clip_denoised=False)["output"]
+            return {"loss": loss * self.num_timesteps if loss_type == "rescaled_kl" else loss}
+        out = self._call(model, xt, t)
+        terms = {}
+        if self.var_type == "learned_range":
+            frozen = out
+            out = torch.split(out, x0.shape[1], dim=1)[0]
+            terms["vb"] = self.vb_terms_bpd(lambda *a: frozen, x0, xt, t, clip_denoised=False)["output"]
+            if loss_type == "rescaled_mse":
+                terms["vb"] = terms["vb"] * self.num_timesteps / 1000.0
+        terms["mse"] = ((noise - out) ** 2).flatten(1).mean(dim=1)
+        terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
+        return terms
+
     def training_mse(self, model, x0, t, noise):
         """training_losses, MSE / EPSILON / fixed variance branch, gaussian_diffusion.py:715-786."""
         xt = self.q_sample(x0, t, noise)

@@ -117,6 +117,53 @@ def gen_gaussian_diffusion(gd):
     save("gaussian_diffusion", **out)
 
 
+def gen_gaussian_moments(gd):
+    """The rest of SURVEY 8 a15: q_posterior_mean_variance, p_mean_variance (three variance types, clipped and not),
+    _predict_xstart_from_eps, ddim_reverse_sample, _vb_terms_bpd and training_losses with a learned variance (MSE + VB,
+    rescaled, and the KL loss types) -- reference outputs on seeded inputs with closed-form models.  x_start has entries at and
+    beyond +-0.999 so that every branch of the discretised decoder likelihood (diffusion_utils.py:66-88) is taken at t = 0."""
+    x0 = seeded((4, 4, 6), 21).clamp(-1.2, 1.2) * 0.8
+    x0[0, 0, :3] = torch.tensor([-1.0, 1.0, 0.9995])
+    x0[0, 1, :2] = torch.tensor([-0.9995, 0.5])
+    xt = seeded((4, 4, 6), 22)
+    noise = seeded((4, 4, 6), 23)
+    t = torch.tensor([0, 1, 417, 999])
+    model = lambda x, ts, **kw: 0.3 * x - 0.01 * ts.float().view(-1, 1, 1) / 100 + 0.05
+    model2 = lambda x, ts, **kw: torch.cat([model(x, ts), torch.tanh(x)], dim=1)
+    out = dict(x0=x0, xt=xt, noise=noise, t=t)
+    for name, kw, mdl in (("large", dict(learn_sigma=False), model), ("small", dict(learn_sigma=False, sigma_small=True), model),
+                          ("learned", dict(learn_sigma=True), model2)):
+        d = gd.create_diffusion(timestep_respacing="", **kw)
+        for clip in (True, False):
+            pm = d.p_mean_variance(mdl, xt, t, clip_denoised=clip)
+            for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                out[f"{name}_pmv{int(clip)}_{k}"] = pm[k] + torch.zeros_like(xt)
+        tr = torch.tensor([0, 1, 417, 998])  # alphas_cumprod_next at 999 is 0: covered too
+        for tt, tag in ((tr, "a"), (t, "b")):
+            rv = d.ddim_reverse_sample(mdl, xt, tt)
+            out[f"{name}_reverse_{tag}"] = rv["sample"]
+        vb = d._vb_terms_bpd(mdl, x0, xt, t, clip_denoised=False)
+        out[f"{name}_vb_output"] = vb["output"]
+    d = gd.create_diffusion(timestep_respacing="", learn_sigma=False)
+    qm, qv, ql = d.q_posterior_mean_variance(x0, xt, t)
+    out.update(qpost_mean=qm, qpost_var=qv + torch.zeros_like(xt), qpost_logvar=ql + torch.zeros_like(xt),
+               xstart_from_eps=d._predict_xstart_from_eps(xt, t, noise))
+    out["t_reverse_a"] = torch.tensor([0, 1, 417, 998])
+    tl_model = lambda x, ts, **kw: (model2(x, ts), None)
+    for name, kw in (("learned_mse", dict(learn_sigma=True)), ("learned_rescaled", dict(learn_sigma=True, rescale_learned_sigmas=True)),
+                     ("learned_kl", dict(learn_sigma=True, use_kl=True))):
+        d = gd.create_diffusion(timestep_respacing="", **kw)
+        terms = d.training_losses(tl_model if "kl" not in name else model2, x0, t, noise=noise)
+        for k in ("loss", "mse", "vb"):
+            if k in terms:
+                out[f"{name}_{k}"] = terms[k]
+    d = gd.create_diffusion(timestep_respacing="ddim50", learn_sigma=True)  # respaced + learned: the wrapped model sees original steps
+    t50 = torch.tensor([0, 1, 20, 49])
+    terms = d.training_losses(tl_model, x0, t50, noise=noise)
+    out.update(ddim50_learned_loss=terms["loss"], ddim50_learned_vb=terms["vb"], t50=t50)
+    save("gaussian_moments", **out)
+
+
 def gen_eps_tiny(lm):
     cfg = TINY_EPS
     sd = O.make_eps_state_dict(cfg, "tiny")
@@ -256,6 +303,7 @@ def main():
     lm, gd = ref_loader.load_reference()
     gen_schedules(lm, gd)
     gen_gaussian_diffusion(gd)
+    gen_gaussian_moments(gd)
     gen_eps_tiny(lm)
     gen_chain(lm)
     if args.full:

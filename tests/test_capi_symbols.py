@@ -60,6 +60,8 @@ def test_struct_layout_matches_header(lib, tmp_path):
         "DnAttnBwdParams": (_lib.AttnBwdParams, ["q", "k", "v", "out", "dout", "dq", "dk", "dv", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq",
                                                  "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
                                                  "delta"]),
+        "DnGaussianMoments": (_lib.GaussianMoments, ["x", "model_out", "x_start", "t", "table", "mean", "variance", "log_variance",
+                                                      "pred_xstart", "vb", "reverse_sample", "N", "inner", "learned_range", "clip_denoised"]),
         "DnVaeTrainBatch": (_lib.VaeTrainBatch, ["feat", "units", "lengths", "noise", "B", "T", "ntokens", "w_lsce", "w_mse", "w_kl",
                                                  "label_smoothing", "loss_scale", "stats", "logits_out", "recon_out", "ext_dlogits"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",

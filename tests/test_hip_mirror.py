@@ -109,8 +109,7 @@ def test_plugin_vae_criterion_end_to_end():
     close(loss, want["loss"], 2e-3)
     close(log["mse_loss"], want["mse_loss"], 1e-3)
     close(log["kl_loss"], want["kl_loss"], 1e-3)
-    with pytest.raises(NotImplementedError):
-        task.train_step(batch, model, crit, optimizer=None, update_num=0)
+    # task.train_step (criterion forward + optimizer.backward through the HIP training engine): tests/test_hip_train.py
 
 
 def test_gaussian_diffusion_matches_reference_golden(golden):
@@ -151,3 +150,44 @@ def test_gaussian_diffusion_matches_reference_golden(golden):
     # the loop entry point itself (own noise): shape/finite only
     out = d5.p_sample_loop(toy, (2, 4, 6), device=DEV)
     assert out.shape == (2, 4, 6) and torch.isfinite(out).all()
+
+
+def test_gaussian_moments_match_reference_golden(golden):
+    """The rest of GaussianDiffusion on the GPU kernel dn_gaussian_moments against the reference's outputs
+    (tests/golden/gaussian_moments.npz): q_posterior_mean_variance, p_mean_variance x 3 variance types x clip on/off,
+    _predict_xstart_from_eps, ddim_reverse_sample, _vb_terms_bpd and training_losses with a learned variance (create_diffusion's
+    DEFAULT), rescaled, KL, and respaced."""
+    from diffnorm_amd.diffusion import create_diffusion
+
+    g = golden("gaussian_moments")
+    x0, xt, noise = (T_(g[k]).to(DEV) for k in ("x0", "xt", "noise"))
+    t = T_(g["t"]).to(DEV)
+    toy = lambda x, ts, **kw: 0.3 * x - 0.01 * ts.float().view(-1, 1, 1) / 100 + 0.05
+    toy2 = lambda x, ts, **kw: torch.cat([toy(x, ts), torch.tanh(x)], dim=1)
+    rel = lambda a, b, tol: close(a.cpu().double() / np.abs(b).max(), b / np.abs(b).max(), tol)
+    for name, kw, mdl in (("large", dict(learn_sigma=False), toy), ("small", dict(learn_sigma=False, sigma_small=True), toy),
+                          ("learned", dict(learn_sigma=True), toy2)):
+        d = create_diffusion("", **kw)
+        for clip in (True, False):
+            pm = d.p_mean_variance(mdl, xt, t, clip_denoised=clip)
+            for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                rel(pm[k], g[f"{name}_pmv{int(clip)}_{k}"], 5e-6)
+        rel(d.ddim_reverse_sample(mdl, xt, T_(g["t_reverse_a"]).to(DEV))["sample"], g[f"{name}_reverse_a"], 5e-6)
+        rel(d.ddim_reverse_sample(mdl, xt, t)["sample"], g[f"{name}_reverse_b"], 5e-6)
+        rel(d._vb_terms_bpd(mdl, x0, xt, t, clip_denoised=False)["output"], g[f"{name}_vb_output"], 2e-5)
+    d = create_diffusion("", learn_sigma=False)
+    qm, qv, ql = d.q_posterior_mean_variance(x0, xt, t)
+    rel(qm, g["qpost_mean"], 2e-6)
+    rel(qv, g["qpost_var"], 2e-6)
+    rel(ql, g["qpost_logvar"], 2e-6)
+    rel(d._predict_xstart_from_eps(xt, t, noise), g["xstart_from_eps"], 2e-6)
+    tl = lambda x, ts, **kw: (toy2(x, ts), None)
+    for name, kw, mdl in (("learned_mse", dict(learn_sigma=True), tl), ("learned_rescaled", dict(learn_sigma=True, rescale_learned_sigmas=True), tl),
+                          ("learned_kl", dict(learn_sigma=True, use_kl=True), toy2)):
+        terms = create_diffusion("", **kw).training_losses(mdl, x0, t, noise=noise)  # learn_sigma=True is create_diffusion's default
+        for k in ("loss", "mse", "vb"):
+            if f"{name}_{k}" in g:
+                rel(terms[k], g[f"{name}_{k}"], 2e-5)
+    terms = create_diffusion("ddim50").training_losses(tl, x0, T_(g["t50"]).to(DEV), noise=noise)
+    rel(terms["loss"], g["ddim50_learned_loss"], 2e-5)
+    rel(terms["vb"], g["ddim50_learned_vb"], 2e-5)

@@ -79,6 +79,41 @@ def test_gaussian_diffusion(golden):
     close(d5.p_sample_loop(_toy, T(g["loop5_xT"]), by_step), g["loop5_out"], 5e-6)
 
 
+def test_gaussian_moments(golden):
+    """The rest of SURVEY 8 a15 (posterior / model moments, DDIM reverse step, VB terms, learned-variance training losses)."""
+    g = golden("gaussian_moments")
+    x0, xt, noise, t = T(g["x0"]), T(g["xt"]), T(g["noise"]), T(g["t"])
+    for name, kw, mdl in (("large", dict(learn_sigma=False), _toy), ("small", dict(learn_sigma=False, sigma_small=True), _toy),
+                          ("learned", dict(learn_sigma=True), _toy2)):
+        d = O.create_diffusion_oracle("", **kw)
+        for clip in (True, False):
+            pm = d.p_mean_variance(mdl, xt, t, clip_denoised=clip)
+            for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                ref = g[f"{name}_pmv{int(clip)}_{k}"]
+                close(pm[k], ref, 2e-6 * max(1.0, float(np.abs(ref).max())))
+        close(d.ddim_reverse_sample(mdl, xt, T(g["t_reverse_a"]))["sample"], g[f"{name}_reverse_a"], 1e-5)
+        close(d.ddim_reverse_sample(mdl, xt, t)["sample"], g[f"{name}_reverse_b"], 1e-4)
+        ref = g[f"{name}_vb_output"]
+        close(d.vb_terms_bpd(mdl, x0, xt, t, clip_denoised=False)["output"] / np.abs(ref).max(), ref / np.abs(ref).max(), 2e-6)
+    d = O.create_diffusion_oracle("", learn_sigma=False)
+    qm, qv, ql = d.q_posterior(x0, xt, t)
+    close(qm, g["qpost_mean"], 1e-6)
+    close(qv + torch.zeros_like(xt), g["qpost_var"], 1e-7)
+    close(ql + torch.zeros_like(xt), g["qpost_logvar"], 1e-5)
+    close(d.predict_xstart_from_eps(xt, t, noise), g["xstart_from_eps"], 1e-3)  # |values| up to ~2e4 at t = 999
+    rel = lambda a, b: close(T(a) / np.abs(b).max(), b / np.abs(b).max(), 3e-6)
+    d = O.create_diffusion_oracle("", learn_sigma=True)
+    for name, lt in (("learned_mse", "mse"), ("learned_rescaled", "rescaled_mse"), ("learned_kl", "rescaled_kl")):
+        terms = d.training_losses(_toy2, x0, t, noise, loss_type=lt)
+        for k in ("loss", "mse", "vb"):
+            if f"{name}_{k}" in g:
+                rel(terms[k], g[f"{name}_{k}"])
+    d50 = O.create_diffusion_oracle("ddim50", learn_sigma=True)
+    terms = d50.training_losses(_toy2, x0, T(g["t50"]), noise)
+    rel(terms["loss"], g["ddim50_learned_loss"])
+    rel(terms["vb"], g["ddim50_learned_vb"])
+
+
 def test_eps_tiny(golden):
     g = golden("eps_tiny")
     cfg = TINY_EPS
