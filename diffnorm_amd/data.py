@@ -246,8 +246,9 @@ def read_unit_tsv(path: str) -> Dict[str, Tuple[str, int, str, int]]:
 
 def load_normalization_inputs(reduce_tsv_dir: str, orig_tsv_dir: str, feature_dir: str, split: str) -> List[Utterance]:
     """The utterance list `diff_norm_synthesis.prepare_data` builds (:70-118): rows of the original (frame-level) TSV
-    that also appear in the reduced TSV and have a feature file, in the original TSV's order.  Features are loaded
-    here once; `normalize.assemble_batch` stages them through one pinned buffer per batch."""
+    that also appear in the reduced TSV and have a feature file, in the original TSV's order.  Only the feature PATHS are kept:
+    `normalize.assemble_batch` reads the files of one batch at a time (and only on the rank that owns the batch) and stages
+    them through one pinned buffer."""
     reduced = read_unit_tsv(f"{reduce_tsv_dir}/{split}.tsv")
     out = []
     with open(f"{orig_tsv_dir}/{split}.tsv", "r") as fh:
@@ -263,8 +264,7 @@ def load_normalization_inputs(reduce_tsv_dir: str, orig_tsv_dir: str, feature_di
             src_audio, src_n, red_units, red_n = reduced[audio_id]
             red = [int(u) for u in red_units.split(" ")]
             assert len(red) == red_n, f"{audio_id}: reduced TSV says {red_n} units, row holds {len(red)}"
-            out.append(Utterance(audio_id, src_audio, src_n, torch.from_numpy(np.load(feature_file)).float(),
-                                 [int(u) for u in tgt_audio.split(" ")], red))
+            out.append(Utterance(audio_id, src_audio, src_n, feature_file, [int(u) for u in tgt_audio.split(" ")], red))
     return out
 
 

@@ -29,9 +29,18 @@ class Utterance:
     audio_id: str
     src_audio: str
     src_n_frames: int
-    feat: torch.Tensor          # [T_full, 768] mHuBERT features of the target speech
+    feat: object                # [T_full, 768] mHuBERT features of the target speech: a tensor, or the path of its .npy file
     tgt_unit: Sequence[int]     # frame-level units (length T_full)
     reduce_tgt_unit: Sequence[int]  # de-duplicated units
+
+    def features(self) -> torch.Tensor:
+        """The feature matrix; a path is read when the utterance's batch is assembled (the reference loads per batch too,
+        diff_norm_synthesis.py:132-171), so a rank only ever holds the features of the batch it is working on."""
+        if isinstance(self.feat, str):
+            import numpy as np
+
+            return torch.from_numpy(np.load(self.feat)).float()
+        return self.feat
 
 
 def assemble_batch(items: Sequence[Utterance], device):
@@ -39,7 +48,7 @@ def assemble_batch(items: Sequence[Utterance], device):
     feats, units = [], []
     for it in items:
         _, _, keep = reduce_token(list(it.tgt_unit))
-        f = it.feat[keep]
+        f = it.features()[keep]
         assert f.shape[0] == len(it.reduce_tgt_unit), "reduced units do not match the de-duplicated frames"
         feats.append(f)
         units.append(torch.tensor(list(it.reduce_tgt_unit), dtype=torch.long))

@@ -107,7 +107,7 @@ def test_normalization_inputs_and_unit_tsv(tmp_path):
         fo.write("broken row without tabs\n")
     utts = D.load_normalization_inputs(str(tmp_path / "reduce"), str(tmp_path / "orig"), str(tmp_path / "feat"), "dev")
     assert [u.audio_id for u in utts] == ["u1", "u2"]
-    assert list(utts[0].reduce_tgt_unit) == [3, 9, 2] and utts[0].feat.shape == (6, 768) and utts[0].src_n_frames == 100
+    assert list(utts[0].reduce_tgt_unit) == [3, 9, 2] and utts[0].features().shape == (6, 768) and isinstance(utts[0].feat, str) and utts[0].src_n_frames == 100
 
     def fake_ddim_sample(feat, input_mask, cond_scale, ref_units, start_step):  # echoes the reference units
         lens = input_mask.sum(1).tolist()

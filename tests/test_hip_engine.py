@@ -235,3 +235,25 @@ def test_vae_full_cfg1_vs_reference_golden(eng, golden, dtype, tol):
     safe = mask & (margin > (1e-3 if dtype == "f32" else 5e-2))
     assert (units.cpu()[safe] == T_(g["units"]).int()[safe]).all()
     assert (units.cpu() == (lg.argmax(-1) - 4).int()).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("latent_flag", [16, 32])
+def test_vae_cascaded_encoders(eng, dtype, tol, latent_flag):
+    """latent_dim = 16 / 32 build three / two cascaded WaveNet encoders and decoders (reference latent_module.py:1044-1081):
+    posterior parameters, reconstruction and logits against the oracle."""
+    engine, _ = eng
+    cfg = O.VaeConfig(dim=192, latent_dim=latent_flag)
+    sd = O.make_vae_state_dict(cfg, f"casc{latent_flag}")
+    ve = engine.VaeEngine(sd, dim=cfg.dim, latent_dim=cfg.latent_dim, dtype=dtype, device=DEV)
+    assert ve.z == cfg.z == {16: 4, 32: 8}[latent_flag] and len(ve.mults) == {16: 3, 32: 2}[latent_flag]
+    feat = seeded((3, 40, cfg.dim), 61)
+    lens = torch.tensor([40, 17, 33])
+    mask = O.lengths_to_mask(lens, 40)
+    params = ve.encode_params(feat.to(DEV)).cpu()
+    want_p = O.vae_encode_params(sd, cfg, feat)
+    assert maxerr(params, want_p) < tol
+    z = O.posterior_sample(want_p, seeded((3, 40, cfg.z), 62))
+    recon, logits, units = ve.decode(z.to(DEV), lens)
+    r_ref, l_ref = O.vae_decode(sd, cfg, z, mask)
+    assert maxerr(recon.cpu()[mask], r_ref[mask]) < tol and maxerr(logits.cpu()[mask], l_ref[mask]) < tol

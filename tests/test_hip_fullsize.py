@@ -96,3 +96,74 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models):
     agree = np.mean([(g_.long() == u_).float().mean().item() for g_, u_ in zip(got, units_o)])
     print(f"config5 slice: unit agreement with the oracle {agree:.4f}")
     assert agree > 0.9
+
+
+def test_manifests_to_normalised_unit_tsv_through_the_hip_path(tmp_path):
+    """SURVEY 8 f1 on the GPU: on-disk unit TSVs + per-utterance feature .npy files -> data.load_normalization_inputs ->
+    normalize() driving the REAL LatentDiscreteModel.ddim_sample on the HIP engines (pinned staging buffer + async H2D per batch,
+    two batches) -> normalised-unit TSV, against the CPU oracle's ddim_sample on the same batches with the same noise (f32)."""
+    import types
+
+    from diffnorm_amd import data as D
+    from diffnorm_amd import normalize as N
+    from diffnorm_amd.latent_module import LatentDiscreteModel, SpeechVAEEncoderDecoder
+    from gen_golden_configs import CHAIN_EPS, CHAIN_VAE
+
+    rng = np.random.RandomState(3)
+    for d in ("orig", "reduce", "feat/dev"):
+        (tmp_path / d).mkdir(parents=True)
+    rows_o, rows_r, feats, frames = [N.TSV_HEADER], [N.TSV_HEADER], {}, {}
+    for i, n_runs in enumerate((21, 34, 27)):
+        runs = rng.randint(1, 4, size=n_runs)
+        vals = rng.randint(0, 1000, size=n_runs)
+        vals[1:][vals[1:] == vals[:-1]] += 1  # neighbouring runs differ, so de-duplication is exactly the run heads
+        units = np.repeat(vals, runs)
+        uid = f"utt{i}"
+        rows_o.append(f"{uid}\tsrc{i}.wav\t{100 + i}\t{' '.join(map(str, units))}\t{len(units)}")
+        rows_r.append(f"{uid}\tsrc{i}.wav\t{100 + i}\t{' '.join(map(str, vals))}\t{n_runs}")
+        feats[uid] = rng.randn(len(units), CHAIN_VAE.dim).astype(np.float32)
+        frames[uid] = np.cumsum(np.concatenate([[0], runs[:-1]]))
+        np.save(tmp_path / "feat" / "dev" / f"{uid}.feat.npy", feats[uid])
+    (tmp_path / "orig" / "dev.tsv").write_text("\n".join(rows_o) + "\n")
+    (tmp_path / "reduce" / "dev.tsv").write_text("\n".join(rows_r) + "\n")
+    utts = D.load_normalization_inputs(str(tmp_path / "reduce"), str(tmp_path / "orig"), str(tmp_path / "feat"), "dev")
+    assert [u.audio_id for u in utts] == ["utt0", "utt1", "utt2"] and all(isinstance(u.feat, str) for u in utts)
+
+    vsd, esd = O.make_vae_state_dict(CHAIN_VAE, "chain"), O.make_eps_state_dict(CHAIN_EPS, "chain")
+    vae = SpeechVAEEncoderDecoder(dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="f32")
+    vae.load_state_dict(vsd, strict=True)
+    ldm = LatentDiscreteModel(types.SimpleNamespace(encoder=vae), CHAIN_EPS.dim, CHAIN_VAE.z, timesteps=200, dtype="f32")
+    ldm.model.load_state_dict(dict(esd, **{"pos_embed._float_tensor": torch.zeros(1)}), strict=True)
+    ldm = ldm.to(DEV).eval()
+    calls = []
+
+    def sample(feat, input_mask, cond_scale, ref_units, start_step):
+        g = torch.Generator().manual_seed(500 + len(calls))
+        post = torch.randn(feat.shape[0], feat.shape[1], CHAIN_VAE.z, generator=g)
+        start = torch.randn(feat.shape[0], feat.shape[1], CHAIN_VAE.z, generator=g)
+        calls.append((feat.cpu(), input_mask.cpu(), ref_units.cpu(), post, start))
+        return ldm.ddim_sample(feat, input_mask=input_mask, cond_scale=cond_scale, ref_units=ref_units, start_step=start_step,
+                               post_noise=post, start_noise=start)
+
+    lines = N.normalize(sample, utts, start_step=5, batch_size=2, device=DEV)
+    out = tmp_path / "dev.normalized.tsv"
+    D.write_unit_tsv(str(out), lines)
+    assert len(calls) == 2 and calls[0][0].shape[0] == 2 and calls[1][0].shape[0] == 1
+    # the assembled batch is what the reference assembles: the first frame of every unit run, zero padded
+    assert torch.equal(calls[0][0][0, :21], torch.from_numpy(feats["utt0"][frames["utt0"]]))
+    assert calls[0][0][0, 21:].abs().max().item() == 0
+    want_lines = []
+    agree = tot = 0
+    for (feat, mask, ref, post, start), items in zip(calls, (utts[:2], utts[2:])):
+        units, _, _, _ = O.ddim_sample(esd, CHAIN_EPS, vsd, CHAIN_VAE, 200, feat, mask, ref, 5, post, start)
+        want_lines += [N.tsv_line(it, u.tolist()) for it, u in zip(items, units)]
+    got_rows = D.read_unit_tsv(str(out))
+    for w in want_lines:
+        uid, src, n, un, cnt = w.split("\t")
+        g_src, g_n, g_units, g_cnt = got_rows[uid]
+        assert (g_src, g_n) == (src, int(n))
+        a, b = un.split(" "), g_units.split(" ")
+        agree += sum(x == y for x, y in zip(a, b)) if len(a) == len(b) else 0
+        tot += len(a)
+    assert agree / tot >= 0.99, (agree, tot)  # f32: identical except where the reference's top-2 logit margin is below round-off
+    assert open(out).readline().strip() == N.TSV_HEADER

@@ -200,3 +200,29 @@ def test_reference_style_criterion_differentiates_the_model_outputs(golden):
     assert abs(float(own) - float(loss)) < 1e-4 * float(loss)
     own.backward()
     assert float((eng.grads - fused).norm() / fused.norm()) < 1e-5
+
+
+def test_cascaded_vae_gradients_vs_oracle_autograd():
+    """latent_dim = 16: three cascaded encoder / decoder WaveNets (the middle ones hand their gradient on in the arithmetic
+    dtype) -- the HIP backward against torch autograd of the oracle's criterion, exact-fp32 mode."""
+    from diffnorm_amd import training
+
+    cfg = O.VaeConfig(dim=192, latent_dim=16)
+    sd = O.make_vae_state_dict(cfg, "casc16")
+    eng = training.VaeTrainEngine(sd, dim=cfg.dim, latent_dim=cfg.latent_dim, dtype="f32", device=DEV, depth=cfg.depth, heads=cfg.heads,
+                                  dim_head=cfg.dim_head, stacks=cfg.stacks, layers=cfg.layers)
+    feat = seeded((2, 36, cfg.dim), 71)
+    lens = torch.tensor([36, 19])
+    g = torch.Generator().manual_seed(72)
+    units = torch.randint(4, 1004, (2, 36), generator=g).masked_fill(~O.lengths_to_mask(lens, 36), 0)
+    noise = seeded((2, 36, cfg.z), 73)
+    stats = eng.forward(feat, units, lens, noise=noise, ntokens=int(lens.sum()))
+    eng.zero_grad()
+    eng.backward()
+    losses, want = TO.vae_loss_and_grads(sd, cfg, feat, units, lens, noise)
+    assert abs(float(stats[0]) - losses["loss"]) < 1e-4 * abs(losses["loss"])
+    got = eng.grad_dict()
+    tot = float(torch.sqrt(sum(v.double().pow(2).sum() for v in want.values())))
+    for k in want:
+        err = float((got[k].double() - want[k].double()).norm())
+        assert err <= 1e-3 * float(want[k].double().norm()) + 1e-6 * tot, (k, err)
