@@ -421,6 +421,18 @@ def run_training(args, ctx):
         frames = sum(batches[i % len(batches)]["frames"] for i in range(K))
         flops = sum(vae_train_flops(b["nsentences"], b["frames"] // b["nsentences"], b["ntokens"]) for b in (batches[i % len(batches)] for i in range(K)))
         assert torch.isfinite(logged).all().item() and torch.isfinite(norm).item(), "training diverged"
+        # the dominant backward kernel, timed where it runs: HIP events around the FFN causal conv's weight-gradient contraction
+        # (one per transformer layer) inside two more updates of the first batch shape
+        import ctypes
+
+        from diffnorm_amd import _lib
+        lib = _lib.load()
+        _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV_WGRAD, 6 * 2), "dn_profile_start")
+        for _ in range(2):
+            tr.train_step([batches[0]], noises=[("philox", 7 + rank, 1 << 40)])
+        k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+        _lib.check(lib.dn_profile_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "dn_profile_stop")
+        k_flops = 2.0 * 2048 * (3 * 2048) * batches[0]["frames"]  # dW_j = dY^T shift_j(X): [2048 x frames] x [frames x 3*2048]
         # all-reduce time of one update (buckets timed with events on the side stream; 0 on one GPU)
         ar_ms = 0.0
         if world > 1:
@@ -428,6 +440,7 @@ def run_training(args, ctx):
             step(0)
             ar_ms = tr.reducer.all_reduce_ms()
             tr.reducer.measure = False
+    roof = (k_flops, k_ms.value, k_n.value, batches[0]["frames"])
     vals = torch.tensor([dt, float(sent), float(toks), float(frames), flops, ar_ms], dtype=torch.float64, device=dev if world > 1 and dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         tmax = vals[:1].clone()
@@ -450,6 +463,11 @@ def run_training(args, ctx):
             "gradient_bytes": eng.n_params * 4, "step_tflops_per_gpu": flops / dt / 1e12 / world,
             "step_mfma_frac": flops / dt / 1e12 / world / peak,
             "loss": float(logged[0]), "grad_norm": float(norm),
+            "roofline": {"bound": "mfma", "kernel": f"dn_conv_gemm weight gradient of the FFN causal conv k=3 (inner 2048): [2048 x {roof[3]}] x "
+                                                    f"[{roof[3]} x 6144] over the padded frames, accumulated into the fp32 gradient",
+                         "achieved": roof[0] / (roof[1] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": roof[0] / (roof[1] * 1e-3) / 1e12 / peak, "flops_per_launch": roof[0], "avg_launch_ms": roof[1],
+                         "launches_timed": roof[2], "traffic": None},
         }
         print(json.dumps(result), flush=True)
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffnorm_hip.so")
 DN_F32, DN_BF16 = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB = range(6)
 DN_MAX_TERMS = 8
-TAG_FFN_CONV, TAG_WN_DILATED = 1, 2
+TAG_FFN_CONV, TAG_WN_DILATED, TAG_FFN_CONV_WGRAD = 1, 2, 3
 
 
 class DiffNormHipError(RuntimeError):

@@ -234,7 +234,7 @@ void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int 
 }
 
 // grad[tap][Np][Kp] += dY^T . shift_tap(X_tap); dY [M, lddy] (cout valid columns), X_tap [M, ldx] (cin valid columns)
-int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad) {
+int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad, int tag = 0) {
   int max_shift = 0;
   for (int j = 0; j < n_taps; ++j) max_shift = taps[j].shift > max_shift ? taps[j].shift : max_shift;
   const WgPlan pl = plan_wgrad(cin, cout, n_taps, max_shift, c.B, c.T, c.es);
@@ -260,6 +260,7 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
     p.terms[0].W = xT; p.terms[0].w_gstride = (int64_t)pl.rows_w * pl.chunk;
     p.epilogue = DN_EPI_RESADD; p.res = grad; p.ldr = Kp; p.res_gstride = (int64_t)Np * Kp;
     p.out = grad; p.ldo = Kp; p.out_dtype = DN_F32; p.out_gstride = (int64_t)Np * Kp;
+    p.pad_ = tag << 8;
     return dn_conv_gemm(&p, c.s);
   }
   DnGemmParams p = gemm_base(c.dtype, cout, pl.N, pl.chunk, cout);
@@ -267,6 +268,7 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
   p.terms[0].A = dyT; p.terms[0].lda = pl.chunk; p.terms[0].a_gstride = (int64_t)cout * pl.chunk;
   p.terms[0].W = xT; p.terms[0].w_gstride = (int64_t)pl.N * pl.chunk;
   p.out = part; p.ldo = pl.N; p.out_dtype = DN_F32; p.out_gstride = (int64_t)cout * pl.N;
+  p.pad_ = tag << 8;
   DN_TRY(dn_conv_gemm(&p, c.s));
   return dn_wgrad_reduce(part, pl.k_slices, cout, pl.N, pl.rows_w, n_taps, grad, padn(cout), padk(cin), c.s);
 }
@@ -590,7 +592,7 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   {  // CausalConv1d(inner, inner, 3) (:894)
     WgTap taps[3];
     for (int j = 0; j < 3; ++j) taps[j] = WgTap{gg, ip, 2 - j};
-    DN_TRY(weight_grad(c, taps, 3, w.inner, tb.d_fc, ip, w.inner, c.G(w.ffconv_W(l))));
+    DN_TRY(weight_grad(c, taps, 3, w.inner, tb.d_fc, ip, w.inner, c.G(w.ffconv_W(l)), DN_TAG_FFN_CONV_WGRAD));
     DN_TRY(bias_grad(c, tb.d_fc, ip, dtype, 1, M, ip, c.G(w.ffconv_b(l)), 0));
     DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
     p.n_terms = 3;

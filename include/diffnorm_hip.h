@@ -145,7 +145,8 @@ int dn_conv_gemm_kblocked_ok(const DnGemmParams* p);
 int dn_conv_gemm_tile(const DnGemmParams* p);
 
 /* launch tags set by the engine on its dominant contractions */
-enum { DN_TAG_FFN_CONV = 1, DN_TAG_WN_DILATED = 2 };
+enum { DN_TAG_FFN_CONV = 1, DN_TAG_WN_DILATED = 2,
+       DN_TAG_FFN_CONV_WGRAD = 3 /* training: the weight-gradient contraction of the FFN causal conv */ };
 
 /* Times the next `max_launches` eager dn_conv_gemm launches carrying `tag` with HIP events recorded on their
  * launch stream (not under graph capture); dn_profile_stop synchronises them and returns the average. */
