@@ -100,6 +100,14 @@ class VaeTrainBatch(C.Structure):
                 ("recon_out", C.c_void_p), ("ext_dlogits", C.c_void_p)]
 
 
+class EpsTrainBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("feat", "units", "lengths", "z", "jitter", "true_noise", "times", "sqrt_ac", "sqrt_1mac",
+                                          "snr_weight")] + \
+               [("beta0", C.c_float), ("B", C.c_int32), ("T", C.c_int32), ("n_units", C.c_int32), ("n_frames", C.c_int32),
+                ("timesteps", C.c_int32), ("multitask", C.c_int32), ("label_smoothing", C.c_float), ("recon_weight", C.c_float),
+                ("loss_scale", C.c_float), ("stats", C.c_void_p), ("eps_out", C.c_void_p)]
+
+
 # every symbol include/diffnorm_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 SYMBOLS = {
@@ -114,6 +122,7 @@ SYMBOLS = {
     "dn_profile_stop": (C.c_int, [C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dn_attention": (C.c_int, [C.POINTER(AttnParams), _vp]),
     "dn_attention_backward": (C.c_int, [C.POINTER(AttnBwdParams), _vp]),
+    "dn_time_cond_backward": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dn_gate_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "dn_gate_backward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "dn_geglu_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -138,6 +147,17 @@ SYMBOLS = {
     "dn_vae_train_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "dn_vae_train_forward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _vp, _sz, _vp]),
     "dn_vae_train_backward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _i32, _i32, _vp, _sz, _vp]),
+    "dn_eps_train_create": (C.c_int, [C.POINTER(EpsConfig), C.POINTER(_vp)]),
+    "dn_eps_train_destroy": (None, [_vp]),
+    "dn_eps_train_param_count": (_i64, [_vp]),
+    "dn_eps_train_aux_bytes": (_sz, [_vp]),
+    "dn_eps_train_offsets": (C.c_int, [_vp, C.POINTER(_i64), _i32]),
+    "dn_eps_train_stage_range": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dn_eps_train_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dn_eps_train_refresh": (C.c_int, [_vp, _vp]),
+    "dn_eps_train_workspace_bytes": (_sz, [_vp, _vp, _i32, _i32]),
+    "dn_eps_train_forward": (C.c_int, [_vp, _vp, C.POINTER(EpsTrainBatch), _vp, _sz, _vp]),
+    "dn_eps_train_backward": (C.c_int, [_vp, _vp, C.POINTER(EpsTrainBatch), _i32, _i32, _vp, _sz, _vp]),
     "dn_sum_groups": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i64, _vp]),
     "dn_transpose_weights": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "dn_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),

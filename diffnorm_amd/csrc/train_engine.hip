@@ -102,6 +102,7 @@ inline int64_t take(int64_t& cur, int64_t n) {
 // ------------------------------------------------------------------------------------------ parameter layout
 struct WaveP {
   int cin, cout, S, L;
+  int film_col;  // FiLM (eps-predictor): first column of block (stack 0, layer 0)'s [gamma ; beta] in the conditioning rows, -1 = none
   int64_t init_W, init_b, conv_W, conv_b, res_W, res_b, skip_W, skip_b, final_W, final_b;  // elements in master/work/grads
   int64_t t_init, t_conv, t_res, t_skip, t_final;                                          // elements in the transposed region
   int64_t skip_bsum;                                                                       // floats in the derived-fp32 region
@@ -112,6 +113,7 @@ struct WaveP {
 // all-reduce -- as soon as that layer's backward has run.  X(l) = element offset of tensor X of layer l.
 struct TfP {
   int dim, depth, heads, dim_head, inner;
+  int cond_col;  // adaptive norms (eps-predictor): first column of (layer 0, attention norm)'s [gamma ; beta] in the conditioning rows; -1 = learned gammas
   int64_t layer0, layer_stride;
   int64_t o_qkv, o_out, o_ffin, o_ffin_b, o_ffconv, o_ffconv_b, o_ffout, o_ffout_b, o_g1, o_g2;
   int64_t pred_gamma, pred_W;
@@ -150,7 +152,10 @@ void layout_tf(TfP& w, int64_t& cur, int64_t& tcur) {
   w.o_ffin = take(o, 2 * ip * Dp); w.o_ffin_b = take(o, 2 * ip);
   w.o_ffconv = take(o, 3 * in_n * ip); w.o_ffconv_b = take(o, ip);
   w.o_ffout = take(o, Dn * ip); w.o_ffout_b = take(o, Dp);
-  w.o_g1 = take(o, D); w.o_g2 = take(o, D);
+  w.o_g1 = w.o_g2 = 0;
+  if (w.cond_col < 0) {  // conditional norms carry no learned gamma (:662-663)
+    w.o_g1 = take(o, D); w.o_g2 = take(o, D);
+  }
   w.layer_stride = o;
   w.layer0 = take(cur, d * o);
   w.pred_gamma = take(cur, D);
@@ -183,16 +188,21 @@ struct DnVaeTrain {
 namespace {
 
 struct Ctx {
-  const DnVaeTrain* m;
+  const float* master;  // fp32 parameters (vectors are read from here in every mode)
+  const void* work;     // the same layout in the arithmetic dtype (matrices)
+  char* aux;            // transposed matrices, then derived fp32 vectors
+  float* grads;
+  int64_t n_trans;
+  bool frozen;          // no parameter gradients (the frozen VAE decoder inside the diffusion loss): data gradients only
   int dtype, es, B, T, M;
   hipStream_t s;
   void* wg_scratch;     // weight-gradient operands + partial sums
   float* red_scratch;   // column-sum / norm-backward partials
-  const void* W(int64_t off) const { return static_cast<const char*>(m->work) + off * es; }
-  const float* P(int64_t off) const { return m->master + off; }       // fp32 vectors (biases, gammas)
-  float* G(int64_t off) const { return m->grads + off; }
-  const void* Wt(int64_t off) const { return m->aux + off * es; }
-  float* F(int64_t off) const { return reinterpret_cast<float*>(m->aux + r64(m->n_trans) * es) + off; }
+  const void* W(int64_t off) const { return static_cast<const char*>(work) + off * es; }
+  const float* P(int64_t off) const { return master + off; }       // fp32 vectors (biases, gammas)
+  float* G(int64_t off) const { return grads + off; }
+  const void* Wt(int64_t off) const { return aux + off * es; }
+  float* F(int64_t off) const { return reinterpret_cast<float*>(aux + ((n_trans + 63) / 64 * 64) * es) + off; }
 };
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -235,6 +245,7 @@ void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int 
 
 // grad[tap][Np][Kp] += dY^T . shift_tap(X_tap); dY [M, lddy] (cout valid columns), X_tap [M, ldx] (cin valid columns)
 int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad, int tag = 0) {
+  if (c.frozen) return DN_OK;
   int max_shift = 0;
   for (int j = 0; j < n_taps; ++j) max_shift = taps[j].shift > max_shift ? taps[j].shift : max_shift;
   const WgPlan pl = plan_wgrad(cin, cout, n_taps, max_shift, c.B, c.T, c.es);
@@ -274,6 +285,7 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
 }
 
 int bias_grad(const Ctx& c, const void* dy, int ld, int dtype, int groups, int rows_per_group, int C, float* grad, int out_ld) {
+  if (c.frozen) return DN_OK;
   return dn_colsum(dy, ld, dtype, groups, rows_per_group, C, grad, out_ld, 1.0f, 1, c.red_scratch, c.s);
 }
 
@@ -292,8 +304,9 @@ WaveSave plan_wave_save(const WaveP& w, int M, int es, Arena& ar) {
   return b;
 }
 
-// `fin` carries the destination of the final 1x1 conv (out, ldo, out_dtype, N).
-int wave_forward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& sv, DnGemmParams fin) {
+// `fin` carries the destination of the final 1x1 conv (out, ldo, out_dtype, N).  gb (FiLM only): fp32 conditioning rows [B, gb_ld],
+// block (st, i) at columns film_col + (st * L + i) * 2 * cp: [gamma (cp) ; beta (cp)].
+int wave_forward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& sv, DnGemmParams fin, const float* gb = nullptr, int gb_ld = 0) {
   const int dtype = c.dtype, es = c.es, M = c.M, T = c.T;
   const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.L, S = w.S;
   const size_t mat = (size_t)cn * cp;
@@ -336,8 +349,15 @@ int wave_forward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& s
       p.out = h_s; p.ldo = cp; p.out_gstride = plane;
       DN_TRY(dn_conv_gemm(&p, c.s));
     }
-    // tanh(h) * sigmoid(h) + res (:528-530), all L blocks in one pass
-    DN_TRY(dn_gate_forward(h_s, res_s, out_s, dtype, L * M, cp, T, nullptr, 0, 0, c.s));
+    // [FiLM h * gamma + beta (:517-527);] tanh(h) * sigmoid(h) + res (:528-530): all L blocks in one pass, or one per block
+    // when each has its own conditioning columns
+    if (!gb || w.film_col < 0) {
+      DN_TRY(dn_gate_forward(h_s, res_s, out_s, dtype, L * M, cp, T, nullptr, 0, 0, c.s));
+    } else {
+      for (int i = 0; i < L; ++i)
+        DN_TRY(dn_gate_forward(eoff(h_s, (size_t)i * plane, es), eoff(res_s, (size_t)i * plane, es), eoff(out_s, (size_t)i * plane, es), dtype, M,
+                               cp, T, gb + w.film_col + (size_t)(st * L + i) * 2 * cp, gb_ld, cp, c.s));
+    }
   }
   const void* last = eoff(sv.out, (size_t)(S - 1) * L * plane, es);
   {  // sum over blocks of skip_conv(out_i) (:511,534,617)
@@ -358,8 +378,10 @@ int wave_forward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& s
 
 // d_y: gradient w.r.t. the final conv's output, arithmetic dtype [M, padk(cout)] (pad columns zero).
 // d_x (optional): gradient w.r.t. the WaveNet's input, [M, padk(cin)] in d_x_dtype.
+// FiLM: gb as in wave_forward; d_gb (fp32 [B, gb_ld], same columns) accumulates the conditioning gradients, film_rows is a
+// [M, 2 * cp] fp32 temporary for the per-frame terms.
 int wave_backward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& sv, const void* d_y, void* d_x, int d_x_dtype,
-                  const WaveTmp& tb) {
+                  const WaveTmp& tb, const float* gb = nullptr, int gb_ld = 0, float* d_gb = nullptr, float* film_rows = nullptr) {
   const int dtype = c.dtype, es = c.es, M = c.M, T = c.T;
   const int cinp = padk(w.cin), cp = padk(w.cout), cn = padn(w.cout), L = w.L, S = w.S;
   const size_t mat = (size_t)cn * cp, tmat = (size_t)padn(cp) * cp;
@@ -380,9 +402,11 @@ int wave_backward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& 
     for (int i = 0; i < L; ++i) taps[i] = WgTap{eoff(last, (size_t)i * plane, es), cp, 0};
     DN_TRY(weight_grad(c, taps, L, w.cout, tb.d_sk, cp, w.cout, c.G(w.skip_W)));
     // every skip bias sees the same gradient: column sums once, then added to each of the L rows
-    float* tmp = c.red_scratch + 1024 * 1024;  // behind the partial sums of dn_colsum
-    DN_TRY(dn_colsum(tb.d_sk, cp, dtype, 1, M, cp, tmp, 0, 1.0f, 0, c.red_scratch, c.s));
-    DN_TRY(dn_add_broadcast(tmp, c.G(w.skip_b), cp, cp, L, c.s));
+    if (!c.frozen) {
+      float* tmp = c.red_scratch + 1024 * 1024;  // behind the partial sums of dn_colsum
+      DN_TRY(dn_colsum(tb.d_sk, cp, dtype, 1, M, cp, tmp, 0, 1.0f, 0, c.red_scratch, c.s));
+      DN_TRY(dn_add_broadcast(tmp, c.G(w.skip_b), cp, cp, L, c.s));
+    }
     DnGemmParams p = gemm_base(dtype, M, cp, cp, T);  // d out_i = d sk . W_skip_i
     p.groups = L;
     p.terms[0].A = tb.d_sk; p.terms[0].lda = cp; p.terms[0].a_gstride = 0;
@@ -395,8 +419,17 @@ int wave_backward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& 
   for (int st = S - 1; st >= 0; --st) {
     const void* in_s = st == 0 ? sv.h0 : eoff(sv.out, (size_t)(st - 1) * L * plane, es);
     const void* h_s = eoff(sv.hpre, (size_t)st * L * plane, es);
-    // d h = d out * gate'(h) (:528)
-    DN_TRY(dn_gate_backward(d_out, h_s, tb.d_h, dtype, L * M, cp, T, nullptr, 0, 0, nullptr, 0, c.s));
+    // d h = d out * gate'(h) (:528) [* gamma, and the conditioning gradients: sum over t of dg * h and dg per sample]
+    if (!gb || w.film_col < 0) {
+      DN_TRY(dn_gate_backward(d_out, h_s, tb.d_h, dtype, L * M, cp, T, nullptr, 0, 0, nullptr, 0, c.s));
+    } else {
+      for (int i = 0; i < L; ++i) {
+        const size_t col = w.film_col + (size_t)(st * L + i) * 2 * cp;
+        DN_TRY(dn_gate_backward(eoff(d_out, (size_t)i * plane, es), eoff(h_s, (size_t)i * plane, es), eoff(tb.d_h, (size_t)i * plane, es), dtype,
+                                M, cp, T, gb + col, gb_ld, cp, film_rows, 2 * cp, c.s));
+        DN_TRY(dn_colsum(film_rows, 2 * cp, DN_F32, c.B, T, 2 * cp, d_gb + col, gb_ld, 1.0f, 1, c.red_scratch, c.s));
+      }
+    }
     DN_TRY(bias_grad(c, d_out, cp, dtype, L, M, cp, c.G(w.res_b) + (size_t)st * L * cp, cp));
     DN_TRY(bias_grad(c, tb.d_h, cp, dtype, L, M, cp, c.G(w.conv_b) + (size_t)st * L * cp, cp));
     for (int i = 0; i < L; ++i) {
@@ -478,7 +511,9 @@ TfTmp plan_tf_tmp(const TfP& w, int B, int T, int es, Arena& ar) {
 }
 
 // x[0] holds the input residual stream; `pred` receives to_pred's output (fp32 [M, pred_ld]).
-int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave& sv, float* pred, int pred_ld) {
+// gb (adaptive norms only): conditioning rows [B, gb_ld]; norm (l, j) at columns cond_col + (2 l + j) * 2 * Dp.
+int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave& sv, float* pred, int pred_ld, const float* gb = nullptr,
+               int gb_ld = 0) {
   const int dtype = c.dtype, es = c.es, B = c.B, T = c.T, M = c.M;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
   const size_t MD = (size_t)M * Dp;
@@ -493,7 +528,10 @@ int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave&
     void* pre = eoff(sv.pre, (size_t)l * M * 2 * ip, es);
     void* gg = eoff(sv.gg, (size_t)l * M * ip, es);
     void* fc = eoff(sv.fc, (size_t)l * M * ip, es);
-    DN_TRY(dn_rmsnorm(x, Dp, xn1, Dp, dtype, M, D, T, c.P(w.g1(l)), nullptr, 0, 0, c.s));
+    const bool ada = gb && w.cond_col >= 0;
+    const float* gb1 = ada ? gb + w.cond_col + (size_t)(2 * l) * 2 * Dp : nullptr;
+    const float* gb2 = ada ? gb + w.cond_col + (size_t)(2 * l + 1) * 2 * Dp : nullptr;
+    DN_TRY(dn_rmsnorm(x, Dp, xn1, Dp, dtype, M, D, T, ada ? nullptr : c.P(w.g1(l)), gb1, gb_ld, Dp, c.s));
     {  // to_q ; to_kv (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
       p.terms[0].A = xn1; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.qkv_W(l));
@@ -516,7 +554,7 @@ int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave&
       p.epilogue = DN_EPI_RESADD; p.res = x; p.ldr = Dp; p.out = xmid; p.ldo = Dp; p.out_dtype = DN_F32;
       DN_TRY(dn_conv_gemm(&p, c.s));
     }
-    DN_TRY(dn_rmsnorm(xmid, Dp, xn2, Dp, dtype, M, D, T, c.P(w.g2(l)), nullptr, 0, 0, c.s));
+    DN_TRY(dn_rmsnorm(xmid, Dp, xn2, Dp, dtype, M, D, T, ada ? nullptr : c.P(w.g2(l)), gb2, gb_ld, Dp, c.s));
     {  // Linear(D -> 2*inner), packed [8 value ; 8 gate] columns, pre-activation kept (:899)
       DnGemmParams p = gemm_base(dtype, M, 2 * ip, Dp, T);
       p.terms[0].A = xn2; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.ffin_W(l));
@@ -566,11 +604,12 @@ int tf_backward_head(const Ctx& c, const TfP& w, const TfSave& sv, const void* d
   DN_TRY(weight_grad(c, &tap, 1, D, d_pred, Dp, D, c.G(w.pred_W)));
   DN_TRY(linear_dgrad(c, d_pred, Dp, Dp, c.Wt(w.t_pred), tb.d_xn, Dp, c.dtype));
   return dn_rmsnorm_backward(sv.x + w.depth * MD, Dp, tb.d_xn, Dp, c.dtype, c.B, c.T, D, c.P(w.pred_gamma), nullptr, 0, 0, nullptr, tb.dx,
-                             tb.dx_act, c.dtype, Dp, c.G(w.pred_gamma), nullptr, 0, c.red_scratch, c.s);
+                             tb.dx_act, c.dtype, Dp, c.frozen ? nullptr : c.G(w.pred_gamma), nullptr, 0, c.red_scratch, c.s);
 }
 
 // one layer: tb.dx / tb.dx_act hold d x[l+1] on entry, d x[l] on exit
-int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths, const TfSave& sv, const TfTmp& tb) {
+int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths, const TfSave& sv, const TfTmp& tb, const float* gb = nullptr,
+                      int gb_ld = 0, float* d_gb = nullptr) {
   const int dtype = c.dtype, es = c.es, B = c.B, T = c.T, M = c.M;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
   const size_t MD = (size_t)M * Dp;
@@ -583,6 +622,8 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   const void* pre = eoff(sv.pre, (size_t)l * M * 2 * ip, es);
   const void* gg = eoff(sv.gg, (size_t)l * M * ip, es);
   const void* fc = eoff(sv.fc, (size_t)l * M * ip, es);
+  const bool ada = gb && w.cond_col >= 0;
+  const size_t col1 = ada ? w.cond_col + (size_t)(2 * l) * 2 * Dp : 0, col2 = col1 + 2 * Dp;
   {  // Linear(inner -> D) (:902)
     WgTap tap{fc, ip, 0};
     DN_TRY(weight_grad(c, &tap, 1, w.inner, tb.dx_act, Dp, D, c.G(w.ffout_W(l))));
@@ -611,8 +652,9 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
     DN_TRY(linear_dgrad(c, tb.d_pre, 2 * ip, 2 * ip, eoff(c.Wt(w.t_ffin), (size_t)l * padn(Dp) * 2 * ip, es), tb.d_xn, Dp, dtype));
   }
   // ff_norm (:703): d xmid = d x[l+1] + norm'(xmid) d xn2
-  DN_TRY(dn_rmsnorm_backward(xmid, Dp, tb.d_xn, Dp, dtype, B, T, D, c.P(w.g2(l)), nullptr, 0, 0, tb.dx, tb.dx, tb.dx_act, dtype,
-                             Dp, c.G(w.g2(l)), nullptr, 0, c.red_scratch, c.s));
+  DN_TRY(dn_rmsnorm_backward(xmid, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g2(l)), ada ? gb + col2 : nullptr, gb_ld, Dp, tb.dx,
+                             tb.dx, tb.dx_act, dtype, Dp, (ada || c.frozen) ? nullptr : c.G(w.g2(l)), ada ? d_gb + col2 : nullptr, gb_ld,
+                             c.red_scratch, c.s));
   {  // to_out (:932)
     WgTap tap{ao, hd, 0};
     DN_TRY(weight_grad(c, &tap, 1, hd, tb.dx_act, Dp, D, c.G(w.out_W(l))));
@@ -635,8 +677,9 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
     DN_TRY(linear_dgrad(c, tb.d_qkv, 3 * hd, 3 * hd, eoff(c.Wt(w.t_qkv), (size_t)l * padn(Dp) * 3 * hd, es), tb.d_xn, Dp, dtype));
   }
   // attn_norm (:691)
-  return dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, c.P(w.g1(l)), nullptr, 0, 0, tb.dx, tb.dx, tb.dx_act, dtype, Dp,
-                             c.G(w.g1(l)), nullptr, 0, c.red_scratch, c.s);
+  return dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g1(l)), ada ? gb + col1 : nullptr, gb_ld, Dp, tb.dx, tb.dx,
+                             tb.dx_act, dtype, Dp, (ada || c.frozen) ? nullptr : c.G(w.g1(l)), ada ? d_gb + col1 : nullptr, gb_ld, c.red_scratch,
+                             c.s);
 }
 
 // ------------------------------------------------------------------------------------------ workspace plan
@@ -680,7 +723,7 @@ size_t max_wgrad_bytes(const DnVaeTrain* m, int B, int T) {
   return mx;
 }
 
-VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar) {
+VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar, bool need_enc = true) {
   const int es = esize(m->cfg.dtype), D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, V = m->cfg.vocab;
   const size_t M = (size_t)B * T;
   VaePlan p;
@@ -690,9 +733,11 @@ VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar) {
   for (int n = 0; n < m->n_wave; ++n) {
     widest = widest > m->enc[n].cout ? widest : m->enc[n].cout;
     widest = widest > m->dec[n].cout ? widest : m->dec[n].cout;
-    p.enc[n] = plan_wave_save(m->enc[n], (int)M, es, ar);
+    if (need_enc) {
+      p.enc[n] = plan_wave_save(m->enc[n], (int)M, es, ar);
+      p.enc_mid[n] = ar.take(M * padk(m->enc[n].cout) * es);
+    }
     p.dec[n] = plan_wave_save(m->dec[n], (int)M, es, ar);
-    p.enc_mid[n] = ar.take(M * padk(m->enc[n].cout) * es);
     p.dec_mid[n] = ar.take(M * padk(m->dec[n].cout) * es);
   }
   p.params = (float*)ar.take(M * 2 * z * 4);
@@ -723,9 +768,10 @@ VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar) {
   return p;
 }
 
-Ctx make_ctx(const DnVaeTrain* m, int B, int T, const VaePlan& pl, hipStream_t s) {
+Ctx make_ctx(const DnVaeTrain* m, int B, int T, const VaePlan& pl, hipStream_t s, bool frozen = false) {
   Ctx c;
-  c.m = m; c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
+  c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = frozen;
+  c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
   c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
   return c;
 }
@@ -741,6 +787,56 @@ int check_batch(const DnVaeTrain* m, const DnVaeTrainBatch* b, void* ws, size_t 
   if (ar.off > ws_bytes) {
     dn_set_error("%s: workspace %zu < required %zu (dn_vae_train_workspace_bytes)", who, ws_bytes, ar.off);
     return DN_EWORKSPACE;
+  }
+  return DN_OK;
+}
+
+// decode_feature (:1109-1116) from pl.z_act: decoder WaveNets -> transformer -> pl.rec (fp32) / pl.rec_act -> decoder_lm -> pl.logits
+int vae_decoder_forward(const Ctx& c, const DnVaeTrain* m, const VaePlan& pl, const int32_t* lengths) {
+  const int dtype = c.dtype, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), V = m->cfg.vocab;
+  const void* cur = pl.z_act;
+  for (int n = 0; n < m->n_wave; ++n) {  // decoder WaveNets (:1130-1131); the last opens the fp32 residual stream
+    const WaveP& w = m->dec[n];
+    const bool lastw = n == m->n_wave - 1;
+    DnGemmParams fin = gemm_base(dtype, M, padk(w.cout), padk(w.cout), T);
+    if (lastw) {
+      fin.out = pl.tf.x; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    } else {
+      fin.out = pl.dec_mid[n]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
+    }
+    DN_TRY(wave_forward(c, w, cur, pl.dec[n], fin));
+    cur = pl.dec_mid[n];
+  }
+  DN_TRY(tf_forward(c, m->tf, lengths, pl.tf, pl.rec, Dp));  // decoded_feature (:1133)
+  DN_TRY(dn_convert_rows(pl.rec, DN_F32, Dp, pl.rec_act, dtype, Dp, M, D, c.s));
+  DnGemmParams p = gemm_base(dtype, M, V, Dp, T);  // decoder_lm (:1141)
+  p.terms[0].A = pl.rec_act; p.terms[0].lda = Dp; p.terms[0].W = c.W(m->lm_W);
+  p.bias = c.P(m->lm_b); p.out = pl.logits; p.ldo = V; p.out_dtype = DN_F32;
+  return dn_conv_gemm(&p, c.s);
+}
+
+// Decoder half of the backward: stage 0 = d logits (pl.dlogits) and the masked-MSE gradient (scale g_mse) through decoder_lm and
+// to_pred, 1 .. depth = transformer layers, depth + 1 = decoder WaveNets, leaving d z (fp32 [M, padk(z)]) in pl.dz.
+int vae_decoder_backward(const Ctx& c, const DnVaeTrain* m, const VaePlan& pl, const float* feat, const int32_t* lengths, float g_mse,
+                         int stage) {
+  const int dtype = c.dtype, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), V = m->cfg.vocab, depth = m->tf.depth;
+  if (stage == 0) {
+    WgTap tap{pl.rec_act, Dp, 0};
+    DN_TRY(weight_grad(c, &tap, 1, D, pl.dlogits, padn(V), V, c.G(m->lm_W)));
+    DN_TRY(bias_grad(c, pl.dlogits, padn(V), dtype, 1, M, V, c.G(m->lm_b), 0));
+    DN_TRY(linear_dgrad(c, pl.dlogits, padn(V), padk(V), c.Wt(m->t_lm), pl.d_rec, Dp, DN_F32));
+    DN_TRY(dn_masked_mse_grad(pl.rec, Dp, feat, D, M, D, T, lengths, g_mse, nullptr, pl.d_rec, Dp, 1, pl.d_rec_act, dtype, Dp, c.s));
+    return tf_backward_head(c, m->tf, pl.tf, pl.d_rec_act, pl.tt);
+  }
+  if (stage <= depth) return tf_backward_layer(c, m->tf, depth - stage, lengths, pl.tf, pl.tt);
+  const void* d_y = pl.tt.dx_act;  // gradient of the residual stream's first state
+  void* mids[2] = {pl.d_mid0, pl.d_mid1};
+  for (int n = m->n_wave - 1; n >= 0; --n) {
+    const WaveP& w = m->dec[n];
+    const void* in = n == 0 ? pl.z_act : pl.dec_mid[n - 1];
+    void* d_x = n == 0 ? (void*)pl.dz : mids[n & 1];
+    DN_TRY(wave_backward(c, w, in, pl.dec[n], d_y, d_x, n == 0 ? DN_F32 : dtype, pl.wt));
+    d_y = d_x;
   }
   return DN_OK;
 }
@@ -764,7 +860,7 @@ extern "C" int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out) {
   int width = cfg->dim;
   for (int n = 0; n < m->n_wave; ++n) {  // latent_module.py:1053-1065
     WaveP& w = m->enc[n];
-    w.cin = width; w.cout = width / cfg->mults[n]; w.S = cfg->stacks; w.L = cfg->layers;
+    w.cin = width; w.cout = width / cfg->mults[n]; w.S = cfg->stacks; w.L = cfg->layers; w.film_col = -1;
     width = w.cout;
     layout_wave(w, cur, tcur, fcur);
   }
@@ -776,7 +872,7 @@ extern "C" int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out) {
   for (int n = 0; n < m->n_wave; ++n) {  // :1067-1081
     WaveP& w = m->dec[n];
     const int mult = cfg->mults[m->n_wave - 1 - n];
-    w.cout = width * mult; w.cin = n == 0 ? width / 2 : width; w.S = cfg->stacks; w.L = cfg->layers;
+    w.cout = width * mult; w.cin = n == 0 ? width / 2 : width; w.S = cfg->stacks; w.L = cfg->layers; w.film_col = -1;
     width = w.cout;
     layout_wave(w, cur, tcur, fcur);
   }
@@ -787,6 +883,7 @@ extern "C" int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out) {
   }
   m->tf.dim = cfg->dim; m->tf.depth = cfg->depth; m->tf.heads = cfg->heads; m->tf.dim_head = cfg->dim_head;
   m->tf.inner = (int)((double)cfg->dim * 4 * 2 / 3);
+  m->tf.cond_col = -1;
   layout_tf(m->tf, cur, tcur);
   const int64_t Dp = padk(cfg->dim), Vn = padn(cfg->vocab);
   m->lm_W = take(cur, Vn * Dp); m->lm_b = take(cur, Vn);
@@ -920,27 +1017,7 @@ extern "C" int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* b, voi
   }
   // posterior sample + KL rows (:1124-1127)
   DN_TRY(dn_posterior_sample(pl.params, 2 * z, b->noise, z, pl.z, pl.z_act, dtype, zp, M, z, T, b->lengths, pl.kl_rows, s));
-  cur = pl.z_act;
-  for (int n = 0; n < m->n_wave; ++n) {  // decoder WaveNets (:1130-1131); the last opens the fp32 residual stream
-    const WaveP& w = m->dec[n];
-    const bool lastw = n == m->n_wave - 1;
-    DnGemmParams fin = gemm_base(dtype, M, padk(w.cout), padk(w.cout), T);
-    if (lastw) {
-      fin.out = pl.tf.x; fin.ldo = Dp; fin.out_dtype = DN_F32;
-    } else {
-      fin.out = pl.dec_mid[n]; fin.ldo = padk(w.cout); fin.out_dtype = dtype;
-    }
-    DN_TRY(wave_forward(c, w, cur, pl.dec[n], fin));
-    cur = pl.dec_mid[n];
-  }
-  DN_TRY(tf_forward(c, m->tf, b->lengths, pl.tf, pl.rec, Dp));  // decoded_feature (:1133)
-  DN_TRY(dn_convert_rows(pl.rec, DN_F32, Dp, pl.rec_act, dtype, Dp, M, D, s));
-  {  // decoder_lm (:1141)
-    DnGemmParams p = gemm_base(dtype, M, V, Dp, T);
-    p.terms[0].A = pl.rec_act; p.terms[0].lda = Dp; p.terms[0].W = c.W(m->lm_W);
-    p.bias = c.P(m->lm_b); p.out = pl.logits; p.ldo = V; p.out_dtype = DN_F32;
-    DN_TRY(dn_conv_gemm(&p, s));
-  }
+  DN_TRY(vae_decoder_forward(c, m, pl, b->lengths));
   if (b->logits_out) DN_TRY(dn_convert_rows(pl.logits, DN_F32, V, b->logits_out, DN_F32, V, M, V, s));
   if (b->recon_out) DN_TRY(dn_convert_rows(pl.rec, DN_F32, Dp, b->recon_out, DN_F32, D, M, D, s));
   // losses (speech_vae_decoder_loss.py:60-83): LS-CE rows (+ d logits, kept for the backward), squared error, KL
@@ -972,30 +1049,12 @@ extern "C" int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* b, in
   DN_CHECK_ARG(first_stage >= 0 && last_stage <= depth + 2 && first_stage <= last_stage, "dn_vae_train_backward: stages [%d, %d]", first_stage,
                last_stage);
   for (int stage = first_stage; stage <= last_stage; ++stage) {
-    if (stage == 0) {
-      // decoder_lm: dW, db, d rec = d logits . W_lm
-      if (b->ext_dlogits) DN_TRY(dn_convert_rows(b->ext_dlogits, DN_F32, V, pl.dlogits, dtype, padn(V), M, V, s));
-      WgTap tap{pl.rec_act, Dp, 0};
-      DN_TRY(weight_grad(c, &tap, 1, D, pl.dlogits, padn(V), V, c.G(m->lm_W)));
-      DN_TRY(bias_grad(c, pl.dlogits, padn(V), dtype, 1, M, V, c.G(m->lm_b), 0));
-      DN_TRY(linear_dgrad(c, pl.dlogits, padn(V), padk(V), c.Wt(m->t_lm), pl.d_rec, Dp, DN_F32));
+    if (stage <= depth + 1) {
+      if (stage == 0 && b->ext_dlogits) DN_TRY(dn_convert_rows(b->ext_dlogits, DN_F32, V, pl.dlogits, dtype, padn(V), M, V, s));
       // + masked MSE gradient (:1135-1138): 2 w / (n_valid * D) * (rec - feat)
       const float g_mse = b->loss_scale * b->w_mse * 2.0f / ((float)b->ntokens * (float)D);
-      DN_TRY(dn_masked_mse_grad(pl.rec, Dp, b->feat, D, M, D, T, b->lengths, g_mse, nullptr, pl.d_rec, Dp, 1, pl.d_rec_act, dtype, Dp, s));
-      DN_TRY(tf_backward_head(c, m->tf, pl.tf, pl.d_rec_act, pl.tt));
-    } else if (stage <= depth) {
-      DN_TRY(tf_backward_layer(c, m->tf, depth - stage, b->lengths, pl.tf, pl.tt));
-    } else if (stage == depth + 1) {
-      // decoder WaveNets, last to first; tt.dx_act = gradient of the residual stream's first state
-      const void* d_y = pl.tt.dx_act;
-      void* mids[2] = {pl.d_mid0, pl.d_mid1};
-      for (int n = m->n_wave - 1; n >= 0; --n) {
-        const WaveP& w = m->dec[n];
-        const void* in = n == 0 ? pl.z_act : pl.dec_mid[n - 1];
-        void* d_x = n == 0 ? (void*)pl.dz : mids[n & 1];
-        DN_TRY(wave_backward(c, w, in, pl.dec[n], d_y, d_x, n == 0 ? DN_F32 : dtype, pl.wt));
-        d_y = d_x;
-      }
+      DN_TRY(vae_decoder_backward(c, m, pl, b->feat, b->lengths, g_mse, stage));
+      if (stage <= depth) continue;
       // posterior sample + KL (:1124-1127): kl.mean() over the batch of per-sample means over (z, T)
       const float klw = b->loss_scale * b->w_kl / ((float)b->B * (float)z * (float)T);
       DN_TRY(dn_posterior_backward(pl.params, 2 * z, b->noise, z, pl.dz, zp, pl.d_params, dtype, padk(2 * z), M, z, T, b->lengths, klw, s));
@@ -1012,5 +1071,476 @@ extern "C" int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* b, in
     }
   }
   (void)es;
+  return DN_OK;
+}
+
+// ===========================================================================================================================
+// Diffusion training step: LatentDiscreteModel.forward (latent_module.py:1514-1613) -- q-sample at a random t,
+// the eps-predictor Model(x_t, t) with FiLM / adaptive-norm time conditioning, the min-SNR-5 weighted masked noise MSE, and
+// (multitask) the reconstruction losses of x1_hat pushed through the FROZEN VAE decoder (50 * MSE + LS-CE, divided by the
+// number of timesteps); the backward pass flows through the frozen decoder's data gradients into the eps-predictor only
+// (diff_discrete.py:79-82).  Flat layout, stages and buffers as for the VAE above; the conditioning path (time MLP and the
+// 2 S L + 2 depth FiLM / adaptive-norm projections, 45 % of the parameters) stays fp32 in every mode, like the sampling engine.
+namespace dn {
+
+// x1 = z + jitter * beta0; x_t = sa[t_b] x1 + s1[t_b] noise  (:1534-1543) -> xt fp32 [M, zl] and its operand copy [M, zp]
+__global__ __launch_bounds__(256) void eps_prep_kernel(const float* __restrict__ z, const float* __restrict__ jitter, const float* __restrict__ noise,
+                                                       const int32_t* __restrict__ times, const float* __restrict__ sa, const float* __restrict__ s1,
+                                                       float beta0, int M, int T, int zl, int zp, float* __restrict__ xt, void* __restrict__ xt_act,
+                                                       int act_dtype) {
+  const int64_t n = (int64_t)M * zp;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / zp), c = (int)(i - (int64_t)m * zp);
+    float v = 0.f;
+    if (c < zl) {
+      const int tb = times[m / T];
+      const int64_t o = (int64_t)m * zl + c;
+      const float x1 = __fadd_rn(z[o], __fmul_rn(jitter[o], beta0));
+      v = __fadd_rn(__fmul_rn(sa[tb], x1), __fmul_rn(s1[tb], noise[o]));
+      xt[o] = v;
+    }
+    if (act_dtype == DN_BF16)
+      reinterpret_cast<uint16_t*>(xt_act)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+    else
+      reinterpret_cast<float*>(xt_act)[i] = v;
+  }
+}
+
+// After the eps-predictor: rows[m] = {sum_c masked (eps_hat - eps)^2, 0, 0, 0}; d_eps[m, c] = g_noise * w_b * diff (valid frames);
+// x1_hat = (x_t - s1 eps_hat) / max(sa, 1e-10) in the arithmetic dtype [M, zp] (:1563-1575)
+__global__ __launch_bounds__(256) void eps_post_kernel(const float* __restrict__ eps_hat, const float* __restrict__ noise, const float* __restrict__ xt,
+                                                       const int32_t* __restrict__ times, const float* __restrict__ sa, const float* __restrict__ s1,
+                                                       const float* __restrict__ snr_w, const int32_t* __restrict__ lengths, float g_noise, int M,
+                                                       int T, int zl, int zp, float* __restrict__ rows, float* __restrict__ d_eps,
+                                                       void* __restrict__ x1_act, int act_dtype) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const int b = m / T, t = m - b * T;
+  const bool valid = t < lengths[b];
+  const int tb = times[b];
+  const float a = sa[tb], s = s1[tb], w = snr_w[b];
+  float sq = 0.f;
+  for (int c = lane; c < zp; c += 64) {
+    float x1 = 0.f, g = 0.f;
+    if (c < zl) {
+      const int64_t o = (int64_t)m * zl + c;
+      const float e = eps_hat[o];
+      const float diff = e - noise[o];
+      if (valid) {
+        sq += diff * diff;
+        g = g_noise * w * diff;
+      }
+      x1 = __fdiv_rn(__fsub_rn(xt[o], __fmul_rn(s, e)), fmaxf(a, 1e-10f));
+    }
+    d_eps[(int64_t)m * zp + c] = g;
+    if (act_dtype == DN_BF16)
+      reinterpret_cast<uint16_t*>(x1_act)[(int64_t)m * zp + c] = (uint16_t)(pack_bf16x2(x1, 0.f) & 0xffff);
+    else
+      reinterpret_cast<float*>(x1_act)[(int64_t)m * zp + c] = x1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if (lane == 0) *reinterpret_cast<float4*>(rows + (int64_t)m * 4) = make_float4(sq, 0.f, 0.f, 0.f);
+}
+
+// d eps_hat = d_eps (noise part) - s1 / max(sa, 1e-10) * d x1_hat  -> operand copy [M, zp]
+__global__ __launch_bounds__(256) void eps_combine_kernel(const float* __restrict__ d_eps, const float* __restrict__ dx1, const int32_t* __restrict__ times,
+                                                          const float* __restrict__ sa, const float* __restrict__ s1, int M, int T, int zl, int zp,
+                                                          void* __restrict__ out, int act_dtype) {
+  const int64_t n = (int64_t)M * zp;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / zp), c = (int)(i - (int64_t)m * zp);
+    float v = 0.f;
+    if (c < zl) {
+      const int tb = times[m / T];
+      v = d_eps[i] - (dx1 ? s1[tb] / fmaxf(sa[tb], 1e-10f) * dx1[i] : 0.f);
+    }
+    if (act_dtype == DN_BF16)
+      reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+    else
+      reinterpret_cast<float*>(out)[i] = v;
+  }
+}
+
+// stats: [0] total_loss, [1] nll_loss (label-smoothed CE / n_units), [2] recon_mse_loss, [3] noise_loss, [4] acc  (:1597-1613)
+__global__ void eps_loss_kernel(const float* __restrict__ lsce_sums, const float* __restrict__ sq_recon, const float* __restrict__ noise_b, int noise_ld,
+                                const float* __restrict__ snr_w, int B, float inv_tz, float eps, int V, float inv_units, float inv_recon,
+                                float recon_w, float inv_steps, int multitask, float* __restrict__ stats) {
+  float noise = 0.f;
+  for (int b = 0; b < B; ++b) noise += snr_w[b] * noise_b[(int64_t)b * noise_ld] * inv_tz;
+  noise /= (float)B;
+  const float eps_i = eps / (float)(V - 1);
+  const float smooth = ((1.0f - eps - eps_i) * lsce_sums[0] + eps_i * lsce_sums[1]) * inv_units;
+  const float rmse = sq_recon[0] * inv_recon;
+  stats[0] = multitask ? noise + (recon_w * rmse + smooth) * inv_steps : noise;
+  stats[1] = smooth; stats[2] = rmse; stats[3] = noise;
+  stats[4] = lsce_sums[3] > 0.f ? lsce_sums[2] / lsce_sums[3] : 0.f;
+  stats[5] = lsce_sums[3]; stats[6] = 0.f; stats[7] = 0.f;
+}
+
+}  // namespace dn
+
+struct DnEpsTrain {
+  DnEpsConfig cfg;
+  int C, n_cond;
+  int64_t w_freq, tc_W, tc_b, cond_W, cond_b, init_W, init_b, final_W, final_b;
+  WaveP wn;
+  TfP tf;
+  int64_t t_init, t_final;
+  int64_t f_condT;  // fp32 transposed conditioning projection [padn(C)][n_cond], in the derived-fp32 region
+  int64_t n_params, n_trans, n_fderived;
+  float* master;
+  void* work;
+  char* aux;
+  float* grads;
+  const float* pos_table;
+};
+
+namespace {
+
+struct EpsPlan {
+  float *cond, *gb, *d_gb, *d_cond, *ds, *xt, *eps, *d_eps, *rows, *sums, *noise_b, *film_rows;
+  void *xt_act, *h0, *x1_act, *d_eps_act, *tp_act, *d_tp, *d_h0;
+  float* pred;
+  WaveSave wv;
+  TfSave tf;
+  WaveTmp wt;
+  TfTmp tt;
+  VaePlan vae;
+  void* wg_scratch;
+  float* red_scratch;
+};
+
+size_t eps_max_wgrad_bytes(const DnEpsTrain* m, int B, int T) {
+  const int es = esize(m->cfg.dtype);
+  size_t mx = 0;
+  auto upd = [&](int cin, int cout, int taps, int max_shift, int b, int t, int e) {
+    const size_t v = plan_wgrad(cin, cout, taps, max_shift, b, t, e).total();
+    mx = v > mx ? v : mx;
+  };
+  const int D = m->cfg.dim, hd = m->cfg.heads * m->cfg.dim_head, ip = padk(m->tf.inner);
+  upd(m->cfg.latent, D, 1, 0, B, T, es); upd(D, D, 3, 2, B, T, es); upd(D, D, 3, 2 << (m->wn.L - 1), B, T, es); upd(D, D, m->wn.L, 0, B, T, es);
+  upd(D, 3 * hd, 1, 0, B, T, es); upd(hd, D, 1, 0, B, T, es); upd(D, 2 * ip, 1, 0, B, T, es); upd(m->tf.inner, m->tf.inner, 3, 2, B, T, es);
+  upd(m->tf.inner, D, 1, 0, B, T, es); upd(D, D, 1, 0, B, T, es); upd(D, m->cfg.latent, 1, 0, B, T, es);
+  upd(m->C, m->n_cond, 1, 0, 1, B, 4);  // the conditioning projection: the batch is its "frame" axis, fp32
+  return mx;
+}
+
+EpsPlan plan_eps_train(const DnEpsTrain* m, const DnVaeTrain* vae, int B, int T, Arena& ar) {
+  const int es = esize(m->cfg.dtype), D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
+  const size_t M = (size_t)B * T;
+  EpsPlan p;
+  memset(&p, 0, sizeof(p));
+  p.cond = (float*)ar.take((size_t)B * m->C * 4);
+  p.gb = (float*)ar.take((size_t)B * m->n_cond * 4);
+  p.d_gb = (float*)ar.take((size_t)B * m->n_cond * 4);
+  p.d_cond = (float*)ar.take((size_t)B * m->C * 4);
+  p.ds = (float*)ar.take((size_t)B * m->C * 4);
+  p.xt = (float*)ar.take(M * zl * 4);
+  p.xt_act = ar.take(M * zp * es);
+  p.h0 = ar.take(M * Dp * es);
+  p.wv = plan_wave_save(m->wn, (int)M, es, ar);
+  p.tf = plan_tf_save(m->tf, B, T, es, ar);
+  p.pred = (float*)ar.take(M * Dp * 4);
+  p.tp_act = ar.take(M * Dp * es);
+  p.eps = (float*)ar.take(M * zl * 4);
+  p.d_eps = (float*)ar.take(M * zp * 4);
+  p.x1_act = ar.take(M * zp * es);
+  p.d_eps_act = ar.take(M * zp * es);
+  p.rows = (float*)ar.take(M * 4 * 4);
+  p.sums = (float*)ar.take(64 * 4);
+  p.noise_b = (float*)ar.take((size_t)B * 4 * 4);
+  p.film_rows = (float*)ar.take(M * 2 * Dp * 4);
+  p.d_tp = ar.take(M * Dp * es);
+  p.d_h0 = ar.take(M * Dp * es);
+  const size_t wide = M * Dp * es;
+  p.wt.d_sk = ar.take(wide); p.wt.d_out0 = ar.take(wide * m->wn.L); p.wt.d_out1 = ar.take(wide * m->wn.L); p.wt.d_h = ar.take(wide * m->wn.L);
+  p.wt.d_h0 = ar.take(wide);
+  p.tt = plan_tf_tmp(m->tf, B, T, es, ar);
+  p.wg_scratch = ar.take(eps_max_wgrad_bytes(m, B, T));
+  p.red_scratch = (float*)ar.take(((size_t)1024 * 1024 + 4096) * 4 + dn_rmsnorm_backward_scratch_bytes(B, T, D));
+  if (vae) {
+    p.vae = plan_vae_train(vae, B, T, ar, false);
+    p.vae.z_act = p.x1_act;  // the decoder's input is x1_hat
+  }
+  return p;
+}
+
+Ctx eps_ctx(const DnEpsTrain* m, int B, int T, const EpsPlan& pl, hipStream_t s) {
+  Ctx c;
+  c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = false;
+  c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
+  c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  return c;
+}
+
+int eps_check(const DnEpsTrain* m, const DnVaeTrain* vae, const DnEpsTrainBatch* b, void* ws, size_t ws_bytes, EpsPlan* pl, const char* who) {
+  DN_CHECK_ARG(m && b && ws, "%s: null argument", who);
+  DN_CHECK_ARG(m->master && m->work && m->aux && m->grads && m->pos_table, "%s: dn_eps_train_bind has not been called", who);
+  DN_CHECK_ARG(b->z && b->jitter && b->true_noise && b->times && b->lengths && b->sqrt_ac && b->sqrt_1mac && b->snr_weight && b->stats,
+               "%s: null batch tensor", who);
+  DN_CHECK_ARG(b->B > 0 && b->T > 2 && b->T <= m->cfg.max_pos && b->timesteps > 1, "%s: B=%d T=%d", who, b->B, b->T);
+  DN_CHECK_ARG(!b->multitask || (vae && vae->work && vae->aux && b->feat && b->units && b->n_units > 0 && b->n_frames > 0),
+               "%s: the multitask loss needs the bound frozen VAE, feat and units", who);
+  DN_CHECK_ARG(!vae || (vae->cfg.z == m->cfg.latent && vae->cfg.dtype == m->cfg.dtype), "%s: VAE latent width / dtype do not match", who);
+  DN_CHECK_ARG(((uintptr_t)ws & 255) == 0, "%s: workspace must be 256-byte aligned", who);
+  Arena ar{(char*)ws, 0, ws_bytes};
+  *pl = plan_eps_train(m, b->multitask ? vae : nullptr, b->B, b->T, ar);
+  if (ar.off > ws_bytes) {
+    dn_set_error("%s: workspace %zu < required %zu (dn_eps_train_workspace_bytes)", who, ws_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  return DN_OK;
+}
+
+}  // namespace
+
+extern "C" int dn_eps_train_create(const DnEpsConfig* cfg, DnEpsTrain** out) {
+  DN_CHECK_ARG(cfg && out, "dn_eps_train_create: null argument");
+  DN_CHECK_ARG(cfg->dtype == DN_F32 || cfg->dtype == DN_BF16, "dn_eps_train_create: bad dtype");
+  DN_CHECK_ARG(cfg->dim % 8 == 0 && (cfg->heads * cfg->dim_head) % 64 == 0 && cfg->latent % 4 == 0 && (cfg->dim * cfg->cond_mult) % 64 == 0,
+               "dn_eps_train_create: dim %% 8, heads*dim_head %% 64, latent %% 4, dim*cond_mult %% 64 required");
+  DN_CHECK_ARG(cfg->wn_layers >= 1 && cfg->wn_layers <= DN_MAX_TERMS && cfg->wn_stacks >= 1, "dn_eps_train_create: wavenet stacks/layers");
+  DnEpsTrain* m = new (std::nothrow) DnEpsTrain();
+  DN_CHECK_ARG(m != nullptr, "dn_eps_train_create: out of host memory");
+  memset(m, 0, sizeof(*m));
+  m->cfg = *cfg;
+  const int64_t D = cfg->dim, Dp = padk(D), Dn = padn(D), zl = cfg->latent, zp = padk(zl);
+  m->C = cfg->dim * cfg->cond_mult;
+  m->n_cond = (cfg->wn_stacks * cfg->wn_layers + 2 * cfg->depth) * 2 * (int)Dp;
+  int64_t cur = 0, tcur = 0, fcur = 0;
+  // conditioning path first: its gradients complete last (every FiLM / adaptive-norm consumer must have run)
+  m->w_freq = take(cur, D / 2); m->tc_W = take(cur, (int64_t)m->C * (D + 1)); m->tc_b = take(cur, m->C);
+  m->cond_W = take(cur, (int64_t)padn(m->n_cond) * m->C); m->cond_b = take(cur, m->n_cond);
+  m->init_W = take(cur, Dn * zp); m->init_b = take(cur, Dp);
+  m->wn.cin = m->wn.cout = cfg->dim; m->wn.S = cfg->wn_stacks; m->wn.L = cfg->wn_layers; m->wn.film_col = 0;
+  layout_wave(m->wn, cur, tcur, fcur);
+  m->tf.dim = cfg->dim; m->tf.depth = cfg->depth; m->tf.heads = cfg->heads; m->tf.dim_head = cfg->dim_head;
+  m->tf.inner = (int)((double)cfg->dim * 4 * 2 / 3);
+  m->tf.cond_col = cfg->wn_stacks * cfg->wn_layers * 2 * (int)Dp;
+  layout_tf(m->tf, cur, tcur);
+  m->final_W = take(cur, (int64_t)padn(zl) * Dp); m->final_b = take(cur, zp);
+  m->t_init = take(tcur, (int64_t)padn(zp) * Dp);
+  m->t_final = take(tcur, (int64_t)padn(Dp) * zp);
+  m->f_condT = take(fcur, (int64_t)padn(m->C) * m->n_cond);
+  m->n_params = cur; m->n_trans = tcur; m->n_fderived = fcur;
+  *out = m;
+  return DN_OK;
+}
+
+extern "C" void dn_eps_train_destroy(DnEpsTrain* m) { delete m; }
+extern "C" int64_t dn_eps_train_param_count(const DnEpsTrain* m) { return m ? m->n_params : 0; }
+extern "C" size_t dn_eps_train_aux_bytes(const DnEpsTrain* m) {
+  return m ? (size_t)r64(m->n_trans) * esize(m->cfg.dtype) + (size_t)m->n_fderived * 4 + 256 : 0;
+}
+
+// table order (diffnorm_amd/packing.py::eps_train_entries): w_freq, tc_W, tc_b, cond_W, cond_b, init_W, init_b, the WaveNet's 10
+// tensors, per layer qkv_W, out_W, ffin_W, ffin_b, ffconv_W, ffconv_b, ffout_W, ffout_b; pred_gamma, pred_W, final_W, final_b
+extern "C" int dn_eps_train_offsets(const DnEpsTrain* m, int64_t* offsets, int32_t capacity) {
+  DN_CHECK_ARG(m && offsets, "dn_eps_train_offsets: null argument");
+  const int n = 7 + 10 + 8 * m->tf.depth + 2 + 2;
+  DN_CHECK_ARG(capacity >= n, "dn_eps_train_offsets: capacity %d < %d", capacity, n);
+  int k = 0;
+  for (int64_t o : {m->w_freq, m->tc_W, m->tc_b, m->cond_W, m->cond_b, m->init_W, m->init_b}) offsets[k++] = o;
+  const WaveP& w = m->wn;
+  for (int64_t o : {w.init_W, w.init_b, w.conv_W, w.conv_b, w.res_W, w.res_b, w.skip_W, w.skip_b, w.final_W, w.final_b}) offsets[k++] = o;
+  const TfP& t = m->tf;
+  for (int l = 0; l < t.depth; ++l)
+    for (int64_t o : {t.qkv_W(l), t.out_W(l), t.ffin_W(l), t.ffin_b(l), t.ffconv_W(l), t.ffconv_b(l), t.ffout_W(l), t.ffout_b(l)}) offsets[k++] = o;
+  for (int64_t o : {t.pred_gamma, t.pred_W, m->final_W, m->final_b}) offsets[k++] = o;
+  return n;
+}
+
+// stages: 0 = losses + frozen VAE decoder + final_proj + to_pred; 1 .. depth = layers depth-1 .. 0; depth+1 = WaveNet + init_conv;
+// depth+2 = conditioning path (time MLP + FiLM / adaptive-norm projections)
+extern "C" int dn_eps_train_stage_range(const DnEpsTrain* m, int32_t stage, int64_t* offset, int64_t* count) {
+  DN_CHECK_ARG(m && offset && count, "dn_eps_train_stage_range: null argument");
+  const int depth = m->tf.depth;
+  DN_CHECK_ARG(stage >= 0 && stage <= depth + 2, "dn_eps_train_stage_range: stage %d", stage);
+  int64_t lo, hi;
+  if (stage == 0) {
+    lo = m->tf.pred_gamma; hi = m->n_params;
+  } else if (stage <= depth) {
+    lo = m->tf.layer0 + (int64_t)(depth - stage) * m->tf.layer_stride; hi = lo + m->tf.layer_stride;
+  } else if (stage == depth + 1) {
+    lo = m->init_W; hi = m->tf.layer0;
+  } else {
+    lo = 0; hi = m->init_W;
+  }
+  *offset = lo; *count = hi - lo;
+  return DN_OK;
+}
+
+extern "C" int dn_eps_train_bind(DnEpsTrain* m, float* master, void* work, void* aux, float* grads, const float* pos_table) {
+  DN_CHECK_ARG(m && master && work && aux && grads && pos_table, "dn_eps_train_bind: null argument");
+  for (const void* p : {(const void*)master, (const void*)work, (const void*)aux, (const void*)grads, (const void*)pos_table})
+    DN_CHECK_ARG(((uintptr_t)p & 255) == 0, "dn_eps_train_bind: buffers must be 256-byte aligned");
+  DN_CHECK_ARG(m->cfg.dtype == DN_BF16 || (const void*)work == (const void*)master, "dn_eps_train_bind: in f32 mode work must be master");
+  m->master = master; m->work = work; m->aux = (char*)aux; m->grads = grads; m->pos_table = pos_table;
+  return DN_OK;
+}
+
+extern "C" int dn_eps_train_refresh(DnEpsTrain* m, void* stream) {
+  DN_CHECK_ARG(m && m->work && m->aux, "dn_eps_train_refresh: not bound");
+  const int dtype = m->cfg.dtype, es = esize(dtype);
+  hipStream_t s = (hipStream_t)stream;
+  auto tr_strided = [&](int64_t off, int64_t src_stride, int64_t toff, int count, int N, int Kp) -> int {
+    return dn_transpose_weights(static_cast<const char*>(m->work) + off * es, dtype, count, src_stride, padk(N), Kp, m->aux + toff * es,
+                                (int64_t)padn(Kp) * padk(N), padk(N), padn(Kp), s);
+  };
+  auto tr = [&](int64_t off, int64_t toff, int count, int N, int Kp) -> int { return tr_strided(off, (int64_t)padn(N) * Kp, toff, count, N, Kp); };
+  float* fder = reinterpret_cast<float*>(m->aux + r64(m->n_trans) * es);
+  const WaveP& w = m->wn;
+  const int D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
+  DN_TRY(tr(m->init_W, m->t_init, 1, D, zp));
+  DN_TRY(tr(w.init_W, w.t_init, 3, D, Dp));
+  DN_TRY(tr(w.conv_W, w.t_conv, w.S * w.L * 3, D, Dp));
+  DN_TRY(tr(w.res_W, w.t_res, w.S * w.L, D, Dp));
+  DN_TRY(tr(w.skip_W, w.t_skip, w.L, D, Dp));
+  DN_TRY(tr(w.final_W, w.t_final, 1, D, Dp));
+  DN_TRY(dn_sum_groups(m->master + w.skip_b, Dp, w.L, fder + w.skip_bsum, DN_F32, Dp, s));
+  const TfP& t = m->tf;
+  const int hd = t.heads * t.dim_head, ip = padk(t.inner);
+  DN_TRY(tr_strided(t.qkv_W(0), t.layer_stride, t.t_qkv, t.depth, 3 * hd, Dp));
+  DN_TRY(tr_strided(t.out_W(0), t.layer_stride, t.t_out, t.depth, D, hd));
+  DN_TRY(tr_strided(t.ffin_W(0), t.layer_stride, t.t_ffin, t.depth, 2 * ip, Dp));
+  for (int l = 0; l < t.depth; ++l) DN_TRY(tr(t.ffconv_W(l), t.t_ffconv + (int64_t)l * 3 * padn(ip) * ip, 3, t.inner, ip));
+  DN_TRY(tr_strided(t.ffout_W(0), t.layer_stride, t.t_ffout, t.depth, D, ip));
+  DN_TRY(tr(t.pred_W, t.t_pred, 1, D, Dp));
+  DN_TRY(tr(m->final_W, m->t_final, 1, zl, Dp));
+  // the fp32 conditioning projection [n_cond][C] -> [padn(C)][n_cond], from the master buffer
+  return dn_transpose_weights(m->master + m->cond_W, DN_F32, 1, (int64_t)padn(m->n_cond) * m->C, m->n_cond, m->C, fder + m->f_condT,
+                              (int64_t)padn(m->C) * m->n_cond, m->n_cond, padn(m->C), s);
+}
+
+extern "C" size_t dn_eps_train_workspace_bytes(const DnEpsTrain* m, const DnVaeTrain* vae, int32_t B, int32_t T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  Arena ar{nullptr, 0, 0};
+  (void)plan_eps_train(m, vae, B, T, ar);
+  return ar.off + 256;
+}
+
+extern "C" int dn_eps_train_forward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch* b, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  EpsPlan pl;
+  DN_TRY(eps_check(m, vae, b, workspace, workspace_bytes, &pl, "dn_eps_train_forward"));
+  hipStream_t s = (hipStream_t)stream;
+  const Ctx c = eps_ctx(m, b->B, b->T, pl, s);
+  const int dtype = c.dtype, B = b->B, T = b->T, M = c.M, D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
+  const int ew = (int)std::min<int64_t>(((int64_t)M * zp + 255) / 256, 4096);
+  hipLaunchKernelGGL(dn::eps_prep_kernel, dim3(ew), dim3(256), 0, s, b->z, b->jitter, b->true_noise, b->times, b->sqrt_ac, b->sqrt_1mac, b->beta0, M, T,
+                     zl, zp, pl.xt, pl.xt_act, dtype);
+  // conditioning: to_time_cond (:741-745) and all FiLM / adaptive-norm projections at once (:507,517,624,637), fp32
+  DN_TRY(dn_time_cond(b->times, B, c.P(m->w_freq), D / 2, c.P(m->tc_W), c.P(m->tc_b), m->C, pl.cond, nullptr, DN_F32, m->C, s));
+  {
+    DnGemmParams p = gemm_base(DN_F32, B, m->n_cond, m->C, 1);
+    p.terms[0].A = pl.cond; p.terms[0].lda = m->C; p.terms[0].W = c.P(m->cond_W);
+    p.bias = c.P(m->cond_b); p.out = pl.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  {  // init_conv 1x1 (:734,864)
+    DnGemmParams p = gemm_base(dtype, M, Dp, zp, T);
+    p.terms[0].A = pl.xt_act; p.terms[0].lda = zp; p.terms[0].W = c.W(m->init_W);
+    p.bias = c.P(m->init_b); p.out = pl.h0; p.ldo = Dp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  {  // WaveNet; its final conv adds the positional embedding and opens the fp32 residual stream (:865-868)
+    DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
+    fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = b->lengths;
+    fin.out = pl.tf.x; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    DN_TRY(wave_forward(c, m->wn, pl.h0, pl.wv, fin, pl.gb, m->n_cond));
+  }
+  DN_TRY(tf_forward(c, m->tf, b->lengths, pl.tf, pl.pred, Dp, pl.gb, m->n_cond));
+  DN_TRY(dn_convert_rows(pl.pred, DN_F32, Dp, pl.tp_act, dtype, Dp, M, D, s));
+  {  // final_proj (:807,875)
+    DnGemmParams p = gemm_base(dtype, M, zl, Dp, T);
+    p.terms[0].A = pl.tp_act; p.terms[0].lda = Dp; p.terms[0].W = c.W(m->final_W);
+    p.bias = c.P(m->final_b); p.out = pl.eps; p.ldo = zl; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  if (b->eps_out) DN_TRY(dn_convert_rows(pl.eps, DN_F32, zl, b->eps_out, DN_F32, zl, M, zl, s));
+  // noise loss (:1563-1571): masked squared error, per-sample mean over ALL T*z, min-SNR weight, batch mean
+  const float g_noise = b->loss_scale * 2.0f / ((float)B * (float)T * (float)zl);
+  hipLaunchKernelGGL(dn::eps_post_kernel, dim3((M + 3) / 4), dim3(256), 0, s, pl.eps, b->true_noise, pl.xt, b->times, b->sqrt_ac, b->sqrt_1mac,
+                     b->snr_weight, b->lengths, g_noise, M, T, zl, zp, pl.rows, pl.d_eps, pl.x1_act, dtype);
+  DN_TRY(dn_colsum(pl.rows, 4, DN_F32, B, T, 4, pl.noise_b, 4, 1.0f, 0, pl.red_scratch, s));
+  hipMemsetAsync(pl.sums, 0, 64 * 4, s);
+  if (b->multitask) {  // x1_hat through the frozen VAE decoder (:1574-1596)
+    const Ctx vc = make_ctx(vae, B, T, pl.vae, s, true);
+    const int V = vae->cfg.vocab, Dv = vae->cfg.dim;
+    DN_TRY(vae_decoder_forward(vc, vae, pl.vae, b->lengths));
+    const float g_ls = b->loss_scale / ((float)b->timesteps * (float)b->n_units);
+    DN_TRY(dn_lsce_loss_grad(pl.vae.logits, V, b->units, M, V, b->label_smoothing, g_ls, pl.vae.lsce_rows, pl.vae.dlogits, dtype, padn(V), s));
+    DN_TRY(dn_masked_mse_grad(pl.vae.rec, padk(Dv), b->feat, Dv, M, Dv, T, b->lengths, 0.f, pl.vae.sq_rows, nullptr, 0, 0, nullptr, dtype, 0, s));
+    DN_TRY(dn_colsum(pl.vae.lsce_rows, 4, DN_F32, 1, M, 4, pl.sums, 0, 1.0f, 0, pl.red_scratch, s));
+    DN_TRY(dn_vec_sum(pl.vae.sq_rows, M, pl.sums + 4, 0, pl.red_scratch, s));
+  }
+  const int Vv = vae ? vae->cfg.vocab : 1004, Dv = vae ? vae->cfg.dim : 1;
+  hipLaunchKernelGGL(dn::eps_loss_kernel, dim3(1), dim3(1), 0, s, pl.sums, pl.sums + 4, pl.noise_b, 4, b->snr_weight, B, 1.0f / ((float)T * (float)zl),
+                     b->label_smoothing, Vv, b->n_units > 0 ? 1.0f / (float)b->n_units : 0.f,
+                     b->n_frames > 0 ? 1.0f / ((float)b->n_frames * (float)Dv) : 0.f, b->recon_weight, 1.0f / (float)b->timesteps, b->multitask,
+                     b->stats);
+  DN_CHECK_LAUNCH("dn_eps_train_forward");
+  return DN_OK;
+}
+
+extern "C" int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch* b, int32_t first_stage, int32_t last_stage,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  EpsPlan pl;
+  DN_TRY(eps_check(m, vae, b, workspace, workspace_bytes, &pl, "dn_eps_train_backward"));
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c = eps_ctx(m, b->B, b->T, pl, s);
+  const int dtype = c.dtype, B = b->B, T = b->T, M = c.M, D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
+  const int depth = m->tf.depth;
+  DN_CHECK_ARG(first_stage >= 0 && last_stage <= depth + 2 && first_stage <= last_stage, "dn_eps_train_backward: stages [%d, %d]", first_stage,
+               last_stage);
+  const int ew = (int)std::min<int64_t>(((int64_t)M * zp + 255) / 256, 4096);
+  for (int stage = first_stage; stage <= last_stage; ++stage) {
+    if (stage == 0) {
+      hipMemsetAsync(pl.d_gb, 0, (size_t)B * m->n_cond * 4, s);
+      const float* dx1 = nullptr;
+      if (b->multitask) {  // d total / d x1_hat: the frozen decoder's data gradients (no parameter gradients)
+        const Ctx vc = make_ctx(vae, B, T, pl.vae, s, true);
+        const float g_mse = b->loss_scale * b->recon_weight * 2.0f / ((float)b->timesteps * (float)b->n_frames * (float)vae->cfg.dim);
+        for (int vs = 0; vs <= vae->tf.depth + 1; ++vs) DN_TRY(vae_decoder_backward(vc, vae, pl.vae, b->feat, b->lengths, g_mse, vs));
+        dx1 = pl.vae.dz;
+      }
+      hipLaunchKernelGGL(dn::eps_combine_kernel, dim3(ew), dim3(256), 0, s, pl.d_eps, dx1, b->times, b->sqrt_ac, b->sqrt_1mac, M, T, zl, zp,
+                         pl.d_eps_act, dtype);
+      // final_proj (:875)
+      WgTap tap{pl.tp_act, Dp, 0};
+      DN_TRY(weight_grad(c, &tap, 1, D, pl.d_eps_act, zp, zl, c.G(m->final_W)));
+      DN_TRY(bias_grad(c, pl.d_eps_act, zp, dtype, 1, M, zp, c.G(m->final_b), 0));
+      DN_TRY(linear_dgrad(c, pl.d_eps_act, zp, zp, c.Wt(m->t_final), pl.d_tp, Dp, dtype));
+      DN_TRY(tf_backward_head(c, m->tf, pl.tf, pl.d_tp, pl.tt));
+    } else if (stage <= depth) {
+      DN_TRY(tf_backward_layer(c, m->tf, depth - stage, b->lengths, pl.tf, pl.tt, pl.gb, m->n_cond, pl.d_gb));
+    } else if (stage == depth + 1) {
+      // the positional embedding is a constant: the residual stream's gradient goes straight into the WaveNet's final conv
+      DN_TRY(wave_backward(c, m->wn, pl.h0, pl.wv, pl.tt.dx_act, pl.d_h0, dtype, pl.wt, pl.gb, m->n_cond, pl.d_gb, pl.film_rows));
+      WgTap tap{pl.xt_act, zp, 0};  // init_conv 1x1
+      DN_TRY(weight_grad(c, &tap, 1, zl, pl.d_h0, Dp, D, c.G(m->init_W)));
+      DN_TRY(bias_grad(c, pl.d_h0, Dp, dtype, 1, M, Dp, c.G(m->init_b), 0));
+    } else {
+      // conditioning path, fp32: gb = cond W_c^T + b_c  ->  d b_c, d W_c = d gb^T cond (the batch is the contracted axis), d cond
+      Ctx cf = c;
+      cf.dtype = DN_F32; cf.es = 4; cf.B = 1; cf.T = B; cf.M = B;
+      cf.work = m->master;  // fp32 operands
+      DN_TRY(dn_colsum(pl.d_gb, m->n_cond, DN_F32, 1, B, m->n_cond, c.G(m->cond_b), 0, 1.0f, 1, pl.red_scratch, s));
+      WgTap tap{pl.cond, m->C, 0};
+      DN_TRY(weight_grad(cf, &tap, 1, m->C, pl.d_gb, m->n_cond, m->n_cond, c.G(m->cond_W)));
+      {
+        float* fder = reinterpret_cast<float*>(m->aux + r64(m->n_trans) * c.es);
+        DnGemmParams p = gemm_base(DN_F32, B, m->C, m->n_cond, 1);
+        p.terms[0].A = pl.d_gb; p.terms[0].lda = m->n_cond; p.terms[0].W = fder + m->f_condT;
+        p.out = pl.d_cond; p.ldo = m->C; p.out_dtype = DN_F32;
+        DN_TRY(dn_conv_gemm(&p, s));
+      }
+      DN_TRY(dn_time_cond_backward(b->times, B, c.P(m->w_freq), D / 2, c.P(m->tc_W), c.P(m->tc_b), m->C, pl.d_cond, m->C, pl.ds, c.G(m->w_freq),
+                                   c.G(m->tc_W), c.G(m->tc_b), s));
+    }
+  }
+  DN_CHECK_LAUNCH("dn_eps_train_backward");
   return DN_OK;
 }

@@ -517,6 +517,95 @@ __global__ __launch_bounds__(256) void transpose_pad_f32_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------ time conditioning backward
+// cond[b, c] = silu(s[b, c]), s = W f[b] + bias, f[b] = [t, sin(2 pi w t), cos(2 pi w t)] (latent_module.py:104-116, 741-745).
+// Stage 1 (one workgroup per (16 outputs, sample)): recompute f and s, ds = dcond * silu'(s) -> ds[B, C].
+__global__ __launch_bounds__(256) void time_cond_bwd_ds_kernel(const int32_t* __restrict__ times, const float* __restrict__ wf, int half,
+                                                               const float* __restrict__ W, const float* __restrict__ bias, int C,
+                                                               const float* __restrict__ dcond, int ldd, float* __restrict__ ds) {
+  extern __shared__ float feat[];
+  const int b = blockIdx.y;
+  const int nfeat = 2 * half + 1;
+  const float tf = (float)times[b];
+  for (int k = threadIdx.x; k < nfeat; k += 256) {
+    float f = tf;
+    if (k > 0) {
+      const int j = k <= half ? k - 1 : k - 1 - half;
+      const float ang = __fmul_rn(__fmul_rn(__fmul_rn(tf, wf[j]), 2.0f), 3.14159265358979323846f);
+      f = k <= half ? sinf(ang) : cosf(ang);
+    }
+    feat[k] = f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = blockIdx.x * 16 + wave * 4 + i;
+    if (c >= C) break;
+    const float* wr = W + (int64_t)c * nfeat;
+    float s = 0.f;
+    for (int k = lane; k < nfeat; k += 64) s += feat[k] * wr[k];
+    s = wave_sum64(s);
+    if (lane == 0) {
+      const float z = s + bias[c];
+      const float sg = 1.0f / (1.0f + expf(-z));
+      ds[(int64_t)b * C + c] = dcond[(int64_t)b * ldd + c] * (sg * (1.0f + z * (1.0f - sg)));  // silu'(z)
+    }
+  }
+}
+
+// Stage 2: dW[c, k] += sum_b ds[b, c] f[b, k]; dbias[c] += sum_b ds[b, c]  (one thread per (c, k); B is small)
+__global__ __launch_bounds__(256) void time_cond_bwd_dw_kernel(const int32_t* __restrict__ times, int B, const float* __restrict__ wf, int half,
+                                                               int C, const float* __restrict__ ds, float* __restrict__ dW,
+                                                               float* __restrict__ dbias) {
+  const int nfeat = 2 * half + 1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)C * nfeat) return;
+  const int c = (int)(i / nfeat), k = (int)(i - (int64_t)c * nfeat);
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float tf = (float)times[b];
+    float f = tf;
+    if (k > 0) {
+      const int j = k <= half ? k - 1 : k - 1 - half;
+      const float ang = __fmul_rn(__fmul_rn(__fmul_rn(tf, wf[j]), 2.0f), 3.14159265358979323846f);
+      f = k <= half ? sinf(ang) : cosf(ang);
+    }
+    const float d = ds[(int64_t)b * C + c];
+    acc += d * f;
+    accb += d;
+  }
+  dW[i] += acc;
+  if (k == 0) dbias[c] += accb;
+}
+
+// Stage 3: dw_freq[j] += sum_b (df_sin[b, j] cos(ang) - df_cos[b, j] sin(ang)) * 2 pi t_b, df[b, k] = sum_c ds[b, c] W[c, k]
+__global__ __launch_bounds__(256) void time_cond_bwd_freq_kernel(const int32_t* __restrict__ times, int B, const float* __restrict__ wf, int half,
+                                                                 const float* __restrict__ W, int C, const float* __restrict__ ds,
+                                                                 float* __restrict__ dwf) {
+  const int j = blockIdx.x;  // one workgroup per frequency
+  const int nfeat = 2 * half + 1;
+  __shared__ float red[4];
+  float total = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float ps = 0.f, pc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float d = ds[(int64_t)b * C + c];
+      ps += d * W[(int64_t)c * nfeat + 1 + j];
+      pc += d * W[(int64_t)c * nfeat + 1 + half + j];
+    }
+    const float tf = (float)times[b];
+    const float ang = __fmul_rn(__fmul_rn(__fmul_rn(tf, wf[j]), 2.0f), 3.14159265358979323846f);
+    float v = (ps * cosf(ang) - pc * sinf(ang)) * (6.28318530717958647692f * tf);
+    v = wave_sum64(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) total += (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dwf[j] += total;
+}
+
 }  // namespace dn
 
 using namespace dn;
@@ -706,5 +795,20 @@ extern "C" int dn_transpose_pad_f32(const float* src, int32_t ld, int32_t B, int
   dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
   hipLaunchKernelGGL(transpose_pad_f32_kernel, grid, dim3(256), 0, S_(stream), src, ld, B, T, C, front, Tp, dst, rows, rows_total, row0, chunk);
   DN_CHECK_LAUNCH("dn_transpose_pad_f32");
+  return DN_OK;
+}
+
+extern "C" int dn_time_cond_backward(const int32_t* times, int32_t B, const float* w_freq, int32_t half, const float* W, const float* bias,
+                                     int32_t C, const float* dcond, int32_t ldd, float* ds_scratch, float* dw_freq, float* dW, float* dbias,
+                                     void* stream) {
+  DN_CHECK_ARG(times && w_freq && W && bias && dcond && ds_scratch && dw_freq && dW && dbias && B > 0 && half > 0 && C > 0 && ldd >= C,
+               "dn_time_cond_backward: bad args");
+  const int nfeat = 2 * half + 1;
+  hipLaunchKernelGGL(time_cond_bwd_ds_kernel, dim3((C + 15) / 16, B), dim3(256), nfeat * sizeof(float), S_(stream), times, w_freq, half, W, bias, C,
+                     dcond, ldd, ds_scratch);
+  hipLaunchKernelGGL(time_cond_bwd_dw_kernel, dim3((unsigned)(((int64_t)C * nfeat + 255) / 256)), dim3(256), 0, S_(stream), times, B, w_freq, half,
+                     C, ds_scratch, dW, dbias);
+  hipLaunchKernelGGL(time_cond_bwd_freq_kernel, dim3(half), dim3(256), 0, S_(stream), times, B, w_freq, half, W, C, ds_scratch, dw_freq);
+  DN_CHECK_LAUNCH("dn_time_cond_backward");
   return DN_OK;
 }

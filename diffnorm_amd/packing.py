@@ -382,3 +382,64 @@ def unpack_flat(flat: torch.Tensor, entries: List[_Entry], offsets: List[int]) -
             n *= s
         e.unpack(flat[off: off + n].view(e.shape), sd)
     return sd
+
+
+def eps_train_entries(cfg) -> List[_Entry]:
+    """Table of the diffusion training engine's packed tensors, in the order of dn_eps_train_offsets (fp32; the conditioning
+    path first: to_time_cond, then the 2 S L FiLM and 2 depth adaptive-norm projections stacked as [gamma (Dp) ; beta (Dp)] rows)."""
+    f32 = _lib.DN_F32
+    D, Dp, Dn, zl = cfg.dim, padk(cfg.dim), padn(cfg.dim), cfg.latent_dim
+    zp, C = padk(zl), cfg.dim * cfg.dim_cond_mult
+    mods = [f"wavenet.stacks.{s}.blocks.{i}.to_time_cond." for s in range(cfg.wavenet_stacks) for i in range(cfg.wavenet_layers)]
+    mods += [f"transformer.layers.{l}.{j}.to_gamma_beta." for l in range(cfg.depth) for j in (0, 4)]
+    n_cond = len(mods) * 2 * Dp
+
+    def cond_pack(sd):
+        out = torch.zeros(padn(n_cond), C)
+        for n, key in enumerate(mods):
+            w = sd[key + "weight"].float()  # [2D, C]: [gamma ; beta]
+            out[n * 2 * Dp: n * 2 * Dp + D] = w[:D]
+            out[n * 2 * Dp + Dp: n * 2 * Dp + Dp + D] = w[D:]
+        return out
+
+    def cond_unpack(p, sd):
+        for n, key in enumerate(mods):
+            sd[key + "weight"] = torch.cat([p[n * 2 * Dp: n * 2 * Dp + D], p[n * 2 * Dp + Dp: n * 2 * Dp + Dp + D]], dim=0).clone()
+
+    def condb_pack(sd):
+        out = torch.zeros(n_cond)
+        for n, key in enumerate(mods):
+            b = sd[key + "bias"].float()
+            out[n * 2 * Dp: n * 2 * Dp + D] = b[:D]
+            out[n * 2 * Dp + Dp: n * 2 * Dp + Dp + D] = b[D:]
+        return out
+
+    def condb_unpack(p, sd):
+        for n, key in enumerate(mods):
+            sd[key + "bias"] = torch.cat([p[n * 2 * Dp: n * 2 * Dp + D], p[n * 2 * Dp + Dp: n * 2 * Dp + Dp + D]]).clone()
+
+    ents = [
+        _Entry("w_freq", (D // 2,), lambda sd: sd["to_time_cond.0.weights"].float().clone(),
+               lambda p, sd: sd.__setitem__("to_time_cond.0.weights", p.clone())),
+        _Entry("tc_W", (C, D + 1), lambda sd: sd["to_time_cond.1.weight"].float().clone(),
+               lambda p, sd: sd.__setitem__("to_time_cond.1.weight", p.clone())),
+        _Entry("tc_b", (C,), lambda sd: sd["to_time_cond.1.bias"].float().clone(), lambda p, sd: sd.__setitem__("to_time_cond.1.bias", p.clone())),
+        _Entry("cond_W", (padn(n_cond), C), cond_pack, cond_unpack),
+        _Entry("cond_b", (n_cond,), condb_pack, condb_unpack),
+        _Entry("init_W", (Dn, zp), lambda sd: _mat(sd["init_conv.weight"][:, :, 0], f32),
+               lambda p, sd: sd.__setitem__("init_conv.weight", _unmat(p, D, zl).unsqueeze(-1))),
+        _Entry("init_b", (Dp,), lambda sd: _vec(sd["init_conv.bias"], Dp), lambda p, sd: sd.__setitem__("init_conv.bias", p[:D].clone())),
+    ]
+    ents += _wavenet_entries("wavenet.", D, D, cfg.wavenet_stacks, cfg.wavenet_layers)
+    for l in range(cfg.depth):
+        ents += _tf_layer_entries("transformer.", l, D, cfg.heads, cfg.dim_head)[:8]  # no learned gammas in conditional norms
+    ents += [
+        _Entry("pred_gamma", (D,), lambda sd: sd["transformer.to_pred.0.gamma"].float().clone(),
+               lambda p, sd: sd.__setitem__("transformer.to_pred.0.gamma", p.clone())),
+        _Entry("pred_W", (Dn, Dp), lambda sd: _mat(sd["transformer.to_pred.1.weight"], f32),
+               lambda p, sd: sd.__setitem__("transformer.to_pred.1.weight", _unmat(p, D, D))),
+        _Entry("final_W", (padn(zl), Dp), lambda sd: _mat(sd["final_proj.weight"], f32),
+               lambda p, sd: sd.__setitem__("final_proj.weight", _unmat(p, zl, D))),
+        _Entry("final_b", (zp,), lambda sd: _vec(sd["final_proj.bias"], zp), lambda p, sd: sd.__setitem__("final_proj.bias", p[:zl].clone())),
+    ]
+    return ents

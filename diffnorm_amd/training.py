@@ -183,6 +183,156 @@ class VaeTrainEngine:
                                                       _lib.current_stream()), "dn_vae_train_backward")
 
 
+class _FlatEngine:
+    """Flat master / work / aux / gradient buffers of a training engine and the state-dict conversions over its entry table."""
+
+    def _alloc(self, aux_bytes: int):
+        with torch.cuda.device(self.device):
+            self._own = []
+            raw, view = _aligned_empty(self.n_params * 4, self.device)
+            self._own.append(raw)
+            self.master = view.view(torch.float32)
+            raw, view = _aligned_empty(self.n_params * 4, self.device)
+            self._own.append(raw)
+            self.grads = view.view(torch.float32)
+            if self.dtype == _lib.DN_BF16:
+                raw, view = _aligned_empty(self.n_params * 2, self.device)
+                self._own.append(raw)
+                self.work = view.view(torch.bfloat16)
+            else:
+                self.work = self.master
+            raw, self.aux = _aligned_empty(aux_bytes, self.device)
+            self._own.append(raw)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        flat = packing.pack_flat(sd, self.entries, self.offsets, self.n_params)
+        self.master.copy_(flat.to(self.device))
+        self.sync_work()
+
+    def sync_work(self):
+        if self.work is not self.master:
+            self.work.copy_(self.master)
+        self.refresh()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return packing.unpack_flat(self.master, self.entries, self.offsets)
+
+    def grad_dict(self) -> Dict[str, torch.Tensor]:
+        return packing.unpack_flat(self.grads, self.entries, self.offsets)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def _ws_ptr(self, need: int):
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        p = self._ws.data_ptr()
+        a = (p + 255) & ~255
+        return a, self._ws.numel() - (a - p)
+
+
+class EpsTrainEngine(_FlatEngine):
+    """The diffusion training step on the GPU (reference LatentDiscreteModel.forward latent_module.py:1514-1613): eps-predictor
+    forward / backward with FiLM and adaptive-norm time conditioning, min-SNR noise loss, and the multitask reconstruction losses
+    through the FROZEN VAE (`vae`: a VaeTrainEngine whose parameters receive no gradient, diff_discrete.py:79-82)."""
+
+    def __init__(self, state_dict, cfg, vae: Optional["VaeTrainEngine"], timesteps: int = 200, dtype="bf16", device="cuda:0",
+                 max_pos: int = 2048, multitask: bool = True):
+        from . import scheduler
+
+        self.device = _require_cuda(device)
+        self.lib = _lib.load()
+        self.cfg, self.vae, self.timesteps, self.multitask = cfg, vae, timesteps, multitask
+        self.dtype = _dtype_code(dtype)
+        self.depth = cfg.depth
+        c = _lib.EpsConfig(cfg.dim, cfg.latent_dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.wavenet_layers, cfg.wavenet_stacks,
+                           cfg.dim_cond_mult, self.dtype, max_pos)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.dn_eps_train_create(C.byref(c), C.byref(self.handle)), "dn_eps_train_create")
+        self.n_params = int(self.lib.dn_eps_train_param_count(self.handle))
+        self.entries = packing.eps_train_entries(cfg)
+        offs = (C.c_int64 * len(self.entries))()
+        n = _lib.check(self.lib.dn_eps_train_offsets(self.handle, offs, len(self.entries)), "dn_eps_train_offsets")
+        assert n == len(self.entries), (n, len(self.entries))
+        self.offsets = list(offs)
+        self._alloc(int(self.lib.dn_eps_train_aux_bytes(self.handle)))
+        raw, view = _aligned_empty((max_pos + 1) * packing.padk(cfg.dim) * 4, self.device)
+        self._own.append(raw)
+        self.pos_table = view.view(torch.float32)
+        self.pos_table.copy_(packing.sinusoidal_table(max_pos + 1, cfg.dim, packing.padk(cfg.dim)).reshape(-1))
+        _lib.check(self.lib.dn_eps_train_bind(self.handle, self.master.data_ptr(), self.work.data_ptr(), self.aux.data_ptr(),
+                                              self.grads.data_ptr(), self.pos_table.data_ptr()), "dn_eps_train_bind")
+        self.sched = scheduler.DDPMScheduler(timesteps)
+        self._sa = self.sched.f32("sqrt_alphas_cumprod", self.device)
+        self._s1 = self.sched.f32("sqrt_one_minus_alphas_cumprod", self.device)
+        self._beta0 = float(self.sched.f32("betas")[0])
+        self._ws = None
+        self._batch = None
+        self.load_state_dict(state_dict)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.dn_eps_train_destroy(self.handle)
+            self.handle = None
+
+    def refresh(self):
+        self.update_count = getattr(self, "update_count", 0) + 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_eps_train_refresh(self.handle, _lib.current_stream()), "dn_eps_train_refresh")
+
+    @property
+    def n_stages(self) -> int:
+        return self.depth + 3
+
+    def stage_ranges(self) -> List[Tuple[int, int]]:
+        out = []
+        off, cnt = C.c_int64(), C.c_int64()
+        for st in range(self.n_stages):
+            _lib.check(self.lib.dn_eps_train_stage_range(self.handle, st, C.byref(off), C.byref(cnt)), "dn_eps_train_stage_range")
+            out.append((off.value, cnt.value))
+        return out
+
+    def _vae_handle(self):
+        return self.vae.handle if (self.vae is not None and self.multitask) else None
+
+    def forward(self, feat, units, lengths, z, times, jitter, true_noise, loss_scale: float = 1.0, want_eps: bool = False):
+        """-> stats fp32 [8]: total_loss, nll_loss, recon_mse_loss, noise_loss, acc, n_units.  z [B,T,latent]: the frozen encoder's
+        posterior sample; times [B] in [1, timesteps); jitter / true_noise [B,T,latent]."""
+        dev = self.device
+        B, T, _ = z.shape
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        feat, z, jitter, true_noise = f32(feat), f32(z), f32(jitter), f32(true_noise)
+        units = units.to(dev, torch.int32).contiguous()
+        lengths = lengths.to(dev, torch.int32).contiguous()
+        times = times.to(dev, torch.int32).contiguous()
+        snr = self.sched.get_snr(times.long())
+        weight = (snr.clamp(max=5.0) / snr).to(dev, torch.float32).contiguous()  # min-SNR-5 (:1565-1569)
+        n_units = int((units != 0).sum().item())
+        n_frames = int(lengths.sum().item())
+        stats = torch.empty(8, dtype=torch.float32, device=dev)
+        eps = torch.empty(B, T, self.cfg.latent_dim, dtype=torch.float32, device=dev) if want_eps else None
+        b = _lib.EpsTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), z.data_ptr(), jitter.data_ptr(), true_noise.data_ptr(),
+                               times.data_ptr(), self._sa.data_ptr(), self._s1.data_ptr(), weight.data_ptr(), self._beta0, B, T, n_units,
+                               n_frames, self.timesteps, int(self.multitask), 0.1, 50.0, float(loss_scale), stats.data_ptr(), _lib.ptr(eps))
+        self._batch, self._keep = b, (feat, units, lengths, z, jitter, true_noise, times, weight, stats, eps)
+        need = int(self.lib.dn_eps_train_workspace_bytes(self.handle, self._vae_handle(), B, T))
+        wp, wn = self._ws_ptr(need)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.dn_eps_train_forward(self.handle, self._vae_handle(), C.byref(b), wp, wn, _lib.current_stream()),
+                       "dn_eps_train_forward")
+        return (stats, eps) if want_eps else stats
+
+    def backward(self, first_stage: int = 0, last_stage: Optional[int] = None):
+        assert self._batch is not None, "backward() needs a forward() first"
+        last_stage = self.n_stages - 1 if last_stage is None else last_stage
+        need = int(self.lib.dn_eps_train_workspace_bytes(self.handle, self._vae_handle(), self._batch.B, self._batch.T))
+        wp, wn = self._ws_ptr(need)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_eps_train_backward(self.handle, self._vae_handle(), C.byref(self._batch), first_stage, last_stage, wp, wn,
+                                                      _lib.current_stream()), "dn_eps_train_backward")
+
+
 def plan_buckets(ranges: Sequence[Tuple[int, int]], min_elems: int) -> List[Tuple[int, int, int]]:
     """Merges consecutive backward-stage ranges (each ends where the previous one starts: the backward walks the buffer from
     its end) into buckets of at least `min_elems` elements.  -> [(last_stage_of_bucket, offset, count)], in completion order."""

@@ -316,6 +316,11 @@ typedef struct {
 } DnAttnBwdParams;
 int dn_attention_backward(const DnAttnBwdParams* p, void* stream);
 
+/* Gradient of dn_time_cond (latent_module.py:104-116, 741-745): dcond fp32 [B, ldd] -> ACCUMULATES dW [C, 2*half+1], dbias [C] and
+ * dw_freq [half] (the learned Fourier frequencies: d/dw sin(2 pi w t) = 2 pi t cos(.)).  ds_scratch: fp32 [B, C].            */
+int dn_time_cond_backward(const int32_t* times, int32_t B, const float* w_freq, int32_t half, const float* W, const float* bias, int32_t C,
+                          const float* dcond, int32_t ldd, float* ds_scratch, float* dw_freq, float* dW, float* dbias, void* stream);
+
 /* WaveNet gate as a stand-alone pass (the training forward keeps the pre-activation h that its derivative needs):
  * out = tanh(h') sigmoid(h') + res with h' = h * gamma[b] + beta[b] when gamma_beta != NULL (latent_module.py:525-530).
  * h, res, out, dout, dh: [M, ld] in `dtype`, same ld.  Backward: dh = dout * gate'(h') [* gamma]; with FiLM, dgb_rows
@@ -494,6 +499,53 @@ int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* batch, void* work
  * the all-reduce of a finished range while later stages still run.                                                       */
 int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* batch, int32_t first_stage, int32_t last_stage, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ diffusion training step */
+/* LatentDiscreteModel.forward (latent_module.py:1514-1613; criterion fairseq/criterions/ddpm_discrete_loss.py:37-75) for the
+ * eps-predictor `Model`, with the frozen VAE (diff_discrete.py:70-85) as a bound DnVaeTrain whose decoder only passes data
+ * gradients.  Flat packed buffers / stages / refresh exactly as for the VAE engine above; the conditioning path (time MLP and
+ * the FiLM / adaptive-norm projections) is stored and differentiated in fp32 in every mode.  The caller supplies what the
+ * reference draws or looks up on the host: t, the posterior sample z of the frozen encoder (dn_vae_encode_params +
+ * dn_posterior_sample), the beta_0 jitter, the target noise, the fp32 schedule tables and min(snr, 5) / snr per sample.   */
+typedef struct DnEpsTrain DnEpsTrain;
+typedef struct {
+  const float* feat;        /* [B, T, dim_feat] target features (multitask reconstruction loss), may be NULL without multitask */
+  const int32_t* units;     /* [B, T] dictionary indices, 0 = pad                                                         */
+  const int32_t* lengths;   /* [B]                                                                                        */
+  const float* z;           /* [B, T, latent] posterior sample of the frozen VAE encoder (:1530)                          */
+  const float* jitter;      /* [B, T, latent]  x1 = z + jitter * beta0 (:1534-1536)                                       */
+  const float* true_noise;  /* [B, T, latent]                                                                             */
+  const int32_t* times;     /* [B] in [1, timesteps)                                                                      */
+  const float* sqrt_ac;     /* fp32 [timesteps] sqrt(alphas_cumprod)                                                      */
+  const float* sqrt_1mac;   /* fp32 [timesteps] sqrt(1 - alphas_cumprod)                                                  */
+  const float* snr_weight;  /* fp32 [B]: min(snr_t, 5) / snr_t (:1565-1569)                                               */
+  float beta0;
+  int32_t B, T;
+  int32_t n_units;          /* number of non-pad units (the LS-CE divisor, :1594)                                         */
+  int32_t n_frames;         /* number of valid frames (the masked recon MSE counts n_frames * dim_feat elements)          */
+  int32_t timesteps, multitask;
+  float label_smoothing;    /* 0.1 */
+  float recon_weight;       /* 50  */
+  float loss_scale;
+  float* stats;             /* fp32 [8] out: total_loss, nll_loss, recon_mse_loss, noise_loss, acc, n_units, 0, 0          */
+  float* eps_out;           /* optional fp32 [B, T, latent]: the predicted noise                                          */
+} DnEpsTrainBatch;
+
+int dn_eps_train_create(const DnEpsConfig* cfg, DnEpsTrain** out);
+void dn_eps_train_destroy(DnEpsTrain* m);
+int64_t dn_eps_train_param_count(const DnEpsTrain* m);
+size_t dn_eps_train_aux_bytes(const DnEpsTrain* m);
+int dn_eps_train_offsets(const DnEpsTrain* m, int64_t* offsets, int32_t capacity);  /* 21 + 8 * depth entries */
+int dn_eps_train_stage_range(const DnEpsTrain* m, int32_t stage, int64_t* offset, int64_t* count);
+/* pos_table: fp32 [max_pos + 1, padk(dim)] sinusoidal table (row 0 zeros), a constant of the model                      */
+int dn_eps_train_bind(DnEpsTrain* m, float* master, void* work, void* aux, float* grads, const float* pos_table);
+int dn_eps_train_refresh(DnEpsTrain* m, void* stream);
+size_t dn_eps_train_workspace_bytes(const DnEpsTrain* m, const DnVaeTrain* vae, int32_t B, int32_t T);
+int dn_eps_train_forward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch* batch, void* workspace, size_t workspace_bytes, void* stream);
+/* stages: 0 = loss gradients + frozen VAE decoder + final_proj + to_pred, 1 .. depth = transformer layers depth-1 .. 0,
+ * depth+1 = WaveNet + init_conv, depth+2 = the conditioning path                                                         */
+int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch* batch, int32_t first_stage, int32_t last_stage,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 const char* dn_last_error(void);
 int dn_version(void);

@@ -64,6 +64,9 @@ def test_struct_layout_matches_header(lib, tmp_path):
                                                       "pred_xstart", "vb", "reverse_sample", "N", "inner", "learned_range", "clip_denoised"]),
         "DnVaeTrainBatch": (_lib.VaeTrainBatch, ["feat", "units", "lengths", "noise", "B", "T", "ntokens", "w_lsce", "w_mse", "w_kl",
                                                  "label_smoothing", "loss_scale", "stats", "logits_out", "recon_out", "ext_dlogits"]),
+        "DnEpsTrainBatch": (_lib.EpsTrainBatch, ["feat", "units", "lengths", "z", "jitter", "true_noise", "times", "sqrt_ac", "sqrt_1mac",
+                                                 "snr_weight", "beta0", "B", "T", "n_units", "n_frames", "timesteps", "multitask",
+                                                 "label_smoothing", "recon_weight", "loss_scale", "stats", "eps_out"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
                                          "dtype", "max_pos"]),
         "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",

@@ -226,3 +226,70 @@ def test_cascaded_vae_gradients_vs_oracle_autograd():
     for k in want:
         err = float((got[k].double() - want[k].double()).norm())
         assert err <= 1e-3 * float(want[k].double().norm()) + 1e-6 * tot, (k, err)
+
+
+def _eps_setup(dtype):
+    from diffnorm_amd import training
+    from gen_golden_configs import CHAIN_EPS
+
+    vsd = O.make_vae_state_dict(CFG, "train")
+    esd = O.make_eps_state_dict(CHAIN_EPS, "train")
+    vae = training.VaeTrainEngine(vsd, dim=CFG.dim, latent_dim=CFG.latent_dim, dtype=dtype, device=DEV, depth=CFG.depth, heads=CFG.heads,
+                                  dim_head=CFG.dim_head, stacks=CFG.stacks, layers=CFG.layers)
+    eps = training.EpsTrainEngine(esd, CHAIN_EPS, vae, timesteps=200, dtype=dtype, device=DEV)
+    return eps, vae, esd, vsd, CHAIN_EPS
+
+
+def test_diffusion_loss_and_gradients_match_reference_f32(golden):
+    """LatentDiscreteModel.forward (multitask) on the HIP diffusion training engine against the REAL reference's loss dict and
+    autograd gradients of every eps-predictor parameter (tests/golden/eps_train.npz; the VAE is frozen)."""
+    g = golden("eps_train")
+    eps, vae, esd, vsd, ecfg = _eps_setup("f32")
+    feat = seeded((3, 48, CFG.dim), 31)
+    lens, units = torch.from_numpy(g["lens"]), torch.from_numpy(g["units"])
+    T = lambda k: torch.from_numpy(g[k])
+    z = O.vae_encode(vsd, CFG, feat, T("post_noise"))  # the frozen encoder's posterior sample (its parity: test_hip_engine)
+    assert torch.equal(eps.state_dict()["wavenet.stacks.1.blocks.2.to_time_cond.weight"], esd["wavenet.stacks.1.blocks.2.to_time_cond.weight"])
+    stats = eps.forward(feat, units, lens, z, T("times"), T("jitter"), T("true_noise"))
+    vae.zero_grad()
+    eps.zero_grad()
+    eps.backward()
+    s = stats.cpu().double().numpy()
+    for i, k in enumerate(("total_loss", "nll_loss", "recon_mse_loss", "noise_loss", "acc")):
+        ref = float(g["loss_" + k])
+        assert abs(s[i] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, s[i], ref)
+    assert float(vae.grads.abs().max()) == 0.0  # frozen
+    worst = TO.compare_grads(eps.grad_dict(), g, "g/", rtol=1e-3)
+    print("diffusion training: worst relative gradient error vs the reference:", worst)
+    # staged == whole, and every stage completes its range
+    whole = eps.grads.clone()
+    eps.forward(feat, units, lens, z, T("times"), T("jitter"), T("true_noise"))
+    eps.zero_grad()
+    for st in range(eps.n_stages):
+        eps.backward(st, st)
+        off, cnt = eps.stage_ranges()[st]
+        assert torch.equal(eps.grads[off: off + cnt], whole[off: off + cnt]), st
+    assert sum(c for _, c in eps.stage_ranges()) == eps.n_params
+
+
+def test_diffusion_gradients_bf16_follow_the_oracle(golden):
+    g = golden("eps_train")
+    eps, vae, esd, vsd, ecfg = _eps_setup("bf16")
+    feat = seeded((3, 48, CFG.dim), 31)
+    lens, units = torch.from_numpy(g["lens"]), torch.from_numpy(g["units"])
+    mask = O.lengths_to_mask(lens, 48)
+    T = lambda k: torch.from_numpy(g[k])
+    z = O.vae_encode(vsd, CFG, feat, T("post_noise"))
+    stats = eps.forward(feat, units, lens, z, T("times"), T("jitter"), T("true_noise"))
+    eps.zero_grad()
+    eps.backward()
+    for i, k in enumerate(("total_loss", "nll_loss", "recon_mse_loss", "noise_loss")):
+        ref = float(g["loss_" + k])
+        assert abs(float(stats[i]) - ref) <= 2e-2 * max(1.0, abs(ref)), (k, float(stats[i]), ref)
+    _, want = TO.eps_loss_and_grads(esd, ecfg, vsd, CFG, 200, feat, units, mask, T("times"), T("post_noise"), T("jitter"), T("true_noise"))
+    got = eps.grad_dict()
+    dot = sum((got[k].double() * want[k].double()).sum() for k in want)
+    n1 = torch.sqrt(sum(got[k].double().pow(2).sum() for k in want))
+    n2 = torch.sqrt(sum(want[k].double().pow(2).sum() for k in want))
+    print("bf16 diffusion gradient: cosine", float(dot / (n1 * n2)), "norm ratio", float(n1 / n2))
+    assert dot / (n1 * n2) > 0.995 and abs(float(n1 / n2) - 1) < 5e-2
