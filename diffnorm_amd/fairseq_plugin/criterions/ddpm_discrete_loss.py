@@ -15,6 +15,7 @@ class DDPMDiscreteLoss(FairseqCriterion):
     def forward(self, model, sample, reduction="mean"):
         model_kwargs = dict(src_feature=sample["net_input"]["src_tokens"], src_lengths=sample["net_input"]["src_lengths"],
                             tgt_lengths=sample["reduce_target_lengths"], unk_token=self.task.tgt_dict.unk_index)
+        model_kwargs.update(sample.get("diffusion_draws") or {})  # parity runs inject t and the three noise tensors the reference draws
         d = model(sample["reduce_target"], sample["reduce_target_unit"], **model_kwargs)
         loss = d["total_loss"]
         sample_size = sample["nsentences"]

@@ -38,8 +38,9 @@ class DiffDiscreteModel(FairseqEncoderModel):
         src = model_kwargs.get("src_feature")
         src_mask = lengths_to_mask(model_kwargs["src_lengths"]) if model_kwargs.get("src_lengths") is not None else None
         tgt_mask = lengths_to_mask(model_kwargs["tgt_lengths"], T)
+        draws = {k: model_kwargs[k] for k in ("times", "post_noise", "jitter_noise", "true_noise") if model_kwargs.get(k) is not None}
         return self.encoder(target_feature, target_unit, src_feature=src, src_mask=src_mask, tgt_mask=tgt_mask,
-                            unk_token=model_kwargs.get("unk_token"))
+                            unk_token=model_kwargs.get("unk_token"), **draws)
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
         logits = net_output[0]

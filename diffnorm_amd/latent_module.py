@@ -104,7 +104,47 @@ class Model(_ParamTree):
         self._adopt(synthetic.random_eps_state_dict(self.cfg, seed))
         self._attach("pos_embed._float_tensor", torch.zeros(1), buffer=True)  # key present upstream (:774-779)
 
+    # ---- training: set by LatentDiscreteModel.enable_training -- the flat master buffer of the diffusion
+    # training engine becomes this module's only parameter; state_dict() keeps the reference's keys
+    _train_engine = None
+
+    def _adopt_flat(self, eng):
+        for name in list(self._modules):
+            del self._modules[name]
+        self._buffers.clear()
+        self.flat_params = nn.Parameter(eng.master)
+        self.flat_params.grad = eng.grads
+        self._train_engine = eng
+        self._engine = None
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if self._train_engine is None:
+            return super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        from collections import OrderedDict
+
+        out = OrderedDict() if destination is None else destination
+        for k, v in self._train_engine.state_dict().items():
+            out[prefix + k] = v
+        out[prefix + "pos_embed._float_tensor"] = torch.zeros(1)
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self._train_engine is None:
+            return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        want = set(self._train_engine.state_dict())
+        got = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix) and not k.endswith("pos_embed._float_tensor")}
+        missing_keys += [prefix + k for k in want - set(got)]
+        unexpected_keys += [prefix + k for k in set(got) - want]
+        if not (want - set(got)):
+            self._train_engine.load_state_dict({k: got[k] for k in want})
+
     def engine(self) -> engine.EpsEngine:
+        if self._train_engine is not None:
+            key = ("train", self._train_engine.update_count)
+            if self._engine is None or self._engine_key != key:
+                self._engine = engine.EpsEngine(self._train_engine.state_dict(), self.cfg, dtype=self.arith, device=self.device)
+                self._engine_key = key
+            return self._engine
         key = self._state_key()
         if self._engine is None or self._engine_key != key:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items() if not k.startswith("pos_embed")}
@@ -151,6 +191,26 @@ class _VaeStepFn(torch.autograd.Function):
             ext = g_logits if g_logits is not None else torch.zeros_like(eng._keep[5])
             eng.backward(ext_dlogits=ext, d_mse=gs[2], d_kl=gs[3])
         return None, None, None, None, None, None, None
+
+
+class _EpsStepFn(torch.autograd.Function):
+    """Autograd node around the HIP diffusion training engine (dn_eps_train_forward / _backward): the loss dict's total_loss is
+    stats[0]; its backward ADDS the eps-predictor's gradients into `flat_params.grad` (nothing is returned for the parameter)."""
+
+    @staticmethod
+    def forward(ctx, flat, owner, feat, units, lengths, z, times, jitter, true_noise):
+        stats = owner._train_engine.forward(feat, units, lengths, z, times, jitter, true_noise)
+        ctx.owner = owner
+        return stats.clone()
+
+    @staticmethod
+    def backward(ctx, g_stats):
+        gs = [float(v) for v in g_stats.tolist()]
+        if any(v != 0.0 for v in gs[1:]) or gs[0] not in (0.0, 1.0):
+            raise NotImplementedError("the HIP diffusion loss is differentiated through total_loss with gradient 1 (no loss scaling)")
+        if gs[0] == 1.0:
+            ctx.owner._train_engine.backward()
+        return (None,) * 9
 
 
 class SpeechVAEEncoderDecoder(_ParamTree):
@@ -301,6 +361,27 @@ class LatentDiscreteModel(nn.Module):
     def max_positions(self):
         return None
 
+    _train_engine = None
+
+    def enable_training(self):
+        """Switches the eps-predictor to the HIP diffusion training engine (diffnorm_amd/training.py::EpsTrainEngine): `self.model`
+        keeps one flat `flat_params` Parameter aliasing the engine's fp32 master buffer (with `.grad` aliasing its gradient
+        buffer); the frozen VAE (diff_discrete.py:79-82) is mirrored into a VaeTrainEngine that only passes data gradients."""
+        if self._train_engine is not None:
+            return self._train_engine
+        from . import training
+
+        vae = self.speech_decoder
+        dev = self.device
+        vsd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+        self._frozen_vae = training.VaeTrainEngine(vsd, dim=vae.dim, latent_dim=vae.latent_dim, dtype=self.model.arith, device=dev)
+        esd = {k: v.detach().cpu() for k, v in self.model.state_dict().items() if not k.startswith("pos_embed")}
+        eng = training.EpsTrainEngine(esd, self.model.cfg, self._frozen_vae, timesteps=self.timesteps, dtype=self.model.arith, device=dev,
+                                      multitask=self.multitask)
+        self.model._adopt_flat(eng)
+        self._train_engine = eng
+        return eng
+
     def _tables(self):
         if self._coef is None or self._coef[0].device != self.device:
             s = self.scheduler
@@ -347,6 +428,16 @@ class LatentDiscreteModel(nn.Module):
         if times is None:
             times = torch.randint(1, self.timesteps, (B,), device=dev)  # never 0 (:1528)
         times = times.to(dev)
+        if self._train_engine is not None:  # HIP training engine: losses and gradients are kernels
+            with torch.no_grad():
+                zt = self.speech_decoder.encode_feature(audio, noise=post_noise).transpose(1, 2).contiguous()
+            jn = torch.randn(zt.shape, device=dev) if jitter_noise is None else jitter_noise
+            tn = torch.randn(zt.shape, device=dev) if true_noise is None else true_noise
+            if torch.is_grad_enabled():
+                st = _EpsStepFn.apply(self.model.flat_params, self, audio, audio_units, lengths, zt, times, jn, tn)
+            else:
+                st = self._train_engine.forward(audio, audio_units, lengths, zt, times, jn, tn)
+            return {"total_loss": st[0], "nll_loss": st[1], "recon_mse_loss": st[2], "noise_loss": st[3], "acc": st[4]}
         t32 = times.to(torch.int32)
         z = self.speech_decoder.encode_feature(audio, noise=post_noise).transpose(1, 2).contiguous()
         jitter_noise = torch.randn(z.shape, device=dev) if jitter_noise is None else jitter_noise.to(dev)

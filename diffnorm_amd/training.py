@@ -440,6 +440,10 @@ class VaeTrainer:
         self.group = group
         self.num_updates = 0
 
+    def _forward(self, sample: dict, noise):
+        return self.engine.forward(sample["reduce_target"], sample["reduce_target_unit"], sample["reduce_target_lengths"], noise=noise,
+                                   ntokens=int(sample["ntokens"]))
+
     def train_step(self, samples: Sequence[dict], noises: Optional[Sequence[torch.Tensor]] = None):
         """samples: the micro-batches of one update (update_freq), each the criterion's sample dict.
         -> (stats [8] of the last micro-batch weighted like the criterion's logging output, grad_norm) as device tensors."""
@@ -447,9 +451,7 @@ class VaeTrainer:
         eng.zero_grad()
         totals = torch.zeros(10, dtype=torch.float32, device=eng.device)  # sum_i nsent_i * stats_i [0:8], nsentences, ntokens
         for k, sample in enumerate(samples):
-            lens = sample["reduce_target_lengths"]
-            stats = eng.forward(sample["reduce_target"], sample["reduce_target_unit"], lens,
-                                noise=None if noises is None else noises[k], ntokens=int(sample["ntokens"]))
+            stats = self._forward(sample, None if noises is None else noises[k])
             nsent = float(sample["nsentences"])
             totals[:8] += stats * nsent
             totals[8] += nsent
@@ -472,3 +474,30 @@ class VaeTrainer:
         self.num_updates += 1
         logged = totals[:8] / totals[8]  # sample-size-weighted means, as reduce_metrics (:97-112)
         return logged, grad_norm
+
+
+class DiffusionTrainer(VaeTrainer):
+    """The same update loop for --task speech_diffusion_discrete --criterion ddpm_discrete_loss (scripts/diffusion/train.sh:
+    lr 1e-4, Adam (0.9, 0.98), clip-norm 2.0, inverse_sqrt): `ldm` is the mirror LatentDiscreteModel; its frozen VAE encodes the
+    features (no gradient), the HIP diffusion engine does the rest.  `noises[k]` (optional) = dict(times, post_noise, jitter_noise,
+    true_noise) injected for micro-batch k; otherwise drawn like the reference (t ~ U{1..T-1}, CPU posterior noise, device noise)."""
+
+    def __init__(self, ldm, lr: float = 1e-4, **kw):
+        self.ldm = ldm
+        super().__init__(ldm.enable_training(), lr=lr, **kw)
+
+    def _forward(self, sample: dict, draws):
+        draws = draws or {}
+        ldm, eng = self.ldm, self.engine
+        feat, lens = sample["reduce_target"], sample["reduce_target_lengths"]
+        B = feat.shape[0]
+        times = draws.get("times")
+        if times is None:
+            times = torch.randint(1, ldm.timesteps, (B,), device=eng.device)
+        with torch.no_grad():
+            z = ldm.speech_decoder.encode_feature(feat, noise=draws.get("post_noise")).transpose(1, 2).contiguous()
+        jn = draws.get("jitter_noise")
+        tn = draws.get("true_noise")
+        jn = torch.randn(z.shape, device=eng.device) if jn is None else jn
+        tn = torch.randn(z.shape, device=eng.device) if tn is None else tn
+        return eng.forward(feat, sample["reduce_target_unit"], lens, z, times, jn, tn)

@@ -293,3 +293,54 @@ def test_diffusion_gradients_bf16_follow_the_oracle(golden):
     n2 = torch.sqrt(sum(want[k].double().pow(2).sum() for k in want))
     print("bf16 diffusion gradient: cosine", float(dot / (n1 * n2)), "norm ratio", float(n1 / n2))
     assert dot / (n1 * n2) > 0.995 and abs(float(n1 / n2) - 1) < 5e-2
+
+
+def test_plugin_diffusion_train_step_matches_reference(golden):
+    """--task speech_diffusion_discrete --criterion ddpm_discrete_loss --arch diff_discrete: task.train_step through the plugin
+    (criterion -> DiffDiscreteModel -> LatentDiscreteModel.forward -> HIP diffusion engine, loss.backward() = the HIP backward)
+    gives the reference's loss dict and gradients; the checkpoint keeps the reference's 516-tensor layout."""
+    import types
+
+    from diffnorm_amd import fairseq_plugin, optim  # noqa: F401
+    from diffnorm_amd.fairseq_plugin import registry
+    from gen_golden_configs import CHAIN_EPS
+
+    g = golden("eps_train")
+    args = types.SimpleNamespace(arch="diff_discrete", criterion="ddpm_discrete_loss", latent_dim=CFG.latent_dim, feature_dim=CFG.dim,
+                                 denoiser_dim=CHAIN_EPS.dim, hip_dtype="f32", multitask=True, diffusion_timesteps=200, speech_decoder_ckpt=None,
+                                 target_code_size=1000, data="")
+    task = registry.TASK_REGISTRY["speech_diffusion_discrete"].setup_task(args)
+    model = task.build_model(args)
+    vsd, esd = O.make_vae_state_dict(CFG, "train"), O.make_eps_state_dict(CHAIN_EPS, "train")
+    full = {"encoder.speech_decoder." + k: v for k, v in vsd.items()}
+    full.update({"encoder.model." + k: v for k, v in esd.items()})
+    full["encoder.model.pos_embed._float_tensor"] = torch.zeros(1)
+    model.load_state_dict(full, strict=True)
+    model.to(DEV)
+    criterion = task.build_criterion(args)
+    eng = model.encoder.enable_training()
+    assert set(model.state_dict()) == set(full)
+    assert [n for n, p in model.named_parameters() if p.requires_grad] == ["encoder.model.flat_params"]
+    feat, units, lens = _batch(g)
+    T = lambda k: torch.from_numpy(g[k])
+    sample = {"net_input": {"src_tokens": feat, "src_lengths": lens}, "reduce_target": feat, "reduce_target_unit": units,
+              "reduce_target_lengths": lens, "ntokens": int(lens.sum()), "nsentences": 3,
+              "diffusion_draws": {"times": T("times"), "post_noise": T("post_noise"), "jitter_noise": T("jitter"), "true_noise": T("true_noise")}}
+    opt = optim.FlatOptimizer(eng, lr=1e-4, betas=(0.9, 0.98))
+    opt.zero_grad()
+    loss, sample_size, log = task.train_step(sample, model, criterion, opt, 0)
+    for k, ref_k in (("loss", "total_loss"), ("nll_loss", "nll_loss"), ("mse_loss", "recon_mse_loss"), ("noise_loss", "noise_loss")):
+        ref = float(g["loss_" + ref_k])
+        assert abs(log[k] - ref) <= 1e-3 * max(1.0, abs(ref)), (k, log[k], ref)
+    TO.compare_grads(eng.grad_dict(), g, "g/", rtol=1e-3)
+    before = model.state_dict()["encoder.model.final_proj.weight"].clone()
+    opt.multiply_grads(1.0 / sample_size)
+    opt.clip_grad_norm(2.0)
+    opt.step()
+    after = model.state_dict()
+    assert not torch.equal(after["encoder.model.final_proj.weight"], before)
+    assert torch.equal(after["encoder.speech_decoder.decoder_lm.weight"].cpu(), vsd["decoder_lm.weight"])  # frozen
+    # sampling still works on the updated weights (the inference engine is rebuilt from the master buffer)
+    mask = O.lengths_to_mask(lens, 48).to(DEV)
+    toks, _, total, _ = model.encoder.ddim_sample(feat.to(DEV), input_mask=mask, ref_units=(units - 4).to(DEV), start_step=3)
+    assert total == int(lens.sum()) and [t.shape[0] for t in toks] == lens.tolist()
