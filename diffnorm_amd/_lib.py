@@ -57,7 +57,7 @@ class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("B", C.c_int32), ("T", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32),
-                ("dtype", C.c_int32), ("pad_", C.c_int32), ("lengths", C.c_void_p),
+                ("dtype", C.c_int32), ("Tk", C.c_int32), ("lengths", C.c_void_p),
                 ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p)]
 
 
@@ -85,7 +85,7 @@ class GaussianMoments(C.Structure):
 
 class EpsConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "latent", "depth", "heads", "dim_head", "wn_layers",
-                                         "wn_stacks", "cond_mult", "dtype", "max_pos")]
+                                         "wn_stacks", "cond_mult", "dtype", "max_pos", "dim_prompt", "num_latents", "resampler_depth")]
 
 
 class VaeConfig(C.Structure):
@@ -177,6 +177,8 @@ SYMBOLS = {
     "dn_eps_destroy": (None, [_vp]),
     "dn_eps_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "dn_eps_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_eps_cond_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "dn_eps_forward_cond": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_vae_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "dn_vae_destroy": (None, [_vp]),
     "dn_vae_workspace_bytes": (_sz, [_vp, _i32, _i32]),

@@ -54,12 +54,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int T = p.T, dh = p.dim_head;
+  const int Tk = p.Tk > 0 ? p.Tk : T;  // cross-attention: the keys are another sequence of Tk rows per batch element
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int dhb = dh * ES;  // valid bytes per head row
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
-  const char* kp = reinterpret_cast<const char*>(p.k) + ((int64_t)b * T * p.ldk + h * dh) * ES;
-  const char* vp = reinterpret_cast<const char*>(p.v) + ((int64_t)b * T * p.ldv + h * dh) * ES;
+  const char* kp = reinterpret_cast<const char*>(p.k) + ((int64_t)b * Tk * p.ldk + h * dh) * ES;
+  const char* vp = reinterpret_cast<const char*>(p.v) + ((int64_t)b * Tk * p.ldv + h * dh) * ES;
 
   // Q fragments (B operand): row = query, chunk = ks*4 + fg
   uint4 qf[2][KS_D];
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   f32x4 acc_l[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const uint4 ones_frag = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 
-  int len = p.lengths ? p.lengths[b] : T;
-  len = len < T ? len : T;
+  int len = p.lengths ? p.lengths[b] : Tk;
+  len = len < Tk ? len : Tk;
   float sc = p.scale * 1.44269504088896340736f;  // work in log2 domain
-  if (len <= 0) {  // every key masked: masked_fill makes all scores equal -> uniform softmax over all T keys
-    len = T;
+  if (len <= 0) {  // every key masked: masked_fill makes all scores equal -> uniform softmax over all Tk keys
+    len = Tk;
     sc = 0.f;
   }
 
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
       const int row = idx / NCH, ch = idx - row * NCH;
       const int key = kv0 + row;
       kreg[S][i] = vreg[S][i] = make_uint4(0, 0, 0, 0);
-      if (idx < KV_TILE * NCH && key < T && ch * 16 < dhb) {
+      if (idx < KV_TILE * NCH && key < Tk && ch * 16 < dhb) {
         kreg[S][i] = *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ldk * ES + ch * 16);
         vreg[S][i] = *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + ch * 16);
       }
@@ -309,7 +310,8 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   DN_CHECK_ARG(pp != nullptr, "dn_attention: null params");
   const DnAttnParams& p = *pp;
   DN_CHECK_ARG(p.q && p.k && p.v && p.out, "dn_attention: null tensor");
-  DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0, "dn_attention: bad shape");
+  DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.Tk >= 0, "dn_attention: bad shape");
+  DN_CHECK_ARG(!(p.lse && p.Tk > 0 && p.Tk != p.T), "dn_attention: the backward pass (lse) covers self-attention only");
   DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_attention: bad dtype");
   const int es = p.dtype == DN_BF16 ? 2 : 4;
   DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);

@@ -92,6 +92,9 @@ struct DnEps {
   int n_cond;  // conditioning columns of a row: 2*padk(dim) per conditioned module
   int n_row;   // row stride of the conditioning table: n_cond, then (split RMSNorm) the depth x (3 hd + 2 padk(inner))
                // columns of beta . W^T for the adaptive norms' consumers
+  // conditional variant (kEpsCondTensors; null when cfg.dim_prompt == 0)
+  const float *tpc_W, *tpc_b, *null_pc, *lat_pos, *rffin_b, *rffout_b, *rnorm_g, *proj_b;
+  const void *null_tok, *proj_W, *rq_W, *rkv_W, *rout_W, *rffin_W, *rffout_W, *cq_W, *ckv_W, *cout_W;
   // hipGraph cache for dn_ddim_loop
   void* graph_exec;
   int graph_B, graph_T;
@@ -106,6 +109,11 @@ struct DnEps {
   int table_B, table_T, table_split, table_rows;
 };
 constexpr int kEpsTensors = 7 + dn::kWavenetTensors + dn::kTransformerTensors + 3;
+// conditional variant (cfg.dim_prompt > 0), appended to the table: tpc_W (fp32 [padn(C)][padk(P)]), tpc_b [C], null_prompt_cond [C],
+// null_prompt_tokens [m][Dp], resampler proj_W [padn(D)][padk(P)], proj_b [Dp], latents + positions fp32 [m][Dp], per resampler layer
+// (stacked) q_W [padn(hd)][Dp], kv_W [padn(2hd)][Dp], out_W [padn(D)][hd], ffin_W [2 ip][Dp] (GEGLU-interleaved), ffin_b [2 ip],
+// ffout_W [padn(D)][ip], ffout_b [Dp], norm gamma [D]; per transformer layer (stacked) cross-attention q_W, kv_W, out_W.
+constexpr int kEpsCondTensors = 18;
 
 struct DnVae {
   DnVaeConfig cfg;

@@ -2,6 +2,7 @@
 // sequences of dn_conv_gemm / dn_attention / pointwise launches on one stream.  Nothing here
 // allocates or synchronises; every intermediate lives in the caller's workspace (bump-allocated by
 // the plan_* functions, which also serve the *_workspace_bytes queries).
+#include <algorithm>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -337,7 +338,11 @@ __global__ void dec_counter_kernel(int32_t* counter) { *counter -= 1; }
 // =========================================================================================== eps
 extern "C" int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights, int32_t n_weights, DnEps** out) {
   DN_CHECK_ARG(cfg && weights && out, "dn_eps_create: null argument");
-  DN_CHECK_ARG(n_weights == kEpsTensors, "dn_eps_create: expected %d packed tensors, got %d", kEpsTensors, n_weights);
+  const bool cond_model = cfg->dim_prompt > 0;
+  const int expect_tensors = kEpsTensors + (cond_model ? kEpsCondTensors : 0);
+  DN_CHECK_ARG(n_weights == expect_tensors, "dn_eps_create: expected %d packed tensors, got %d", expect_tensors, n_weights);
+  DN_CHECK_ARG(!cond_model || (cfg->dim_prompt % 4 == 0 && cfg->num_latents >= 1 && cfg->resampler_depth >= 1),
+               "dn_eps_create: conditional model needs dim_prompt %% 4 == 0, num_latents >= 1, resampler_depth >= 1");
   DN_TRY(check_dims("dn_eps_create", cfg->dtype, cfg->dim, cfg->heads, cfg->dim_head, cfg->wn_layers));
   DN_CHECK_ARG(cfg->dim % 2 == 0 && (cfg->dim * cfg->cond_mult) % 64 == 0, "dn_eps_create: dim*cond_mult must be a multiple of 64");
   DN_CHECK_ARG(cfg->latent % 4 == 0 && cfg->latent > 0, "dn_eps_create: latent=%d must be a multiple of 4", cfg->latent);
@@ -357,8 +362,16 @@ extern "C" int dn_eps_create(const DnEpsConfig* cfg, const void* const* weights,
   t = take_transformer(m->tf, t);
   m->tf.g1 = m->tf.g2 = nullptr;  // time-conditioned norms carry no learned gamma (:662-663)
   m->final_W = t[0]; m->final_b = (const float*)t[1]; m->pos_table = (const float*)t[2];
-  m->n_cond = (cfg->wn_stacks * cfg->wn_layers + 2 * cfg->depth) * 2 * padk(cfg->dim);
+  m->n_cond = (cfg->wn_stacks * cfg->wn_layers + (cond_model ? 3 : 2) * cfg->depth) * 2 * padk(cfg->dim);
   m->n_row = m->n_cond + cfg->depth * (3 * cfg->heads * cfg->dim_head + 2 * padk(m->tf.inner));
+  if (cond_model) {
+    const void* const* c = t + 3;
+    m->tpc_W = (const float*)c[0]; m->tpc_b = (const float*)c[1]; m->null_pc = (const float*)c[2]; m->null_tok = c[3];
+    m->proj_W = c[4]; m->proj_b = (const float*)c[5]; m->lat_pos = (const float*)c[6];
+    m->rq_W = c[7]; m->rkv_W = c[8]; m->rout_W = c[9]; m->rffin_W = c[10]; m->rffin_b = (const float*)c[11];
+    m->rffout_W = c[12]; m->rffout_b = (const float*)c[13]; m->rnorm_g = (const float*)c[14];
+    m->cq_W = c[15]; m->ckv_W = c[16]; m->cout_W = c[17];
+  }
   *out = m;
   return DN_OK;
 }
@@ -469,6 +482,7 @@ __global__ void iota_kernel(int32_t* t, int n) {
 extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
                               int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
   DN_CHECK_ARG(m && x && t && lengths && eps_out && workspace, "dn_eps_forward: null argument");
+  DN_CHECK_ARG(m->cfg.dim_prompt == 0, "dn_eps_forward: this model is conditioned on a prompt: use dn_eps_forward_cond");
   DN_CHECK_ARG(B > 0 && T > 0, "dn_eps_forward: B=%d T=%d", B, T);
   DN_CHECK_ARG(T <= m->cfg.max_pos, "dn_eps_forward: T=%d exceeds the positional table (%d)", T, m->cfg.max_pos);
   DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward: workspace must be 256-byte aligned");
@@ -500,6 +514,7 @@ extern "C" size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, 
 extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
                             const float* coef, int32_t timesteps, int32_t flags, void* workspace, size_t workspace_bytes,
                             void* stream) {
+  DN_CHECK_ARG(m && m->cfg.dim_prompt == 0, "dn_ddim_loop: the device loop covers the unconditional model (prompted chains step through dn_eps_forward_cond)");
   int use_graph = flags & DN_LOOP_GRAPH;
   const bool split = (flags & DN_LOOP_SPLIT2) && B >= 2;
   DN_CHECK_ARG(m && x && lengths && coef && workspace, "dn_ddim_loop: null argument");
@@ -621,6 +636,300 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
     for (; done < n_eval; ++done) DN_TRY(one_step());
   }
   return n_eval;
+}
+
+
+// =========================================================================================== conditional variant (f3)
+namespace dn {
+// pooled[b, c] = mean over ALL Tp positions of the masked prompt (masked_fill(~mask, 0) then Reduce 'b n d -> b d' mean,
+// latent_module.py:844-845, 764); prompt fp32 [B, Tp, P] -> pooled fp32 [B, Pp] (pad columns zero)
+__global__ __launch_bounds__(256) void prompt_pool_kernel(const float* __restrict__ prompt, const int32_t* __restrict__ plen, int B, int Tp, int P,
+                                                          int Pp, float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  const int n = plen[b] < Tp ? plen[b] : Tp;
+  for (int c = threadIdx.x; c < Pp; c += 256) {
+    float s = 0.f;
+    if (c < P)
+      for (int t = 0; t < n; ++t) s += prompt[((int64_t)b * Tp + t) * P + c];
+    pooled[(int64_t)b * Pp + c] = s / (float)Tp;
+  }
+}
+// cond2[b] = [time_cond[b] | (drop[b] ? null_prompt_cond : prompt_cond[b])]  (:846-852)
+__global__ __launch_bounds__(256) void assemble_cond2_kernel(const float* __restrict__ tc, const float* __restrict__ pc, const float* __restrict__ null_pc,
+                                                             const int32_t* __restrict__ drop, int B, int C, float* __restrict__ out) {
+  const int64_t n = (int64_t)B * 2 * C;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / (2 * C)), c = (int)(i - (int64_t)b * 2 * C);
+    out[i] = c < C ? tc[(int64_t)b * C + c] : (drop[b] ? null_pc[c - C] : pc[(int64_t)b * C + c - C]);
+  }
+}
+// dst rows [b, row0 + j] (row stride of a sample: rows_total) <- src rows: sample-indexed [b, j] (src_bstride = rows * ld) or shared
+// (src_bstride = 0); optional per-sample override by `alt` (shared rows) where flag[b] != 0.  fp32 or bf16 sources -> dst dtype.
+__global__ __launch_bounds__(256) void place_rows_kernel(const void* __restrict__ src, int src_dtype, int64_t src_bstride, const void* __restrict__ alt,
+                                                         const int32_t* __restrict__ flag, void* __restrict__ dst, int dst_dtype, int B, int rows,
+                                                         int ld, int rows_total, int row0) {
+  const int64_t n = (int64_t)B * rows * ld;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % ld);
+    const int j = (int)((i / ld) % rows);
+    const int b = (int)(i / ((int64_t)ld * rows));
+    const bool use_alt = alt && flag && flag[b] != 0;
+    const void* sp = use_alt ? alt : src;
+    const int64_t so = (use_alt ? 0 : (int64_t)b * src_bstride) + (int64_t)j * ld + c;
+    const float v = src_dtype == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(sp)[so]) : reinterpret_cast<const float*>(sp)[so];
+    const int64_t o = ((int64_t)b * rows_total + row0 + j) * ld + c;
+    if (dst_dtype == DN_BF16)
+      reinterpret_cast<uint16_t*>(dst)[o] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+    else
+      reinterpret_cast<float*>(dst)[o] = v;
+  }
+}
+__global__ void add_const_i32_kernel(const int32_t* __restrict__ a, int32_t c, int32_t cap, int32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (a[i] < cap ? a[i] : cap) + c;
+}
+}  // namespace dn
+
+namespace {
+
+struct CondBufs {
+  float *cond, *pooled, *pc, *cond2, *gb, *lat, *xres;
+  void *prompt_act, *ctx, *kvsrc, *lat_act, *rq, *rkv, *rao, *rgg, *c_act, *ckv, *xin, *h0, *xn, *qkv, *ao, *cq, *gg, *fc, *tp;
+  int32_t* klen;
+  WaveBufs wv;
+};
+
+CondBufs plan_eps_cond(const DnEps* m, int B, int T, int Tp, Arena& ar) {
+  const DnEpsConfig& c = m->cfg;
+  const int es = esize(c.dtype);
+  const size_t M = (size_t)B * T, Dp = padk(c.dim), zp = padk(c.latent), C = (size_t)c.dim * c.cond_mult, Pp = padk(c.dim_prompt);
+  const size_t hd = (size_t)c.heads * c.dim_head, ip = padk(m->tf.inner), ml = c.num_latents, Lk = ml + Tp;
+  CondBufs b;
+  memset(&b, 0, sizeof(b));
+  b.cond = (float*)ar.take(B * C * 4); b.pooled = (float*)ar.take(B * Pp * 4); b.pc = (float*)ar.take(B * C * 4);
+  b.cond2 = (float*)ar.take(B * 2 * C * 4); b.gb = (float*)ar.take((size_t)B * m->n_cond * 4);
+  b.prompt_act = ar.take((size_t)B * Tp * Pp * es); b.ctx = ar.take((size_t)B * Tp * Dp * es);
+  b.kvsrc = ar.take(B * Lk * Dp * es); b.lat = (float*)ar.take(B * ml * Dp * 4); b.lat_act = ar.take(B * ml * Dp * es);
+  b.rq = ar.take(B * ml * hd * es); b.rkv = ar.take(B * Lk * 2 * hd * es); b.rao = ar.take(B * ml * hd * es);
+  b.rgg = ar.take(B * ml * ip * es); b.c_act = ar.take(B * ml * Dp * es); b.ckv = ar.take((size_t)c.depth * B * ml * 2 * hd * es);
+  b.klen = (int32_t*)ar.take((size_t)B * 4);
+  b.xin = ar.take(M * zp * es); b.h0 = ar.take(M * Dp * es);
+  b.wv = plan_wave(m->wn, (int)M, es, ar);
+  b.xres = (float*)ar.take(M * Dp * 4); b.xn = ar.take(M * Dp * es); b.qkv = ar.take(M * 3 * hd * es); b.ao = ar.take(M * hd * es);
+  b.cq = ar.take(M * hd * es); b.gg = ar.take(M * ip * es); b.fc = ar.take(M * ip * es); b.tp = ar.take(M * Dp * es);
+  return b;
+}
+
+int attn_call(int dtype, const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, int ldo, int B, int T, int Tk, int heads,
+              int dim_head, const int32_t* lengths, hipStream_t s) {
+  DnAttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.ldq = ldq; a.ldk = a.ldv = ldkv; a.ldo = ldo;
+  a.B = B; a.T = T; a.Tk = Tk; a.heads = heads; a.dim_head = dim_head; a.dtype = dtype; a.lengths = lengths;
+  a.scale = 1.0f / sqrtf((float)dim_head);
+  return dn_attention(&a, s);
+}
+
+inline int ew(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 4096); }
+
+}  // namespace
+
+extern "C" size_t dn_eps_cond_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t Tp) {
+  if (!m || m->cfg.dim_prompt <= 0 || B <= 0 || T <= 0 || Tp <= 0) return 0;
+  Arena ar{nullptr, 0, 0};
+  (void)plan_eps_cond(m, B, T, Tp, ar);
+  return ar.off + 256;
+}
+
+extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
+                                   const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && x && t && lengths && prompt && prompt_lengths && drop && eps_out && workspace, "dn_eps_forward_cond: null argument");
+  DN_CHECK_ARG(m->cfg.dim_prompt > 0, "dn_eps_forward_cond: the model was created without a prompt branch (cfg.dim_prompt == 0)");
+  DN_CHECK_ARG(B > 0 && T > 0 && Tp > 0 && T <= m->cfg.max_pos, "dn_eps_forward_cond: B=%d T=%d Tp=%d", B, T, Tp);
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward_cond: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  Arena ar{(char*)workspace, 0, workspace_bytes};
+  const CondBufs b = plan_eps_cond(m, B, T, Tp, ar);
+  if (ar.off > workspace_bytes) {
+    dn_set_error("dn_eps_forward_cond: workspace %zu < required %zu", workspace_bytes, ar.off);
+    return DN_EWORKSPACE;
+  }
+  const DnEpsConfig& c = m->cfg;
+  const int dtype = c.dtype, es = esize(dtype), M = B * T;
+  const int D = c.dim, Dp = padk(D), Dn = padn(D), z = c.latent, zp = padk(z), C = D * c.cond_mult, P = c.dim_prompt, Pp = padk(P);
+  const int hd = c.heads * c.dim_head, ip = padk(m->tf.inner), in_n = padn(m->tf.inner), ml = c.num_latents, Lk = ml + Tp, R = c.resampler_depth;
+  // ---- conditioning rows: [time cond | pooled-prompt cond] -> FiLM / adaptive-norm [gamma ; beta] (:841-852), fp32
+  DN_TRY(dn_time_cond(t, B, m->w_freq, D / 2, m->tc_W, m->tc_b, C, b.cond, nullptr, DN_F32, C, s));
+  hipLaunchKernelGGL(dn::prompt_pool_kernel, dim3(B), dim3(256), 0, s, prompt, prompt_lengths, B, Tp, P, Pp, b.pooled);
+  {  // to_prompt_cond: Linear(P -> C) + SiLU (:760-764)
+    DnGemmParams p = gemm_base(DN_F32, B, C, Pp, 1);
+    p.terms[0].A = b.pooled; p.terms[0].lda = Pp; p.terms[0].W = m->tpc_W;
+    p.bias = m->tpc_b; p.epilogue = DN_EPI_SILU; p.out = b.pc; p.ldo = C; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  hipLaunchKernelGGL(dn::assemble_cond2_kernel, dim3(ew((int64_t)B * 2 * C)), dim3(256), 0, s, b.cond, b.pc, m->null_pc, drop, B, C, b.cond2);
+  {
+    DnGemmParams p = gemm_base(DN_F32, B, m->n_cond, 2 * C, 1);
+    p.terms[0].A = b.cond2; p.terms[0].lda = 2 * C; p.terms[0].W = m->cond_W;
+    p.bias = m->cond_b; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  // ---- PerceiverResampler (:416-471): prompt -> ml latents per sample
+  DN_TRY(dn_convert_rows(prompt, DN_F32, P, b.prompt_act, dtype, Pp, B * Tp, P, s));
+  {  // proj_context
+    DnGemmParams p = gemm_base(dtype, B * Tp, Dp, Pp, Tp);
+    p.terms[0].A = b.prompt_act; p.terms[0].lda = Pp; p.terms[0].W = m->proj_W;
+    p.bias = m->proj_b; p.out = b.ctx; p.ldo = Dp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  // keys/values of every resampler layer = [latents ; projected prompt]: the prompt rows are placed once
+  hipLaunchKernelGGL(dn::place_rows_kernel, dim3(ew((int64_t)B * Tp * Dp)), dim3(256), 0, s, b.ctx, dtype, (int64_t)Tp * Dp, nullptr, nullptr, b.kvsrc,
+                     dtype, B, Tp, Dp, Lk, ml);
+  hipLaunchKernelGGL(dn::place_rows_kernel, dim3(ew((int64_t)B * ml * Dp)), dim3(256), 0, s, m->lat_pos, DN_F32, (int64_t)0, nullptr, nullptr, b.lat,
+                     DN_F32, B, ml, Dp, ml, 0);
+  hipLaunchKernelGGL(dn::add_const_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, prompt_lengths, ml, Tp, b.klen, B);  // mask = [ones(ml) ; prompt_mask]
+  for (int l = 0; l < R; ++l) {
+    DN_TRY(dn_convert_rows(b.lat, DN_F32, Dp, b.lat_act, dtype, Dp, B * ml, Dp, s));
+    hipLaunchKernelGGL(dn::place_rows_kernel, dim3(ew((int64_t)B * ml * Dp)), dim3(256), 0, s, b.lat_act, dtype, (int64_t)ml * Dp, nullptr, nullptr,
+                       b.kvsrc, dtype, B, ml, Dp, Lk, 0);
+    {
+      DnGemmParams p = gemm_base(dtype, B * ml, hd, Dp, ml);
+      p.terms[0].A = b.lat_act; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->rq_W, (size_t)l * padn(hd) * Dp, es);
+      p.out = b.rq; p.ldo = hd;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      DnGemmParams p = gemm_base(dtype, B * Lk, 2 * hd, Dp, Lk);
+      p.terms[0].A = b.kvsrc; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->rkv_W, (size_t)l * padn(2 * hd) * Dp, es);
+      p.out = b.rkv; p.ldo = 2 * hd;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    DN_TRY(attn_call(dtype, b.rq, hd, b.rkv, eoff(b.rkv, hd, es), 2 * hd, b.rao, hd, B, ml, Lk, c.heads, c.dim_head, b.klen, s));
+    {
+      DnGemmParams p = gemm_base(dtype, B * ml, Dp, hd, ml);
+      p.terms[0].A = b.rao; p.terms[0].lda = hd; p.terms[0].W = eoff(m->rout_W, (size_t)l * Dn * hd, es);
+      p.epilogue = DN_EPI_RESADD; p.res = b.lat; p.ldr = Dp; p.out = b.lat; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    DN_TRY(dn_convert_rows(b.lat, DN_F32, Dp, b.lat_act, dtype, Dp, B * ml, Dp, s));
+    {  // FeedForward without the causal conv: Linear -> GEGLU -> Linear (:887-903)
+      DnGemmParams p = gemm_base(dtype, B * ml, ip, Dp, ml);
+      p.terms[0].A = b.lat_act; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->rffin_W, (size_t)l * 2 * ip * Dp, es);
+      p.bias = m->rffin_b + (size_t)l * 2 * ip; p.epilogue = DN_EPI_GEGLU; p.out = b.rgg; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      DnGemmParams p = gemm_base(dtype, B * ml, Dp, ip, ml);
+      p.terms[0].A = b.rgg; p.terms[0].lda = ip; p.terms[0].W = eoff(m->rffout_W, (size_t)l * Dn * ip, es);
+      p.bias = m->rffout_b + (size_t)l * Dp;
+      p.epilogue = DN_EPI_RESADD; p.res = b.lat; p.ldr = Dp; p.out = b.lat; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+  }
+  DN_TRY(dn_rmsnorm(b.lat, Dp, b.lat_act, Dp, dtype, B * ml, D, ml, m->rnorm_g, nullptr, 0, 0, s));
+  // c = where(drop, null_prompt_tokens, resampled) (:855-859)
+  hipLaunchKernelGGL(dn::place_rows_kernel, dim3(ew((int64_t)B * ml * Dp)), dim3(256), 0, s, b.lat_act, dtype, (int64_t)ml * Dp, m->null_tok, drop, b.c_act,
+                     dtype, B, ml, Dp, ml, 0);
+  {  // keys / values of all cross-attention layers at once (they depend on the prompt only)
+    DnGemmParams p = gemm_base(dtype, B * ml, 2 * hd, Dp, ml);
+    p.groups = c.depth;
+    p.terms[0].A = b.c_act; p.terms[0].lda = Dp; p.terms[0].a_gstride = 0;
+    p.terms[0].W = m->ckv_W; p.terms[0].w_gstride = (int64_t)padn(2 * hd) * Dp;
+    p.out = b.ckv; p.ldo = 2 * hd; p.out_gstride = (int64_t)B * ml * 2 * hd;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  // ---- the eps-predictor proper (:861-876)
+  DN_TRY(dn_convert_rows(x, DN_F32, z, b.xin, dtype, zp, M, z, s));
+  {
+    DnGemmParams p = gemm_base(dtype, M, Dp, zp, T);
+    p.terms[0].A = b.xin; p.terms[0].lda = zp; p.terms[0].W = m->init_W;
+    p.bias = m->init_b; p.out = b.h0; p.ldo = Dp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  {
+    DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
+    fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
+    fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, b.gb, m->n_cond, b.wv, fin, s));
+  }
+  const TransformerW& w = m->tf;
+  const float* gb_tf = b.gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
+  auto norm = [&](int l, int j) -> int {  // j = 0 attention, 1 cross-attention, 2 feed-forward
+    return dn_rmsnorm(b.xres, Dp, b.xn, Dp, dtype, M, D, T, nullptr, gb_tf + (size_t)(3 * l + j) * 2 * Dp, m->n_cond, Dp, s);
+  };
+  for (int l = 0; l < w.depth; ++l) {
+    DN_TRY(norm(l, 0));
+    {
+      DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
+      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
+      p.out = b.qkv; p.ldo = 3 * hd;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    DN_TRY(attn_call(dtype, b.qkv, 3 * hd, eoff(b.qkv, hd, es), eoff(b.qkv, 2 * hd, es), 3 * hd, b.ao, hd, B, T, 0, c.heads, c.dim_head, lengths, s));
+    {
+      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
+      p.terms[0].A = b.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
+      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    // cross-attention to the resampled prompt latents, no mask (:694-700)
+    DN_TRY(norm(l, 1));
+    {
+      DnGemmParams p = gemm_base(dtype, M, hd, Dp, T);
+      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->cq_W, (size_t)l * padn(hd) * Dp, es);
+      p.out = b.cq; p.ldo = hd;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      const void* kv = eoff(b.ckv, (size_t)l * B * ml * 2 * hd, es);
+      DN_TRY(attn_call(dtype, b.cq, hd, kv, eoff(kv, hd, es), 2 * hd, b.ao, hd, B, T, ml, c.heads, c.dim_head, nullptr, s));
+    }
+    {
+      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
+      p.terms[0].A = b.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(m->cout_W, (size_t)l * Dn * hd, es);
+      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    DN_TRY(norm(l, 2));
+    {
+      DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
+      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
+      p.bias = w.ffin_b + (size_t)l * 2 * ip; p.epilogue = DN_EPI_GEGLU; p.out = b.gg; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
+      p.n_terms = 3;
+      for (int j = 0; j < 3; ++j) {
+        p.terms[j].A = b.gg; p.terms[j].lda = ip; p.terms[j].shift = 2 - j;
+        p.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
+      }
+      p.bias = w.ffconv_b + (size_t)l * ip; p.out = b.fc; p.ldo = ip;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+    {
+      DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
+      p.terms[0].A = b.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
+      p.bias = w.ffout_b + (size_t)l * Dp;
+      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
+      DN_TRY(dn_conv_gemm(&p, s));
+    }
+  }
+  DN_TRY(dn_rmsnorm(b.xres, Dp, b.xn, Dp, dtype, M, D, T, w.pred_gamma, nullptr, 0, 0, s));
+  {
+    DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
+    p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = w.pred_W;
+    p.out = b.tp; p.ldo = Dp;
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
+  p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
+  p.bias = m->final_b; p.out = eps_out; p.ldo = z; p.out_dtype = DN_F32;
+  DN_TRY(dn_conv_gemm(&p, s));
+  DN_CHECK_LAUNCH("dn_eps_forward_cond");
+  return DN_OK;
 }
 
 // =========================================================================================== VAE

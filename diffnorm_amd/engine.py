@@ -67,8 +67,11 @@ class EpsEngine(_Engine):
         self.cfg = cfg
         self.dtype = _dtype_code(dtype)
         super().__init__(device, packing.pack_eps(state_dict, cfg, self.dtype, max_pos))
+        self.conditional = getattr(cfg, "dim_prompt", 0) > 0
         c = _lib.EpsConfig(cfg.dim, cfg.latent_dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.wavenet_layers,
-                           cfg.wavenet_stacks, cfg.dim_cond_mult, self.dtype, max_pos)
+                           cfg.wavenet_stacks, cfg.dim_cond_mult, self.dtype, max_pos, getattr(cfg, "dim_prompt", 0),
+                           getattr(cfg, "num_latents_m", 0) if self.conditional else 0,
+                           getattr(cfg, "resampler_depth", 0) if self.conditional else 0)
         _lib.check(self.lib.dn_eps_create(C.byref(c), self._table, len(self.tensors), C.byref(self.handle)),
                    "dn_eps_create")
 
@@ -95,6 +98,33 @@ class EpsEngine(_Engine):
                                                int(shared_t), out.data_ptr(), wp, wn, _lib.current_stream()),
                        "dn_eps_forward")
         return out
+
+    def forward_cond(self, x: torch.Tensor, times: torch.Tensor, lengths: torch.Tensor, prompt: torch.Tensor, prompt_lengths: torch.Tensor,
+                     drop: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Conditional variant (reference Model.forward with condition_on_prompt, latent_module.py:828-876): prompt [B,Tp,dim_prompt],
+        prompt_lengths [B]; drop [B] bool = the classifier-free-guidance drop mask (True: null condition)."""
+        B, T, z = x.shape
+        Tp = prompt.shape[1]
+        x, prompt = _f32(x, self.device), _f32(prompt, self.device)
+        t32, l32, p32 = _i32(times, self.device), _i32(lengths, self.device), _i32(prompt_lengths, self.device)
+        d32 = torch.zeros(B, dtype=torch.int32, device=self.device) if drop is None else _i32(drop, self.device)
+        out = torch.empty_like(x) if out is None else out
+        ws = self._workspace(int(self.lib.dn_eps_cond_workspace_bytes(self.handle, B, T, Tp)))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_eps_forward_cond(self.handle, x.data_ptr(), t32.data_ptr(), l32.data_ptr(), prompt.data_ptr(), p32.data_ptr(),
+                                                    d32.data_ptr(), B, T, Tp, out.data_ptr(), wp, wn, _lib.current_stream()),
+                       "dn_eps_forward_cond")
+        return out
+
+    def forward_with_cond_scale(self, x, times, lengths, prompt, prompt_lengths, cond_scale: float = 1.0) -> torch.Tensor:
+        """Classifier-free guidance (latent_module.py:813-826): null + (cond - null) * cond_scale; one pass when the scale is 1."""
+        B = x.shape[0]
+        cond = self.forward_cond(x, times, lengths, prompt, prompt_lengths, torch.zeros(B, dtype=torch.bool))
+        if cond_scale == 1.0:
+            return cond
+        null = self.forward_cond(x, times, lengths, prompt, prompt_lengths, torch.ones(B, dtype=torch.bool))
+        return torch.add(null, cond - null, alpha=cond_scale)
 
     def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
                   use_graph: bool = True, max_evals: int = 0, split: bool = True, keep_table: bool = False) -> int:

@@ -143,14 +143,17 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
 
 
 def pack_eps(sd: SD, cfg, dtype: int, max_pos: int = 2048) -> List[torch.Tensor]:
-    """cfg: object with dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult."""
+    """cfg: object with dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult [, dim_prompt,
+    num_latents_m, resampler_depth: the conditional variant, whose extra tensors (csrc/engine.h kEpsCondTensors) follow the table]."""
     D, Dp = cfg.dim, padk(cfg.dim)
     C = D * cfg.dim_cond_mult
+    cond = getattr(cfg, "dim_prompt", 0) > 0
+    C2 = 2 * C if cond else C  # [time cond | pooled-prompt cond] (reference latent_module.py:784, 852)
     cond_rows, cond_b = [], []
 
     def add_cond(wname, bname):
-        w, b = sd[wname].float(), sd[bname].float()  # [2D, C]: [gamma ; beta]
-        blk = torch.zeros(2 * Dp, C)
+        w, b = sd[wname].float(), sd[bname].float()  # [2D, C2]: [gamma ; beta]
+        blk = torch.zeros(2 * Dp, C2)
         bb = torch.zeros(2 * Dp)
         blk[:D], blk[Dp:Dp + D] = w[:D], w[D:]
         bb[:D], bb[Dp:Dp + D] = b[:D], b[D:]
@@ -162,7 +165,7 @@ def pack_eps(sd: SD, cfg, dtype: int, max_pos: int = 2048) -> List[torch.Tensor]
             p = f"wavenet.stacks.{s}.blocks.{i}.to_time_cond."
             add_cond(p + "weight", p + "bias")
     for l in range(cfg.depth):
-        for j in (0, 4):
+        for j in ((0, 2, 4) if cond else (0, 4)):  # attention norm, [cross-attention norm,] feed-forward norm
             p = f"transformer.layers.{l}.{j}.to_gamma_beta."
             add_cond(p + "weight", p + "bias")
     cond_W = _mat(torch.cat(cond_rows, dim=0), _lib.DN_F32)  # conditioning stays fp32 in every mode
@@ -181,7 +184,49 @@ def pack_eps(sd: SD, cfg, dtype: int, max_pos: int = 2048) -> List[torch.Tensor]
         _mat(sd["final_proj.weight"], dtype), _vec(sd["final_proj.bias"], padk(cfg.latent_dim)),
         sinusoidal_table(max_pos + 1, D, Dp),
     ]
+    if cond:
+        tensors += pack_eps_cond(sd, cfg, dtype)
     return tensors
+
+
+def pack_eps_cond(sd: SD, cfg, dtype: int) -> List[torch.Tensor]:
+    """Extra tensors of the conditional variant in csrc/engine.h's kEpsCondTensors order (reference latent_module.py:416-471,
+    752-773): prompt-condition MLP and null condition (fp32), null prompt tokens, the PerceiverResampler (latents with their
+    sinusoidal positions 1..m folded in: a constant), and the transformer layers' cross-attention projections."""
+    D, Dp, Dn = cfg.dim, padk(cfg.dim), padn(cfg.dim)
+    C, P, m, R = D * cfg.dim_cond_mult, cfg.dim_prompt, cfg.num_latents_m, cfg.resampler_depth
+    inner = int(D * 4 * 2 / 3)
+    ip, hd = padk(inner), cfg.heads * cfg.dim_head
+    rows = _geglu_rows(inner)
+    keep = rows >= 0
+    r = "perceiver_resampler."
+    pad_rows = lambda t: torch.cat([t, torch.zeros(t.shape[0], Dp - t.shape[1])], dim=1)
+    lat_pos = pad_rows(sd[r + "latents"].float() + sinusoidal_table(m + 1, D, D)[1:m + 1])
+    rq, rkv, rout, rffin, rffin_b, rffout, rffout_b = ([] for _ in range(7))
+    for l in range(R):
+        a = f"{r}layers.{l}.0."
+        f = f"{r}layers.{l}.1."
+        rq.append(_mat(sd[a + "to_q.weight"], dtype))
+        rkv.append(_mat(sd[a + "to_kv.weight"], dtype))
+        rout.append(_mat(sd[a + "to_out.weight"], dtype))
+        w, b = sd[f + "0.weight"].float(), sd[f + "0.bias"].float()
+        wp, bp = torch.zeros(2 * ip, Dp), torch.zeros(2 * ip)
+        wp[keep, :D], bp[keep] = w[rows[keep]], b[rows[keep]]
+        rffin.append(wp.to(_act_dtype(dtype)))
+        rffin_b.append(bp)
+        rffout.append(_mat(sd[f + "2.weight"], dtype))
+        rffout_b.append(_vec(sd[f + "2.bias"], Dp))
+    t = "transformer.layers."
+    return [
+        _mat(sd["to_prompt_cond.1.weight"], _lib.DN_F32), sd["to_prompt_cond.1.bias"].float().clone(), sd["null_prompt_cond"].float().clone(),
+        pad_rows(sd["null_prompt_tokens"].float()).to(_act_dtype(dtype)),
+        _mat(sd[r + "proj_context.weight"], dtype), _vec(sd[r + "proj_context.bias"], Dp), lat_pos,
+        torch.stack(rq), torch.stack(rkv), torch.stack(rout), torch.stack(rffin), torch.stack(rffin_b), torch.stack(rffout),
+        torch.stack(rffout_b), sd[r + "norm.gamma"].float().clone(),
+        torch.stack([_mat(sd[f"{t}{l}.3.to_q.weight"], dtype) for l in range(cfg.depth)]),
+        torch.stack([_mat(sd[f"{t}{l}.3.to_kv.weight"], dtype) for l in range(cfg.depth)]),
+        torch.stack([_mat(sd[f"{t}{l}.3.to_out.weight"], dtype) for l in range(cfg.depth)]),
+    ]
 
 
 def vae_mults(latent_flag: int) -> List[int]:

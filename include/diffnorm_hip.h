@@ -162,7 +162,8 @@ typedef struct {
   int32_t ldq, ldk, ldv, ldo;
   int32_t B, T, heads, dim_head;
   int32_t dtype;      /* element type of q,k,v,out                                                 */
-  int32_t pad_;
+  int32_t Tk;         /* keys per sequence when they are not the queries' frames (cross-attention, latent_module.py:935-943:
+                         k / v row = b*Tk + j); 0 = T (self-attention).  lengths then count valid KEYS (<= Tk)       */
   const int32_t* lengths; /* [B] or NULL (no mask)                                                  */
   float scale;        /* dim_head ** -0.5                                                           */
   int32_t pad2_;
@@ -402,6 +403,8 @@ typedef struct {
   int32_t dim, latent, depth, heads, dim_head, wn_layers, wn_stacks, cond_mult;
   int32_t dtype;  /* DN_F32 | DN_BF16 */
   int32_t max_pos; /* rows in the positional table minus 1 */
+  /* conditional variant (use_cond=True, latent_module.py:752-773): 0 = the unconditional model of the recipe */
+  int32_t dim_prompt, num_latents, resampler_depth;
 } DnEpsConfig;
 
 typedef struct {
@@ -423,6 +426,16 @@ size_t dn_eps_workspace_bytes(const DnEps* m, int32_t B, int32_t T);
  * projections run for one row.                                                                     */
 int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, int32_t B, int32_t T,
                    int32_t shared_t, float* eps_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Conditional variant (Model.forward with condition_on_prompt, latent_module.py:828-876, PerceiverResampler :416-471,
+ * classifier-free guidance :813-826): prompt fp32 [B, Tp, dim_prompt] with prompt_lengths [B]; drop int32 [B] = the guidance drop
+ * mask (1: the sample runs on null_prompt_cond / null_prompt_tokens).  The pooled-prompt condition is concatenated to the time
+ * condition (2x conditioning width), the resampled prompt latents feed a cross-attention block in every transformer layer.
+ * Needs a model created with cfg.dim_prompt > 0 (packed table: diffnorm_amd/packing.py::pack_eps).                        */
+size_t dn_eps_cond_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t Tp);
+int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
+                        const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 int dn_vae_create(const DnVaeConfig* cfg, const void* const* weights, int32_t n_weights, DnVae** out);
 void dn_vae_destroy(DnVae* m);

@@ -45,6 +45,10 @@ class EpsConfig:
     wavenet_layers: int = 8
     wavenet_stacks: int = 4
     dim_cond_mult: int = 4
+    # conditional variant (use_cond=True; latent_module.py:709-728, 752-773): 0 = unconditional
+    dim_prompt: int = 0
+    num_latents_m: int = 64
+    resampler_depth: int = 2
 
 
 @dataclass
@@ -195,19 +199,23 @@ def rms_norm(x: Tensor, gamma: Optional[Tensor] = None, cond_wb=None, cond: Opti
     return out
 
 
-def attention(sd: SD, x: Tensor, mask: Optional[Tensor], heads: int) -> Tensor:
+def attention(sd: SD, x: Tensor, mask: Optional[Tensor], heads: int, context: Optional[Tensor] = None) -> Tensor:
     """Attention.forward + Attend.forward (non-flash): latent_module.py:934-950, 299-343.
 
-    Only keys are masked (fill -finfo.max); no biases; eval mode (no dropout).
+    Only keys are masked (fill -finfo.max); no biases; eval mode (no dropout).  `context` (cross-attention, :935-943): keys and
+    values come from it, `mask` then masks ITS positions.
     """
     B, T, _ = x.shape
+    ctx = x if context is None else context
+    Tk = ctx.shape[1]
     q = F.linear(x, sd["to_q.weight"])
-    k, v = F.linear(x, sd["to_kv.weight"]).chunk(2, dim=-1)  # [k ; v] :945
+    k, v = F.linear(ctx, sd["to_kv.weight"]).chunk(2, dim=-1)  # [k ; v] :945
     dh = q.shape[-1] // heads
-    q, k, v = (z.view(B, T, heads, dh).transpose(1, 2) for z in (q, k, v))  # (h d), h major
+    q = q.view(B, T, heads, dh).transpose(1, 2)  # (h d), h major
+    k, v = (z.view(B, Tk, heads, dh).transpose(1, 2) for z in (k, v))
     sim = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     if mask is not None:
-        sim = sim.masked_fill(~mask.view(B, 1, 1, T), -torch.finfo(sim.dtype).max)
+        sim = sim.masked_fill(~mask.view(B, 1, 1, Tk), -torch.finfo(sim.dtype).max)
     out = torch.matmul(sim.softmax(dim=-1), v)
     out = out.transpose(1, 2).reshape(B, T, heads * dh)
     return F.linear(out, sd["to_out.weight"])
@@ -226,8 +234,9 @@ def feed_forward(sd: SD, x: Tensor) -> Tensor:
     return F.linear(h, sd["3.weight"], sd["3.bias"])
 
 
-def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor], t: Optional[Tensor]):
-    """ConditionableTransformer.forward latent_module.py:681-706 (no cross-attention)."""
+def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor], t: Optional[Tensor], context: Optional[Tensor] = None):
+    """ConditionableTransformer.forward latent_module.py:681-706; with `context` the layers carry the cross-attention block
+    (:694-700: norm, attend to the resampled prompt latents without a mask, residual)."""
     for layer in range(depth):
         p = f"layers.{layer}."
         if t is not None:
@@ -235,6 +244,9 @@ def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor
         else:
             n1 = rms_norm(x, sd[p + "0.gamma"])
         x = attention(sub(sd, p + "1."), n1, mask, heads) + x
+        if context is not None:
+            nc = rms_norm(x, None, (sd[p + "2.to_gamma_beta.weight"], sd[p + "2.to_gamma_beta.bias"]), t)
+            x = attention(sub(sd, p + "3."), nc, None, heads, context=context) + x
         if t is not None:
             n2 = rms_norm(x, None, (sd[p + "4.to_gamma_beta.weight"], sd[p + "4.to_gamma_beta.bias"]), t)
         else:
@@ -256,6 +268,57 @@ def eps_forward(sd: SD, cfg: EpsConfig, x: Tensor, times: Tensor, mask: Tensor) 
     h = h + positional_embedding(mask, cfg.dim)
     h = transformer(sub(sd, "transformer."), h, cfg.depth, cfg.heads, mask, t)
     return F.linear(h, sd["final_proj.weight"], sd["final_proj.bias"])
+
+
+def perceiver_resampler(sd: SD, prompt: Tensor, prompt_mask: Tensor, heads: int) -> Tensor:
+    """PerceiverResampler.forward latent_module.py:416-471: learned latents (+ sinusoidal positions 1..m) attend to
+    [latents ; projected prompt] (cross_attn_include_queries, :935-943: the mask gets ones for the latents), feed-forward without
+    the causal conv, residuals, final learned-gamma RMSNorm."""
+    B = prompt.shape[0]
+    x = F.linear(prompt, sd["proj_context.weight"], sd["proj_context.bias"])
+    lat = sd["latents"]
+    m, D = lat.shape
+    lat = lat.unsqueeze(0).expand(B, -1, -1) + positional_embedding(torch.ones(B, m, dtype=torch.bool), D)
+    heads_dim = sd["layers.0.0.to_q.weight"].shape[0]
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
+    for l in range(depth):
+        a = sub(sd, f"layers.{l}.0.")
+        ctx = torch.cat([lat, x], dim=1)
+        cmask = torch.cat([torch.ones(B, m, dtype=torch.bool), prompt_mask], dim=1)
+        lat = attention(a, lat, cmask, heads, context=ctx) + lat
+        f = sub(sd, f"layers.{l}.1.")
+        h = F.linear(lat, f["0.weight"], f["0.bias"])
+        val, gate = h.chunk(2, dim=-1)
+        lat = F.linear(F.gelu(gate) * val, f["2.weight"], f["2.bias"]) + lat
+    return rms_norm(lat, sd["norm.gamma"])
+
+
+def eps_forward_cond(sd: SD, cfg: EpsConfig, x: Tensor, times: Tensor, mask: Tensor, prompt: Tensor, prompt_mask: Tensor,
+                     drop: Tensor) -> Tensor:
+    """Model.forward with condition_on_prompt (latent_module.py:828-876).  drop [B] bool = the classifier-free-guidance drop mask
+    (prob_mask_like, :843): dropped samples use null_prompt_cond / null_prompt_tokens."""
+    t = time_cond(sd, times)
+    masked = prompt.masked_fill(~prompt_mask.unsqueeze(2), 0.0)
+    pc = F.silu(F.linear(masked.mean(dim=1), sd["to_prompt_cond.1.weight"], sd["to_prompt_cond.1.bias"]))  # mean over ALL positions
+    pc = torch.where(drop.view(-1, 1), sd["null_prompt_cond"], pc)
+    t = torch.cat((t, pc), dim=-1)
+    c = perceiver_resampler(sub(sd, "perceiver_resampler."), masked, prompt_mask, cfg.heads)
+    c = torch.where(drop.view(-1, 1, 1), sd["null_prompt_tokens"], c)
+    h = causal_conv1d(x, sd["init_conv.weight"], sd["init_conv.bias"])
+    h = wavenet(sub(sd, "wavenet."), h, cfg.wavenet_stacks, cfg.wavenet_layers, t)
+    h = h + positional_embedding(mask, cfg.dim)
+    h = transformer(sub(sd, "transformer."), h, cfg.depth, cfg.heads, mask, t, context=c)
+    return F.linear(h, sd["final_proj.weight"], sd["final_proj.bias"])
+
+
+def eps_forward_with_cond_scale(sd, cfg, x, times, mask, prompt, prompt_mask, cond_scale: float) -> Tensor:
+    """forward_with_cond_scale latent_module.py:813-826."""
+    B = x.shape[0]
+    cond = eps_forward_cond(sd, cfg, x, times, mask, prompt, prompt_mask, torch.zeros(B, dtype=torch.bool))
+    if cond_scale == 1.0:
+        return cond
+    null = eps_forward_cond(sd, cfg, x, times, mask, prompt, prompt_mask, torch.ones(B, dtype=torch.bool))
+    return null + (cond - null) * cond_scale
 
 
 # --------------------------------------------------------------------------- VAE
@@ -656,6 +719,8 @@ def make_eps_state_dict(cfg: EpsConfig, seed: str = "eps") -> SD:
     inner = int(D * 4 * 2 / 3)
     hd = cfg.heads * cfg.dim_head
     sd: SD = {}
+    cond = cfg.dim_prompt > 0
+    C2 = C * (2 if cond else 1)  # the conditional variant concatenates the pooled-prompt condition to the time condition (:784)
 
     def lin(name, out, inp, bias=True, k=None):
         shape = (out, inp) if k is None else (out, inp, k)
@@ -671,7 +736,7 @@ def make_eps_state_dict(cfg: EpsConfig, seed: str = "eps") -> SD:
     for s in range(cfg.wavenet_stacks):
         for i in range(cfg.wavenet_layers):
             p = f"wavenet.stacks.{s}.blocks.{i}."
-            lin(p + "to_time_cond", 2 * D, C)
+            lin(p + "to_time_cond", 2 * D, C2)
             lin(p + "conv", D, D, k=3)
             lin(p + "res_conv", D, D, k=1)
             if s == cfg.wavenet_stacks - 1:
@@ -679,17 +744,37 @@ def make_eps_state_dict(cfg: EpsConfig, seed: str = "eps") -> SD:
     lin("wavenet.final_conv", D, D, k=1)
     for layer in range(cfg.depth):
         p = f"transformer.layers.{layer}."
-        lin(p + "0.to_gamma_beta", 2 * D, C)
+        lin(p + "0.to_gamma_beta", 2 * D, C2)
         lin(p + "1.to_q", hd, D, bias=False)
         lin(p + "1.to_kv", 2 * hd, D, bias=False)
         lin(p + "1.to_out", D, hd, bias=False)
-        lin(p + "4.to_gamma_beta", 2 * D, C)
+        if cond:
+            lin(p + "2.to_gamma_beta", 2 * D, C2)
+            lin(p + "3.to_q", hd, D, bias=False)
+            lin(p + "3.to_kv", 2 * hd, D, bias=False)
+            lin(p + "3.to_out", D, hd, bias=False)
+        lin(p + "4.to_gamma_beta", 2 * D, C2)
         lin(p + "5.0", 2 * inner, D)
         lin(p + "5.2.1", inner, inner, k=3)
         lin(p + "5.3", D, inner)
     sd["transformer.to_pred.0.gamma"] = 1.0 + _unit_hash_normal(seed + "tpg", (D,), 0.05)
     lin("transformer.to_pred.1", D, D, bias=False)
     lin("final_proj", Z, D)
+    if cond:
+        m, P = cfg.num_latents_m, cfg.dim_prompt
+        sd["null_prompt_cond"] = _unit_hash_normal(seed + "npc", (C,), 0.02)
+        sd["null_prompt_tokens"] = _unit_hash_normal(seed + "npt", (m, D), 0.02)
+        lin("to_prompt_cond.1", C, P)
+        r = "perceiver_resampler."
+        sd[r + "latents"] = _unit_hash_normal(seed + "lat", (m, D), 0.02)
+        lin(r + "proj_context", D, P)
+        for l in range(cfg.resampler_depth):
+            lin(r + f"layers.{l}.0.to_q", hd, D, bias=False)
+            lin(r + f"layers.{l}.0.to_kv", 2 * hd, D, bias=False)
+            lin(r + f"layers.{l}.0.to_out", D, hd, bias=False)
+            lin(r + f"layers.{l}.1.0", 2 * inner, D)
+            lin(r + f"layers.{l}.1.2", D, inner)
+        sd[r + "norm.gamma"] = 1.0 + _unit_hash_normal(seed + "rng", (D,), 0.05)
     return sd
 
 

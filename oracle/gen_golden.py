@@ -25,7 +25,7 @@ import ref_loader  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
-from gen_golden_configs import (CHAIN_EPS, CHAIN_VAE, FULL_EPS, FULL_VAE, TINY_EPS,  # noqa: E402
+from gen_golden_configs import (CHAIN_EPS, CHAIN_VAE, FULL_EPS, FULL_VAE, TINY_EPS, TINY_EPS_COND,  # noqa: E402
                                 ragged_lengths, seeded)
 
 
@@ -182,6 +182,37 @@ def gen_eps_tiny(lm):
     save("eps_tiny", x=x, t=t, lens=lens, eps=eps, time_cond=tc, wavenet=wn, pos_emb=pe)
 
 
+def gen_eps_cond_tiny(lm):
+    """Conditional eps-predictor (use_cond=True): Model(condition_on_prompt=True) with a ragged prompt -- the
+    conditioned pass (cond_drop_prob 0), the null pass (1), classifier-free guidance at scale 2 (forward_with_cond_scale,
+    latent_module.py:813-826), and the two conditioning products (pooled prompt condition, resampled prompt latents)."""
+    cfg = TINY_EPS_COND
+    sd = O.make_eps_state_dict(cfg, "cond")
+    m = lm.Model(cfg.dim, cfg.latent_dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads, wavenet_layers=cfg.wavenet_layers,
+                 wavenet_stacks=cfg.wavenet_stacks, dim_cond_mult=cfg.dim_cond_mult, condition_on_prompt=True, dim_prompt=cfg.dim_prompt,
+                 num_latents_m=cfg.num_latents_m, resampler_depth=cfg.resampler_depth)
+    full = dict(sd)
+    full["pos_embed._float_tensor"] = torch.zeros(1)
+    full["perceiver_resampler.embed_positions._float_tensor"] = torch.zeros(1)
+    m.load_state_dict(full, strict=True)
+    m.eval()
+    B, T, Tp = 3, 40, 21
+    x = seeded((B, T, cfg.latent_dim), 81)
+    lens, plens = torch.tensor([40, 23, 31]), torch.tensor([21, 9, 14])
+    mask, pmask = O.lengths_to_mask(lens, T), O.lengths_to_mask(plens, Tp)
+    prompt = seeded((B, Tp, cfg.dim_prompt), 82)
+    t = torch.tensor([3, 120, 77])
+    with torch.no_grad():
+        cond = m(x, t, prompt=prompt.clone(), prompt_mask=pmask, input_mask=mask, cond_drop_prob=0.0)
+        null = m(x, t, prompt=prompt.clone(), prompt_mask=pmask, input_mask=mask, cond_drop_prob=1.0)
+        cfg2 = m.forward_with_cond_scale(x, t, prompt=prompt.clone(), prompt_mask=pmask, input_mask=mask, cond_scale=2.0)
+        masked = prompt.clone().masked_fill_(~pmask.unsqueeze(2), 0)
+        pc = m.to_prompt_cond(masked)
+        c = m.perceiver_resampler(masked, mask=pmask)
+    save("eps_cond_tiny", x=x, t=t, lens=lens, plens=plens, prompt=prompt, eps_cond=cond, eps_null=null, eps_cfg2=cfg2, prompt_cond=pc,
+         resampled=c)
+
+
 def gen_eps_full(lm):
     cfg = FULL_EPS
     sd = O.make_eps_state_dict(cfg, "full")
@@ -305,6 +336,7 @@ def main():
     gen_gaussian_diffusion(gd)
     gen_gaussian_moments(gd)
     gen_eps_tiny(lm)
+    gen_eps_cond_tiny(lm)
     gen_chain(lm)
     if args.full:
         gen_eps_full(lm)

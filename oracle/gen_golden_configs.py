@@ -8,6 +8,9 @@ TINY_EPS = O.EpsConfig(dim=64, latent_dim=16, depth=2, heads=4, dim_head=16, wav
 # chain config: the reference's LatentDiscreteModel always builds Model(dim, z) with default depth
 CHAIN_EPS = O.EpsConfig(dim=64, latent_dim=8)
 CHAIN_VAE = O.VaeConfig(dim=192, latent_dim=32)  # mults [4,3] -> z = 8
+# conditional variant (use_cond=True): prompt dim 48, 8 resampled latents
+TINY_EPS_COND = O.EpsConfig(dim=64, latent_dim=16, depth=2, heads=4, dim_head=16, wavenet_layers=3, wavenet_stacks=2, dim_prompt=48,
+                            num_latents_m=8, resampler_depth=2)
 FULL_EPS = O.EpsConfig()
 FULL_VAE = O.VaeConfig()
 

@@ -56,7 +56,7 @@ def test_struct_layout_matches_header(lib, tmp_path):
         "DnAdamParams": (_lib.AdamParams, ["lr", "beta1", "beta2", "eps", "weight_decay", "max_norm", "step", "grad_scale",
                                            "grad_scale_dev"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
-                                           "dtype", "lengths", "scale", "lse"]),
+                                           "dtype", "Tk", "lengths", "scale", "lse"]),
         "DnAttnBwdParams": (_lib.AttnBwdParams, ["q", "k", "v", "out", "dout", "dq", "dk", "dv", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq",
                                                  "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
                                                  "delta"]),
@@ -68,7 +68,7 @@ def test_struct_layout_matches_header(lib, tmp_path):
                                                  "snr_weight", "beta0", "B", "T", "n_units", "n_frames", "timesteps", "multitask",
                                                  "label_smoothing", "recon_weight", "loss_scale", "stats", "eps_out"]),
         "DnEpsConfig": (_lib.EpsConfig, ["dim", "latent", "depth", "heads", "dim_head", "wn_layers", "wn_stacks", "cond_mult",
-                                         "dtype", "max_pos"]),
+                                         "dtype", "max_pos", "dim_prompt", "num_latents", "resampler_depth"]),
         "DnVaeConfig": (_lib.VaeConfig, ["dim", "z", "depth", "heads", "dim_head", "stacks", "layers", "vocab", "n_mults",
                                          "mults", "dtype"]),
     }

@@ -257,3 +257,36 @@ def test_vae_cascaded_encoders(eng, dtype, tol, latent_flag):
     recon, logits, units = ve.decode(z.to(DEV), lens)
     r_ref, l_ref = O.vae_decode(sd, cfg, z, mask)
     assert maxerr(recon.cpu()[mask], r_ref[mask]) < tol and maxerr(logits.cpu()[mask], l_ref[mask]) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+def test_eps_conditional_variant_vs_reference_golden(eng, golden, dtype, tol):
+    """SURVEY 8 f3 (use_cond=True): Model.forward with condition_on_prompt -- pooled-prompt condition (2x conditioning width),
+    PerceiverResampler, cross-attention in every layer -- and classifier-free guidance, against the reference's outputs
+    (tests/golden/eps_cond_tiny.npz: conditioned, null and cond_scale = 2 passes, ragged prompt)."""
+    from gen_golden_configs import TINY_EPS_COND
+
+    engine, _ = eng
+    g = golden("eps_cond_tiny")
+    sd = O.make_eps_state_dict(TINY_EPS_COND, "cond")
+    e = engine.EpsEngine(sd, TINY_EPS_COND, dtype=dtype, device=DEV)
+    x, t, lens, plens, prompt = (T_(g[k]) for k in ("x", "t", "lens", "plens", "prompt"))
+    mask = O.lengths_to_mask(lens, x.shape[1])
+    B = x.shape[0]
+    cond = e.forward_cond(x.to(DEV), t, lens, prompt.to(DEV), plens, torch.zeros(B, dtype=torch.bool)).cpu()
+    null = e.forward_cond(x.to(DEV), t, lens, prompt.to(DEV), plens, torch.ones(B, dtype=torch.bool)).cpu()
+    cfg2 = e.forward_with_cond_scale(x.to(DEV), t, lens, prompt.to(DEV), plens, cond_scale=2.0).cpu()
+    for name, got in (("eps_cond", cond), ("eps_null", null), ("eps_cfg2", cfg2)):
+        err = maxerr(got[mask], T_(g[name])[mask])
+        print(f"conditional {name} {dtype}: max abs err {err:.3e}")
+        assert err < tol * (2 if name == "eps_cfg2" else 1), (name, err)
+    # a mixed drop mask equals the per-sample selection of the two passes (the guidance mask is per sample, :843-859)
+    mixed = e.forward_cond(x.to(DEV), t, lens, prompt.to(DEV), plens, torch.tensor([True, False, True])).cpu()
+    assert maxerr(mixed[0][mask[0]], null[0][mask[0]]) < 1e-6 and maxerr(mixed[1][mask[1]], cond[1][mask[1]]) < 1e-6
+    # the prompt's padded positions do not matter
+    p2 = prompt.clone()
+    p2[~O.lengths_to_mask(plens, prompt.shape[1])] = 7.0
+    again = e.forward_cond(x.to(DEV), t, lens, p2.to(DEV), plens, torch.zeros(B, dtype=torch.bool)).cpu()
+    assert torch.equal(again, cond)
+    with pytest.raises(Exception):
+        e.forward(x.to(DEV), t, lens)

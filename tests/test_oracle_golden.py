@@ -128,6 +128,22 @@ def test_eps_tiny(golden):
     close(O.eps_forward(sd, cfg, x, t, mask), g["eps"], 5e-5)
 
 
+def test_eps_conditional_variant(golden):
+    """use_cond=True: the oracle's PerceiverResampler / prompt conditioning / cross-attention / guidance restatement."""
+    from gen_golden_configs import TINY_EPS_COND as cfg
+
+    g = golden("eps_cond_tiny")
+    sd = O.make_eps_state_dict(cfg, "cond")
+    x, t, lens, plens, prompt = (T(g[k]) for k in ("x", "t", "lens", "plens", "prompt"))
+    mask, pmask = O.lengths_to_mask(lens, x.shape[1]), O.lengths_to_mask(plens, prompt.shape[1])
+    B = x.shape[0]
+    close(O.eps_forward_cond(sd, cfg, x, t, mask, prompt, pmask, torch.zeros(B, dtype=torch.bool)), g["eps_cond"], 2e-5)
+    close(O.eps_forward_cond(sd, cfg, x, t, mask, prompt, pmask, torch.ones(B, dtype=torch.bool)), g["eps_null"], 2e-5)
+    close(O.eps_forward_with_cond_scale(sd, cfg, x, t, mask, prompt, pmask, 2.0), g["eps_cfg2"], 5e-5)
+    masked = prompt.masked_fill(~pmask.unsqueeze(2), 0.0)
+    close(O.perceiver_resampler(O.sub(sd, "perceiver_resampler."), masked, pmask, cfg.heads), g["resampled"], 2e-5)
+
+
 def test_chain_small(golden):
     g = golden("chain_small")
     esd = O.make_eps_state_dict(CHAIN_EPS, "chain")
