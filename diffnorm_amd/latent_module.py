@@ -92,17 +92,21 @@ class Model(_ParamTree):
                  dim_cond_mult=4, use_flash_attn=False, dim_prompt=None, num_latents_m=64, resampler_depth=2,
                  cond_drop_prob=0., condition_on_prompt=False, dtype="bf16", seed=0):
         super().__init__()
-        if condition_on_prompt:
-            raise NotImplementedError("prompt conditioning (use_cond=True) is row f3 of the scope table, not built yet")
         if ff_mult != 4:
             raise NotImplementedError("the engine packs ff_mult = 4 (the only value the recipe uses)")
+        if condition_on_prompt and not dim_prompt:
+            raise ValueError("condition_on_prompt needs dim_prompt")
         self.dim, self.latent_dim = dim, latent_dim
         self.cond_drop_prob = cond_drop_prob
-        self.condition_on_prompt = False
-        self.cfg = synthetic.eps_config(dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult)
+        self.condition_on_prompt = bool(condition_on_prompt)
+        self.cfg = synthetic.eps_config(dim, latent_dim, depth, heads, dim_head, wavenet_layers, wavenet_stacks, dim_cond_mult,
+                                        dim_prompt=dim_prompt if condition_on_prompt else 0, num_latents_m=num_latents_m,
+                                        resampler_depth=resampler_depth)
         self.arith = dtype
         self._adopt(synthetic.random_eps_state_dict(self.cfg, seed))
         self._attach("pos_embed._float_tensor", torch.zeros(1), buffer=True)  # key present upstream (:774-779)
+        if self.condition_on_prompt:
+            self._attach("perceiver_resampler.embed_positions._float_tensor", torch.zeros(1), buffer=True)  # (:428-435)
 
     # ---- training: set by LatentDiscreteModel.enable_training -- the flat master buffer of the diffusion
     # training engine becomes this module's only parameter; state_dict() keeps the reference's keys
@@ -147,21 +151,40 @@ class Model(_ParamTree):
             return self._engine
         key = self._state_key()
         if self._engine is None or self._engine_key != key:
-            sd = {k: v.detach().cpu() for k, v in self.state_dict().items() if not k.startswith("pos_embed")}
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items() if not k.endswith("._float_tensor")}
             self._engine = engine.EpsEngine(sd, self.cfg, dtype=self.arith, device=self.device)
             self._engine_key = key
         return self._engine
 
-    def forward(self, x, times, prompt=None, prompt_mask=None, input_mask=None, cond=None, cond_drop_prob=None):
-        """x [B,T,latent], times [B] (raw integer steps), input_mask [B,T] bool -> eps_hat [B,T,latent]."""
+    def forward(self, x, times, prompt=None, prompt_mask=None, input_mask=None, cond=None, cond_drop_prob=None, drop_mask=None):
+        """x [B,T,latent], times [B] (raw integer steps), input_mask [B,T] bool -> eps_hat [B,T,latent].  With
+        condition_on_prompt: prompt [B,Tp,dim_prompt], prompt_mask [B,Tp]; the classifier-free-guidance drop mask is drawn per
+        sample with probability cond_drop_prob like upstream's prob_mask_like (:843) unless `drop_mask` [B] bool is given."""
         if input_mask is None:
             input_mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
         lengths = _mask_to_lengths(input_mask)
+        if self.condition_on_prompt:
+            if prompt is None or prompt_mask is None:
+                raise ValueError("this Model is conditioned on a prompt: pass prompt and prompt_mask")
+            B = x.shape[0]
+            if drop_mask is None:
+                p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+                drop_mask = torch.ones(B, dtype=torch.bool) if p >= 1 else (
+                    torch.zeros(B, dtype=torch.bool) if p <= 0 else torch.zeros(B).float().uniform_(0, 1) < p)
+            return self.engine().forward_cond(x, times, lengths, prompt, _mask_to_lengths(prompt_mask), drop_mask)
         shared = bool((times == times[0]).all())
         return self.engine().forward(x, times, lengths, shared_t=shared)
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
-        return self.forward(*args, **kwargs)  # no prompt branch: guidance is the identity (:813-826)
+        """null + (cond - null) * cond_scale (:813-826); without a prompt branch guidance is the identity."""
+        if not self.condition_on_prompt:
+            return self.forward(*args, **kwargs)
+        kwargs.pop("cond_drop_prob", None)
+        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale == 1.:
+            return logits
+        null = self.forward(*args, cond_drop_prob=1., **kwargs)
+        return torch.add(null, logits - null, alpha=cond_scale)
 
 
 class _VaeStepFn(torch.autograd.Function):
@@ -348,7 +371,9 @@ class LatentDiscreteModel(nn.Module):
         assert objective in {'x0', 'eps', 'v'}, 'objective must be either predict x0 or noise'
         self.speech_decoder = speech_decoder.encoder
         self.use_cond, self.multitask = use_cond, multitask
-        self.model = Model(dim, latent_dim, condition_on_prompt=use_cond, dtype=dtype)
+        # use_cond: Model(dim, latent_dim, condition_on_prompt=True, dim_prompt=768, num_latents_m=64) upstream (:1325-1333)
+        self.model = Model(dim, latent_dim, condition_on_prompt=use_cond, dim_prompt=getattr(speech_decoder.encoder, "dim", 768) if use_cond else None,
+                           num_latents_m=64, dtype=dtype)
         self.scheduler = DDPMScheduler(timesteps, scale=scale)
         self.dim, self.timesteps, self.objective = dim, timesteps, objective
         self.min_snr_loss_weight, self.min_snr_gamma = min_snr_loss_weight, min_snr_gamma
@@ -369,6 +394,9 @@ class LatentDiscreteModel(nn.Module):
         buffer); the frozen VAE (diff_discrete.py:79-82) is mirrored into a VaeTrainEngine that only passes data gradients."""
         if self._train_engine is not None:
             return self._train_engine
+        if self.use_cond:
+            raise NotImplementedError("the HIP training engine covers the unconditional eps-predictor (the recipe); the conditional "
+                                      "variant (use_cond) has its forward / guidance path only")
         from . import training
 
         vae = self.speech_decoder
@@ -405,7 +433,22 @@ class LatentDiscreteModel(nn.Module):
             start_noise = torch.randn(z.shape, device=dev)
         t_start = torch.full((B,), start_step, dtype=torch.int32, device=dev)
         x = ops.q_sample(z, start_noise.to(dev, torch.float32).contiguous(), sa, s1, t_start, T)  # (:1405-1409)
-        self.model.engine().ddim_loop(x, lengths, start_step, coef, use_graph=use_graph)        # (:1411-1445)
+        if self.use_cond:
+            # prompted chain (f3): the reference's loop drops the prompt it was given (:1413-1417 -- with use_cond it cannot run at
+            # all); here every step is the guided prediction forward_with_cond_scale (:813-826) followed by the same DDIM update.
+            # The device-resident graph loop covers the unconditional model; this one steps from the host.
+            if prompt is None or prompt_mask is None:
+                raise ValueError("use_cond: ddim_sample needs prompt and prompt_mask")
+            eng = self.model.engine()
+            plens = _mask_to_lengths(prompt_mask.to(dev))
+            for time in range(start_step - 1, -1, -1):
+                tt = torch.full((B,), time, dtype=torch.int32, device=dev)
+                eps = eng.forward_with_cond_scale(x, tt, lengths, prompt, plens, cond_scale=cond_scale)
+                x = ops.ddim_step(x, eps, coef, tt, T)
+                if time == 1:
+                    break
+        else:
+            self.model.engine().ddim_loop(x, lengths, start_step, coef, use_graph=use_graph)    # (:1411-1445)
         recon, _, units = self.speech_decoder.engine().decode(x, lengths, want_logits=False)     # (:1448-1451)
         pred_units = units.long()
         match = total = 0
@@ -445,7 +488,11 @@ class LatentDiscreteModel(nn.Module):
         beta0 = float(self.scheduler.f32("betas")[0])
         x1 = (z + jitter_noise * beta0).contiguous()  # beta_0, not sqrt(beta_0) (:1534-1536)
         xt = ops.q_sample(x1, true_noise, sa_t, s1_t, t32, T)
-        eps = self.model(xt, times, input_mask=tgt_mask, cond_drop_prob=0.1)
+        if self.use_cond:  # (:1546-1553): the source features are the prompt
+            eps = self.model(xt, times, prompt=src_feature, prompt_mask=src_mask, input_mask=tgt_mask, cond_drop_prob=0.1,
+                             drop_mask=kwargs.get("drop_mask"))
+        else:
+            eps = self.model(xt, times, input_mask=tgt_mask, cond_drop_prob=0.1)
         snr = self.scheduler.get_snr(times)
         weight = snr.clamp(max=5.0) / snr
         mse = ((eps - true_noise) ** 2).masked_fill(~tgt_mask.unsqueeze(2), 0.0).flatten(1).mean(dim=1)

@@ -8,10 +8,13 @@ from typing import Dict
 import torch
 
 
-def eps_config(dim=512, latent_dim=128, depth=12, heads=8, dim_head=64, wavenet_layers=8, wavenet_stacks=4, dim_cond_mult=4):
-    """Hyper-parameters of the eps-predictor `Model` (reference latent_module.py:709-728, diff_discrete.py:83-84)."""
+def eps_config(dim=512, latent_dim=128, depth=12, heads=8, dim_head=64, wavenet_layers=8, wavenet_stacks=4, dim_cond_mult=4,
+               dim_prompt=0, num_latents_m=64, resampler_depth=2):
+    """Hyper-parameters of the eps-predictor `Model` (reference latent_module.py:709-728, diff_discrete.py:83-84); dim_prompt > 0 =
+    the conditional variant (use_cond=True: dim_prompt 768, 64 resampled latents, :1325-1333)."""
     return SimpleNamespace(dim=dim, latent_dim=latent_dim, depth=depth, heads=heads, dim_head=dim_head,
-                           wavenet_layers=wavenet_layers, wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult)
+                           wavenet_layers=wavenet_layers, wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult,
+                           dim_prompt=dim_prompt, num_latents_m=num_latents_m, resampler_depth=resampler_depth)
 
 
 class _Init:
@@ -30,6 +33,8 @@ class _Init:
 def random_eps_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     D, Z, C = cfg.dim, cfg.latent_dim, cfg.dim * cfg.dim_cond_mult
     inner, hd = int(D * 4 * 2 / 3), cfg.heads * cfg.dim_head
+    cond = getattr(cfg, "dim_prompt", 0) > 0
+    C2 = C * (2 if cond else 1)
     it = _Init(seed)
     it.lin("init_conv", D, Z, k=1)
     it.sd["to_time_cond.0.weights"] = torch.randn(D // 2, generator=it.g)
@@ -38,7 +43,7 @@ def random_eps_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     for s in range(cfg.wavenet_stacks):
         for i in range(cfg.wavenet_layers):
             p = f"wavenet.stacks.{s}.blocks.{i}."
-            it.lin(p + "to_time_cond", 2 * D, C)
+            it.lin(p + "to_time_cond", 2 * D, C2)
             it.lin(p + "conv", D, D, k=3)
             it.lin(p + "res_conv", D, D, k=1)
             if s == cfg.wavenet_stacks - 1:
@@ -46,17 +51,37 @@ def random_eps_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     it.lin("wavenet.final_conv", D, D, k=1)
     for l in range(cfg.depth):
         p = f"transformer.layers.{l}."
-        it.lin(p + "0.to_gamma_beta", 2 * D, C)
+        it.lin(p + "0.to_gamma_beta", 2 * D, C2)
         it.lin(p + "1.to_q", hd, D, bias=False)
         it.lin(p + "1.to_kv", 2 * hd, D, bias=False)
         it.lin(p + "1.to_out", D, hd, bias=False)
-        it.lin(p + "4.to_gamma_beta", 2 * D, C)
+        if cond:
+            it.lin(p + "2.to_gamma_beta", 2 * D, C2)
+            it.lin(p + "3.to_q", hd, D, bias=False)
+            it.lin(p + "3.to_kv", 2 * hd, D, bias=False)
+            it.lin(p + "3.to_out", D, hd, bias=False)
+        it.lin(p + "4.to_gamma_beta", 2 * D, C2)
         it.lin(p + "5.0", 2 * inner, D)
         it.lin(p + "5.2.1", inner, inner, k=3)
         it.lin(p + "5.3", D, inner)
     it.sd["transformer.to_pred.0.gamma"] = torch.ones(D)
     it.lin("transformer.to_pred.1", D, D, bias=False)
     it.lin("final_proj", Z, D)
+    if cond:  # reference latent_module.py:752-773, 416-440 (std 0.02 normal for the null condition / tokens / latents)
+        m, P = cfg.num_latents_m, cfg.dim_prompt
+        it.sd["null_prompt_cond"] = torch.randn(C, generator=it.g) * 0.02
+        it.sd["null_prompt_tokens"] = torch.randn(m, D, generator=it.g) * 0.02
+        it.lin("to_prompt_cond.1", C, P)
+        r = "perceiver_resampler."
+        it.sd[r + "latents"] = torch.randn(m, D, generator=it.g) * 0.02
+        it.lin(r + "proj_context", D, P)
+        for l in range(cfg.resampler_depth):
+            it.lin(r + f"layers.{l}.0.to_q", hd, D, bias=False)
+            it.lin(r + f"layers.{l}.0.to_kv", 2 * hd, D, bias=False)
+            it.lin(r + f"layers.{l}.0.to_out", D, hd, bias=False)
+            it.lin(r + f"layers.{l}.1.0", 2 * inner, D)
+            it.lin(r + f"layers.{l}.1.2", D, inner)
+        it.sd[r + "norm.gamma"] = torch.ones(D)
     return it.sd
 
 

@@ -191,3 +191,54 @@ def test_gaussian_moments_match_reference_golden(golden):
     terms = create_diffusion("ddim50").training_losses(tl, x0, T_(g["t50"]).to(DEV), noise=noise)
     rel(terms["loss"], g["ddim50_learned_loss"], 2e-5)
     rel(terms["vb"], g["ddim50_learned_vb"], 2e-5)
+
+
+def test_conditional_variant_through_the_mirror(golden):
+    """use_cond=True through the reference-named modules: Model(condition_on_prompt=True) with the reference's
+    state-dict keys, forward / forward_with_cond_scale against the reference's outputs, and a prompted, guided DDIM chain of
+    LatentDiscreteModel against the oracle's per-step restatement."""
+    from diffnorm_amd import ops, scheduler
+    from diffnorm_amd.latent_module import LatentDiscreteModel, Model, SpeechVAEEncoderDecoder
+    from gen_golden_configs import TINY_EPS_COND as cfg
+
+    g = golden("eps_cond_tiny")
+    sd = O.make_eps_state_dict(cfg, "cond")
+    m = Model(cfg.dim, cfg.latent_dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads, wavenet_layers=cfg.wavenet_layers,
+              wavenet_stacks=cfg.wavenet_stacks, condition_on_prompt=True, dim_prompt=cfg.dim_prompt, num_latents_m=cfg.num_latents_m,
+              resampler_depth=cfg.resampler_depth, dtype="f32")
+    extra = {"pos_embed._float_tensor", "perceiver_resampler.embed_positions._float_tensor"}
+    assert set(m.state_dict()) == set(sd) | extra  # the reference's conditional key set (strict-loaded there by gen_golden.py)
+    m.load_state_dict(dict(sd, **{k: torch.zeros(1) for k in extra}), strict=True)
+    m.to(DEV)
+    x, t, lens, plens, prompt = (T_(g[k]) for k in ("x", "t", "lens", "plens", "prompt"))
+    mask, pmask = O.lengths_to_mask(lens, 40), O.lengths_to_mask(plens, 21)
+    kw = dict(prompt=prompt.to(DEV), prompt_mask=pmask.to(DEV), input_mask=mask.to(DEV))
+    close(m(x.to(DEV), t, cond_drop_prob=0.0, **kw).cpu()[mask], T_(g["eps_cond"])[mask], 1e-4)
+    close(m(x.to(DEV), t, cond_drop_prob=1.0, **kw).cpu()[mask], T_(g["eps_null"])[mask], 1e-4)
+    close(m.forward_with_cond_scale(x.to(DEV), t, cond_scale=2.0, **kw).cpu()[mask], T_(g["eps_cfg2"])[mask], 1e-4)
+    with pytest.raises(ValueError):
+        m(x.to(DEV), t, input_mask=mask.to(DEV))
+    # prompted + guided chain: LatentDiscreteModel(use_cond=True) builds Model(dim, z, condition_on_prompt=True, dim_prompt = feature dim)
+    vae = SpeechVAEEncoderDecoder(dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="f32")
+    vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
+    vae.load_state_dict(vsd, strict=True)
+    ldm = LatentDiscreteModel(types.SimpleNamespace(encoder=vae), 64, CHAIN_VAE.z, timesteps=200, use_cond=True, dtype="f32").to(DEV).eval()
+    assert ldm.model.condition_on_prompt and ldm.model.cfg.dim_prompt == CHAIN_VAE.dim and ldm.model.cfg.num_latents_m == 64
+    ecfg = O.EpsConfig(dim=64, latent_dim=CHAIN_VAE.z, dim_prompt=CHAIN_VAE.dim, num_latents_m=64)
+    esd = {k: v.detach().cpu() for k, v in ldm.model.state_dict().items() if not k.endswith("._float_tensor")}
+    feat, src = seeded((2, 24, CHAIN_VAE.dim), 91), seeded((2, 30, CHAIN_VAE.dim), 92)
+    flen, slen = torch.tensor([24, 15]), torch.tensor([30, 22])
+    fmask, smask = O.lengths_to_mask(flen, 24), O.lengths_to_mask(slen, 30)
+    post, start = seeded((2, 24, CHAIN_VAE.z), 93), seeded((2, 24, CHAIN_VAE.z), 94)
+    toks, _, total, recon = ldm.ddim_sample(feat.to(DEV), prompt=src.to(DEV), prompt_mask=smask.to(DEV), input_mask=fmask.to(DEV),
+                                            cond_scale=2.0, start_step=4, post_noise=post, start_noise=start)
+    tab = O.ddpm_tables(200)
+    xx = O.vae_encode(vsd, CHAIN_VAE, feat, post)
+    ts = torch.full((2,), 4, dtype=torch.long)
+    xx = tab.at("sqrt_alphas_cumprod", ts, 3) * xx + tab.at("sqrt_one_minus_alphas_cumprod", ts, 3) * start
+    for time in (3, 2, 1):
+        tt = torch.full((2,), time, dtype=torch.long)
+        xx = O.ddim_update(tab, xx, O.eps_forward_with_cond_scale(esd, ecfg, xx, tt, fmask, src, smask, 2.0), tt)
+    want, _ = O.vae_decode(vsd, CHAIN_VAE, xx, fmask)
+    close(recon.cpu()[fmask], want[fmask], 2e-3)
+    assert total == int(flen.sum()) and [t_.shape[0] for t_ in toks] == flen.tolist()
