@@ -147,6 +147,7 @@ SYMBOLS = {
     "dn_vae_train_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "dn_vae_train_forward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _vp, _sz, _vp]),
     "dn_vae_train_backward": (C.c_int, [_vp, C.POINTER(VaeTrainBatch), _i32, _i32, _vp, _sz, _vp]),
+    "dn_cmlm_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dn_eps_train_create": (C.c_int, [C.POINTER(EpsConfig), C.POINTER(_vp)]),
     "dn_eps_train_destroy": (None, [_vp]),
     "dn_eps_train_param_count": (_i64, [_vp]),

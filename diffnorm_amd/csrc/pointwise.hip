@@ -361,6 +361,75 @@ __global__ __launch_bounds__(256) void gaussian_moments_kernel(const DnGaussianM
   }
 }
 
+// ------------------------------------------------------------------------------------------ CMLM mask-predict update (f4)
+// One workgroup per sequence (T <= 2048).  Phase 1: every position holding `unk` (the mask symbol) takes argmax / max of
+// log_softmax(logits[b, t, :]) (one wave per position).  Phase 2 (not on the last iteration): the boundary lowest-scoring
+// positions -- boundary = trunc((n_nonpad - 2) * p), scores ascending, ties by position -- are re-masked (token = unk, score = 0).
+__global__ __launch_bounds__(256) void cmlm_step_kernel(const float* __restrict__ logits, int32_t* __restrict__ tokens, float* __restrict__ scores,
+                                                        int32_t* __restrict__ predicted, int T, int V, float p, int remask, int unk, int pad) {
+  __shared__ float s_sc[2048];
+  __shared__ int32_t s_tok[2048];
+  __shared__ int s_n;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_n = 0;
+  for (int t = wave; t < T; t += 4) {
+    int32_t tok = tokens[(int64_t)b * T + t];
+    float sc = scores[(int64_t)b * T + t];
+    if (tok == unk) {  // wave-uniform
+      const float* lr = logits + ((int64_t)b * T + t) * V;
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < V; c += 64) {
+        const float v = lr[c];
+        if (v > best) { best = v; bi = c; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      float se = 0.f;
+      for (int c = lane; c < V; c += 64) se += expf(lr[c] - best);
+      se = wave_sum(se);
+      tok = bi;
+      sc = -logf(se);  // max - logsumexp = -(log sum exp(x - max))
+    }
+    if (lane == 0) {
+      s_tok[t] = tok;
+      s_sc[t] = sc;
+      predicted[(int64_t)b * T + t] = tok;
+    }
+  }
+  __syncthreads();
+  if (remask) {
+    int cnt = 0;
+    for (int t = threadIdx.x; t < T; t += 256) cnt += s_tok[t] != pad;
+    if (cnt) atomicAdd(&s_n, cnt);  // integer count within the workgroup: order-independent
+    __syncthreads();
+    const long long boundary = (long long)((float)(s_n - 2) * p);
+    for (int i = threadIdx.x; i < T; i += 256) {
+      const float si = s_sc[i];
+      int rank = 0;
+      for (int j = 0; j < T; ++j) {
+        const float sj = s_sc[j];
+        rank += (sj < si) || (sj == si && j < i);
+      }
+      int32_t tok = s_tok[i];
+      float sc = si;
+      if ((long long)rank < boundary) { tok = unk; sc = 0.f; }
+      tokens[(int64_t)b * T + i] = tok;
+      scores[(int64_t)b * T + i] = sc;
+    }
+  } else {
+    for (int i = threadIdx.x; i < T; i += 256) {
+      tokens[(int64_t)b * T + i] = s_tok[i];
+      scores[(int64_t)b * T + i] = s_sc[i];
+    }
+  }
+}
+
 static inline int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -454,5 +523,16 @@ extern "C" int dn_gaussian_moments(const DnGaussianMoments* p, void* stream) {
   DN_CHECK_ARG(p->N > 0 && p->inner > 0, "dn_gaussian_moments: bad shape");
   hipLaunchKernelGGL(gaussian_moments_kernel, dim3(ew_grid((int64_t)p->N * p->inner)), dim3(256), 0, (hipStream_t)stream, *p);
   DN_CHECK_LAUNCH("dn_gaussian_moments");
+  return DN_OK;
+}
+
+extern "C" int dn_cmlm_step(const float* logits, int32_t* tokens, float* scores, int32_t* predicted, int32_t B, int32_t T, int32_t V,
+                            int32_t step, int32_t max_step, int32_t unk, int32_t pad, void* stream) {
+  DN_CHECK_ARG(logits && tokens && scores && predicted && B > 0 && T > 0 && T <= 2048 && V > 1 && max_step > 0 && step >= 0,
+               "dn_cmlm_step: bad args (T=%d must be <= 2048)", T);
+  const int remask = (step + 1) < max_step;
+  const float p = (float)(1.0 - (double)(step + 1) / (double)max_step);  // the Python float of the reference, cast to the scores' fp32
+  hipLaunchKernelGGL(cmlm_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, tokens, scores, predicted, T, V, p, remask, unk, pad);
+  DN_CHECK_LAUNCH("dn_cmlm_step");
   return DN_OK;
 }

@@ -513,6 +513,15 @@ int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* batch, void* work
 int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* batch, int32_t first_stage, int32_t last_stage, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ mask-predict update */
+/* The per-iteration update of the CMLM decoder downstream of the normalised units (fairseq/models/nat/cmlm_transformer.py:88-134,
+ * called from the loop of fairseq/iterative_refinement_generator.py:200-230): positions holding `unk` (the mask symbol) take
+ * argmax / max of log_softmax(logits); `predicted` receives the tokens at that point; then, unless step + 1 == max_step, the
+ * trunc((n_nonpad - 2) * (1 - (step + 1) / max_step)) lowest-scoring positions are re-masked (_skeptical_unmasking :19-25; equal
+ * scores ordered by position).  logits fp32 [B, T, V]; tokens int32 [B, T] and scores fp32 [B, T] updated in place.  T <= 2048.  */
+int dn_cmlm_step(const float* logits, int32_t* tokens, float* scores, int32_t* predicted, int32_t B, int32_t T, int32_t V, int32_t step,
+                 int32_t max_step, int32_t unk, int32_t pad, void* stream);
+
 /* ------------------------------------------------------------------ diffusion training step */
 /* LatentDiscreteModel.forward (latent_module.py:1514-1613; criterion fairseq/criterions/ddpm_discrete_loss.py:37-75) for the
  * eps-predictor `Model`, with the frozen VAE (diff_discrete.py:70-85) as a bound DnVaeTrain whose decoder only passes data
