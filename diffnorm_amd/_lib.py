@@ -58,14 +58,16 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("B", C.c_int32), ("T", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32),
                 ("dtype", C.c_int32), ("Tk", C.c_int32), ("lengths", C.c_void_p),
-                ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p)]
+                ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p),
+                ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("pad3_", C.c_int32)]
 
 
 class AttnBwdParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "out", "dout", "dq", "dk", "dv")] + \
                [(n, C.c_int32) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv", "B", "T", "heads", "dim_head",
                                          "dtype", "pad_")] + \
-               [("lengths", C.c_void_p), ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p), ("delta", C.c_void_p)]
+               [("lengths", C.c_void_p), ("scale", C.c_float), ("pad2_", C.c_int32), ("lse", C.c_void_p), ("delta", C.c_void_p),
+                ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("pad3_", C.c_int32)]
 
 
 class GaussianStep(C.Structure):
@@ -97,7 +99,8 @@ class VaeTrainBatch(C.Structure):
     _fields_ = [("feat", C.c_void_p), ("units", C.c_void_p), ("lengths", C.c_void_p), ("noise", C.c_void_p), ("B", C.c_int32),
                 ("T", C.c_int32), ("ntokens", C.c_int32), ("w_lsce", C.c_float), ("w_mse", C.c_float), ("w_kl", C.c_float),
                 ("label_smoothing", C.c_float), ("loss_scale", C.c_float), ("stats", C.c_void_p), ("logits_out", C.c_void_p),
-                ("recon_out", C.c_void_p), ("ext_dlogits", C.c_void_p)]
+                ("recon_out", C.c_void_p), ("ext_dlogits", C.c_void_p), ("attn_dropout", C.c_float),
+                ("dropout_seed_lo", C.c_uint32), ("dropout_seed_hi", C.c_uint32), ("pad_", C.c_int32)]
 
 
 class EpsTrainBatch(C.Structure):
@@ -105,7 +108,8 @@ class EpsTrainBatch(C.Structure):
                                           "snr_weight")] + \
                [("beta0", C.c_float), ("B", C.c_int32), ("T", C.c_int32), ("n_units", C.c_int32), ("n_frames", C.c_int32),
                 ("timesteps", C.c_int32), ("multitask", C.c_int32), ("label_smoothing", C.c_float), ("recon_weight", C.c_float),
-                ("loss_scale", C.c_float), ("stats", C.c_void_p), ("eps_out", C.c_void_p)]
+                ("loss_scale", C.c_float), ("stats", C.c_void_p), ("eps_out", C.c_void_p), ("attn_dropout", C.c_float),
+                ("dropout_seed_lo", C.c_uint32), ("dropout_seed_hi", C.c_uint32), ("pad_", C.c_int32)]
 
 
 # every symbol include/diffnorm_hip.h declares: name -> (restype, argtypes)

@@ -38,7 +38,7 @@ __device__ __forceinline__ int lds_off<F32>(int row, int byte) {
 constexpr int KV_TILE = 64;
 constexpr float NEG_BIG = -3.0e38f;
 
-template <typename E, int DHP>
+template <typename E, int DHP, bool DROP>
 __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
@@ -92,6 +92,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     len = Tk;
     sc = 0.f;
   }
+
+  // attention dropout (training): thr = p * 2^32, kept probabilities scaled by 1 / (1 - p); the per-lane query rows' hashes are hoisted
+  uint32_t drop_thr = 0, drop_row[2] = {0, 0};
+  float drop_inv = 1.f;
+  if constexpr (DROP) {
+    drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
+    drop_inv = 1.0f / (1.0f - p.dropout_p);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      drop_row[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fr)), p.seed_lo);
+  }
+  auto dropped = [&](float pv, int qt, int key) -> float {
+    if constexpr (DROP) return dn_drop_keep(drop_row[qt], (uint32_t)key, p.seed_hi, drop_thr) ? pv * drop_inv : 0.f;
+    return pv;
+  };
 
   // K/V tiles are double-buffered in LDS and register-staged TWO tiles ahead (two register sets): a key tile's work
   // (~1.5k cycles per wave) is shorter than a loaded L2/HBM round trip, so with one tile of lead every iteration ended
@@ -221,13 +236,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     if constexpr (ES == 2) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {  // 32-key k-steps = accumulator tiles (2kk, 2kk+1)
-        uint4 pf[2];
+        uint4 pf[2], pfd[2];  // pf: the probabilities (denominator); pfd: after dropout (numerator)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           pf[qt].x = pack_bf16x2(acc_s[2 * kk][qt][0], acc_s[2 * kk][qt][1]);
           pf[qt].y = pack_bf16x2(acc_s[2 * kk][qt][2], acc_s[2 * kk][qt][3]);
           pf[qt].z = pack_bf16x2(acc_s[2 * kk + 1][qt][0], acc_s[2 * kk + 1][qt][1]);
           pf[qt].w = pack_bf16x2(acc_s[2 * kk + 1][qt][2], acc_s[2 * kk + 1][qt][3]);
+          pfd[qt] = pf[qt];
+          if constexpr (DROP) {
+            const int ka = kv0 + (2 * kk) * 16 + fg * 4, kb = ka + 16;
+            pfd[qt].x = pack_bf16x2(dropped(acc_s[2 * kk][qt][0], qt, ka), dropped(acc_s[2 * kk][qt][1], qt, ka + 1));
+            pfd[qt].y = pack_bf16x2(dropped(acc_s[2 * kk][qt][2], qt, ka + 2), dropped(acc_s[2 * kk][qt][3], qt, ka + 3));
+            pfd[qt].z = pack_bf16x2(dropped(acc_s[2 * kk + 1][qt][0], qt, kb), dropped(acc_s[2 * kk + 1][qt][1], qt, kb + 1));
+            pfd[qt].w = pack_bf16x2(dropped(acc_s[2 * kk + 1][qt][2], qt, kb + 2), dropped(acc_s[2 * kk + 1][qt][3], qt, kb + 3));
+          }
         }
         // transposed read: lane i of a 16-lane group supplies row (i>>2) cols 4*(i&3).., receives column i
         const int krow0 = (2 * kk) * 16 + fg * 4 + (fr >> 2);
@@ -242,8 +265,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           uint4 vf;
           const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
           vf.x = lo2.x; vf.y = lo2.y; vf.z = hi2.x; vf.w = hi2.y;
-          mma_kstep<E>(acc_o[dt][0], vf, pf[0]);
-          mma_kstep<E>(acc_o[dt][1], vf, pf[1]);
+          mma_kstep<E>(acc_o[dt][0], vf, pfd[0]);
+          mma_kstep<E>(acc_o[dt][1], vf, pfd[1]);
         }
         mma_kstep<E>(acc_l[0], ones_frag, pf[0]);
         mma_kstep<E>(acc_l[1], ones_frag, pf[1]);
@@ -254,11 +277,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;  // k-slot fg of MFMA (kt, r)
+          const float p0 = dropped(acc_s[kt][0][r], 0, kv0 + key), p1 = dropped(acc_s[kt][1][r], 1, kv0 + key);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const float vv = *reinterpret_cast<const float*>(vt_lds + lds_off<E>(key, (dt * 16 + fr) * 4));
-            acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][0][r], acc_o[dt][0], 0, 0, 0);
-            acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, acc_s[kt][1][r], acc_o[dt][1], 0, 0, 0);
+            acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p0, acc_o[dt][0], 0, 0, 0);
+            acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p1, acc_o[dt][1], 0, 0, 0);
           }
         }
     }
@@ -290,18 +314,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   }
 }
 
-template <typename E, int DHP>
-static int launch_attn(const DnAttnParams& p, hipStream_t s) {
+template <typename E, int DHP, bool DROP>
+static int launch_attn_v(const DnAttnParams& p, hipStream_t s) {
   constexpr int lds = 4 * KV_TILE * AttnGeom<E>::ROWB;  // K and V, double-buffered
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   dim3 grid((p.T + 127) / 128, p.heads, p.B);
-  hipLaunchKernelGGL((attn_kernel<E, DHP>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((attn_kernel<E, DHP, DROP>), grid, dim3(256), lds, s, p);
   DN_CHECK_LAUNCH("dn_attention");
   return DN_OK;
+}
+
+template <typename E, int DHP>
+static int launch_attn(const DnAttnParams& p, hipStream_t s) {
+  return p.dropout_p > 0.f ? launch_attn_v<E, DHP, true>(p, s) : launch_attn_v<E, DHP, false>(p, s);
 }
 
 }  // namespace dn
@@ -313,6 +342,7 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.Tk >= 0, "dn_attention: bad shape");
   DN_CHECK_ARG(!(p.lse && p.Tk > 0 && p.Tk != p.T), "dn_attention: the backward pass (lse) covers self-attention only");
   DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_attention: bad dtype");
+  DN_CHECK_ARG(p.dropout_p >= 0.f && p.dropout_p < 1.f, "dn_attention: dropout_p %g", (double)p.dropout_p);
   const int es = p.dtype == DN_BF16 ? 2 : 4;
   DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);
   DN_CHECK_ARG((p.ldq * es) % 16 == 0 && (p.ldk * es) % 16 == 0 && (p.ldv * es) % 16 == 0 && p.ldo % 4 == 0,

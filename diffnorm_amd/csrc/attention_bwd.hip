@@ -118,10 +118,12 @@ struct AttnBwdArgs {
   float scale;
   const float* lse;
   const float* delta;
+  float dropout_p;  // the forward's attention dropout: out = (P o M / (1 - p)) V, so dV uses the dropped P and dP = (dO V^T) o M / (1 - p)
+  uint32_t seed_lo, seed_hi;
 };
 
 // ------------------------------------------------------------------------------------------------------ dK, dV
-template <typename E, int DHP>
+template <typename E, int DHP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using TP = TilePair<E, DHP>;
@@ -158,6 +160,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
     out_scale = 0.f;
   }
 
+  uint32_t drop_thr = 0;
+  float drop_inv = 1.f;
+  if constexpr (DROP) {
+    drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
+    drop_inv = 1.0f / (1.0f - p.dropout_p);
+  }
   // K, V fragments (B operands): row = key
   uint4 kf[2][KS_D], vf[2][KS_D];
 #pragma unroll
@@ -229,15 +237,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
       const float4 l4 = *reinterpret_cast<const float4*>(lse_t + qt * 16 + fg * 4);
       const float4 d4 = *reinterpret_cast<const float4*>(del_t + qt * 16 + fg * 4);
       const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+      uint32_t rowh[4] = {0, 0, 0, 0};
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rowh[r] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fg * 4 + r)), p.seed_lo);
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const bool key_ok = k0 + kt * 16 + fr < len;
+        const int key = k0 + kt * 16 + fr;
+        const bool key_ok = key < len;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[qt][kt][r], sc, -lq[r]));
           pv = key_ok ? pv : 0.f;
-          acc_s[qt][kt][r] = pv;
-          acc_dp[qt][kt][r] = pv * (acc_dp[qt][kt][r] - dq_[r]);
+          float md = 1.f;  // dropout mask / (1 - p)
+          if constexpr (DROP) md = dn_drop_keep(rowh[r], (uint32_t)key, p.seed_hi, drop_thr) ? drop_inv : 0.f;
+          acc_s[qt][kt][r] = pv * md;                                      // dropped P: dV = (P o M)^T dO
+          acc_dp[qt][kt][r] = pv * (acc_dp[qt][kt][r] * md - dq_[r]);      // dS = P (dP o M - delta)
         }
       }
     }
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------------------ dQ
-template <typename E, int DHP>
+template <typename E, int DHP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using TP = TilePair<E, DHP>;
@@ -348,9 +365,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
 
   uint4 qf[2][KS_D], dof[2][KS_D];  // B operands: row = query
   float lse_q[2], del_q[2];
+  uint32_t drop_thr = 0, rowh[2] = {0, 0};
+  float drop_inv = 1.f;
+  if constexpr (DROP) {
+    drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
+    drop_inv = 1.0f / (1.0f - p.dropout_p);
+  }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     int q = q0 + qt * 16 + fr;
+    if constexpr (DROP) rowh[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + q), p.seed_lo);
     q = q < T ? q : T - 1;
     lse_q[qt] = lsep[q];
     del_q[qt] = delp[q];
@@ -409,9 +433,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kt * 16 + fg * 4 + r;
           float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, -lse_q[qt]));
-          if (straddle) pv = (kv0 + kt * 16 + fg * 4 + r) < len ? pv : 0.f;
-          acc_dp[kt][qt][r] = pv * (acc_dp[kt][qt][r] - del_q[qt]);
+          if (straddle) pv = key < len ? pv : 0.f;
+          float md = 1.f;
+          if constexpr (DROP) md = dn_drop_keep(rowh[qt], (uint32_t)key, p.seed_hi, drop_thr) ? drop_inv : 0.f;
+          acc_dp[kt][qt][r] = pv * (acc_dp[kt][qt][r] * md - del_q[qt]);
         }
     // ---- dQ^T += K^T dS^T  (contraction over the tile's 64 keys)
     if constexpr (ES == 2) {
@@ -466,22 +493,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
   }
 }
 
-template <typename E, int DHP>
-static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
+template <typename E, int DHP, bool DROP>
+static int launch_attn_bwd_v(const AttnBwdArgs& a, hipStream_t s) {
   constexpr int tile = BT * BwdGeom<E>::ROWB;
   constexpr int lds_dkv = 4 * tile + 4 * BT * (int)sizeof(float);
   constexpr int lds_dq = 4 * tile;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<E, DHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<E, DHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     attr_done = true;
   }
   dim3 grid((a.T + 127) / 128, a.heads, a.B);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<E, DHP>), grid, dim3(256), lds_dkv, s, a);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<E, DHP>), grid, dim3(256), lds_dq, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<E, DHP, DROP>), grid, dim3(256), lds_dkv, s, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<E, DHP, DROP>), grid, dim3(256), lds_dq, s, a);
   DN_CHECK_LAUNCH("dn_attention_backward");
   return DN_OK;
+}
+
+template <typename E, int DHP>
+static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
+  return a.dropout_p > 0.f ? launch_attn_bwd_v<E, DHP, true>(a, s) : launch_attn_bwd_v<E, DHP, false>(a, s);
 }
 
 }  // namespace dn
@@ -492,6 +524,7 @@ extern "C" int dn_attention_backward(const DnAttnBwdParams* pp, void* stream) {
   DN_CHECK_ARG(p.q && p.k && p.v && p.out && p.dout && p.dq && p.dk && p.dv && p.lse && p.delta, "dn_attention_backward: null tensor");
   DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.dim_head % 4 == 0, "dn_attention_backward: bad shape");
   DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_attention_backward: bad dtype");
+  DN_CHECK_ARG(p.dropout_p >= 0.f && p.dropout_p < 1.f, "dn_attention_backward: dropout_p %g", (double)p.dropout_p);
   const int es = p.dtype == DN_BF16 ? 2 : 4;
   DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention_backward: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);
   for (int ld : {p.ldq, p.ldk, p.ldv, p.ldo, p.lddo, p.lddq, p.lddk, p.lddv})
@@ -509,6 +542,7 @@ extern "C" int dn_attention_backward(const DnAttnBwdParams* pp, void* stream) {
   a.ldq = p.ldq; a.ldk = p.ldk; a.ldv = p.ldv; a.lddo = p.lddo; a.lddq = p.lddq; a.lddk = p.lddk; a.lddv = p.lddv;
   a.B = p.B; a.T = p.T; a.heads = p.heads; a.dim_head = p.dim_head; a.dtype = p.dtype;
   a.lengths = p.lengths; a.scale = p.scale; a.lse = p.lse; a.delta = p.delta;
+  a.dropout_p = p.dropout_p; a.seed_lo = p.seed_lo; a.seed_hi = p.seed_hi;
   const int dh = p.dim_head;
   if (p.dtype == DN_BF16) {
     if (dh <= 32) return dn::launch_attn_bwd<dn::BF16, 32>(a, s);

@@ -109,6 +109,19 @@ __device__ __forceinline__ float tanh_sigmoid_gate(float h) {
 
 }  // namespace dn
 
+namespace dn {
+// Attention-dropout keep decision, a counter-based hash of (seed, row = (b * heads + h) * T + query, key): the forward and both
+// backward kernels regenerate the same mask from the same seed (nothing is stored).  thr = p * 2^32: keep iff hash >= thr.
+__device__ __forceinline__ uint32_t dn_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t dn_drop_row(uint32_t row, uint32_t seed_lo) { return dn_mix32(row ^ seed_lo); }
+__device__ __forceinline__ bool dn_drop_keep(uint32_t row_hash, uint32_t key, uint32_t seed_hi, uint32_t thr) {
+  return dn_mix32(row_hash + key * 0x9E3779B9U + seed_hi) >= thr;
+}
+}  // namespace dn
+
 // host-side error plumbing (defined in capi.hip)
 void dn_set_error(const char* fmt, ...);
 #define DN_CHECK_ARG(cond, ...)  \

@@ -194,6 +194,8 @@ struct Ctx {
   float* grads;
   int64_t n_trans;
   bool frozen;          // no parameter gradients (the frozen VAE decoder inside the diffusion loss): data gradients only
+  float attn_dropout = 0.f;  // attention-probability dropout (train mode); layer l hashes with seed_hi + l
+  uint32_t seed_lo = 0, seed_hi = 0;
   int dtype, es, B, T, M;
   hipStream_t s;
   void* wg_scratch;     // weight-gradient operands + partial sums
@@ -546,6 +548,7 @@ int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave&
       a.B = B; a.T = T; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = lengths;
       a.scale = 1.0f / sqrtf((float)w.dim_head);
       a.lse = sv.lse + (size_t)l * B * w.heads * T;
+      a.dropout_p = c.attn_dropout; a.seed_lo = c.seed_lo; a.seed_hi = c.seed_hi + (uint32_t)l;
       DN_TRY(dn_attention(&a, c.s));
     }
     {  // to_out + residual (:932,692)
@@ -669,6 +672,7 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
     a.B = B; a.T = T; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = lengths;
     a.scale = 1.0f / sqrtf((float)w.dim_head);
     a.lse = sv.lse + (size_t)l * B * w.heads * T; a.delta = tb.delta;
+    a.dropout_p = c.attn_dropout; a.seed_lo = c.seed_lo; a.seed_hi = c.seed_hi + (uint32_t)l;
     DN_TRY(dn_attention_backward(&a, c.s));
   }
   {  // to_q ; to_kv (:930-931)
@@ -999,7 +1003,8 @@ extern "C" int dn_vae_train_forward(DnVaeTrain* m, const DnVaeTrainBatch* b, voi
   VaePlan pl;
   DN_TRY(check_batch(m, b, workspace, workspace_bytes, &pl, "dn_vae_train_forward"));
   hipStream_t s = (hipStream_t)stream;
-  const Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  c.attn_dropout = b->attn_dropout; c.seed_lo = b->dropout_seed_lo; c.seed_hi = b->dropout_seed_hi;
   const int dtype = c.dtype, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, zp = padk(z), V = m->cfg.vocab;
   DN_TRY(dn_convert_rows(b->feat, DN_F32, D, pl.feat_act, dtype, Dp, M, D, s));
   const void* cur = pl.feat_act;
@@ -1043,7 +1048,8 @@ extern "C" int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* b, in
   VaePlan pl;
   DN_TRY(check_batch(m, b, workspace, workspace_bytes, &pl, "dn_vae_train_backward"));
   hipStream_t s = (hipStream_t)stream;
-  const Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  Ctx c = make_ctx(m, b->B, b->T, pl, s);
+  c.attn_dropout = b->attn_dropout; c.seed_lo = b->dropout_seed_lo; c.seed_hi = b->dropout_seed_hi;
   const int dtype = c.dtype, es = c.es, M = c.M, T = c.T, D = m->cfg.dim, Dp = padk(D), z = m->cfg.z, zp = padk(z), V = m->cfg.vocab;
   const int depth = m->tf.depth;
   DN_CHECK_ARG(first_stage >= 0 && last_stage <= depth + 2 && first_stage <= last_stage, "dn_vae_train_backward: stages [%d, %d]", first_stage,
@@ -1426,7 +1432,8 @@ extern "C" int dn_eps_train_forward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsT
   EpsPlan pl;
   DN_TRY(eps_check(m, vae, b, workspace, workspace_bytes, &pl, "dn_eps_train_forward"));
   hipStream_t s = (hipStream_t)stream;
-  const Ctx c = eps_ctx(m, b->B, b->T, pl, s);
+  Ctx c = eps_ctx(m, b->B, b->T, pl, s);
+  c.attn_dropout = b->attn_dropout; c.seed_lo = b->dropout_seed_lo; c.seed_hi = b->dropout_seed_hi;
   const int dtype = c.dtype, B = b->B, T = b->T, M = c.M, D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
   const int ew = (int)std::min<int64_t>(((int64_t)M * zp + 255) / 256, 4096);
   hipLaunchKernelGGL(dn::eps_prep_kernel, dim3(ew), dim3(256), 0, s, b->z, b->jitter, b->true_noise, b->times, b->sqrt_ac, b->sqrt_1mac, b->beta0, M, T,
@@ -1491,6 +1498,7 @@ extern "C" int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEps
   DN_TRY(eps_check(m, vae, b, workspace, workspace_bytes, &pl, "dn_eps_train_backward"));
   hipStream_t s = (hipStream_t)stream;
   Ctx c = eps_ctx(m, b->B, b->T, pl, s);
+  c.attn_dropout = b->attn_dropout; c.seed_lo = b->dropout_seed_lo; c.seed_hi = b->dropout_seed_hi;
   const int dtype = c.dtype, B = b->B, T = b->T, M = c.M, D = m->cfg.dim, Dp = padk(D), zl = m->cfg.latent, zp = padk(zl);
   const int depth = m->tf.depth;
   DN_CHECK_ARG(first_stage >= 0 && last_stage <= depth + 2 && first_stage <= last_stage, "dn_eps_train_backward: stages [%d, %d]", first_stage,

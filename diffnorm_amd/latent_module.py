@@ -187,6 +187,14 @@ class Model(_ParamTree):
         return torch.add(null, logits - null, alpha=cond_scale)
 
 
+def _set_dropout(engine, p: float):
+    """Train mode of the reference's Attention(dropout=0.1) (latent_module.py:338,668): the mask's seed comes off torch's CPU
+    generator, so `torch.manual_seed` (fairseq: seed + num_updates before every update) makes a step repeatable."""
+    engine.attn_dropout = float(p)
+    if p > 0.0:
+        engine.dropout_seed, engine._dropout_calls = int(torch.randint(0, 2 ** 31 - 1, (1,))), 0
+
+
 class _VaeStepFn(torch.autograd.Function):
     """Autograd node around the HIP training engine: forward = dn_vae_train_forward (activations stay in the engine's
     workspace), backward = dn_vae_train_backward, which ADDS the parameter gradients into the flat gradient buffer that is
@@ -245,6 +253,7 @@ class SpeechVAEEncoderDecoder(_ParamTree):
         self.dim, self.latent_dim = dim, latent_dim
         self.arith = dtype
         self._train_engine = None
+        self.attn_dropout = 0.1  # Attention(dropout=0.1) of the decoder transformer (:668); active in train() mode with the training engine
         self._adopt(synthetic.random_vae_state_dict(dim, latent_dim, seed=seed))
 
     def max_positions(self):
@@ -343,6 +352,7 @@ class SpeechVAEEncoderDecoder(_ParamTree):
             lengths = _mask_to_lengths(mask)
             if ntokens is None:
                 ntokens = int(lengths.sum())
+            _set_dropout(self._train_engine, self.attn_dropout if self.training else 0.0)
             if torch.is_grad_enabled():
                 stats, logits = _VaeStepFn.apply(self.flat_params, self, input_feature, input_token, lengths, noise, ntokens)
             else:
@@ -387,6 +397,7 @@ class LatentDiscreteModel(nn.Module):
         return None
 
     _train_engine = None
+    attn_dropout = 0.1  # the eps-predictor's Attention(dropout=0.1) (:668); the frozen VAE stays in eval mode (:1530)
 
     def enable_training(self):
         """Switches the eps-predictor to the HIP diffusion training engine (diffnorm_amd/training.py::EpsTrainEngine): `self.model`
@@ -476,6 +487,7 @@ class LatentDiscreteModel(nn.Module):
                 zt = self.speech_decoder.encode_feature(audio, noise=post_noise).transpose(1, 2).contiguous()
             jn = torch.randn(zt.shape, device=dev) if jitter_noise is None else jitter_noise
             tn = torch.randn(zt.shape, device=dev) if true_noise is None else true_noise
+            _set_dropout(self._train_engine, self.attn_dropout if self.training else 0.0)
             if torch.is_grad_enabled():
                 st = _EpsStepFn.apply(self.model.flat_params, self, audio, audio_units, lengths, zt, times, jn, tn)
             else:

@@ -228,8 +228,9 @@ def _scratch(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device)
 
 
-def attention_fwd_lse(q, k, v, out, B, T, heads, dim_head, lengths, ldq=None, ldk=None, ldv=None):
-    """dn_attention that also keeps the per-query log-sum-exp [B, heads, T] for `attention_backward`."""
+def attention_fwd_lse(q, k, v, out, B, T, heads, dim_head, lengths, ldq=None, ldk=None, ldv=None, dropout_p=0.0, seed=0):
+    """dn_attention that also keeps the per-query log-sum-exp [B, heads, T] for `attention_backward`.  dropout_p > 0: train-mode
+    dropout on the probabilities with the counter-hash mask of `seed` (64 bits)."""
     lib = _lib.load()
     lse = torch.empty(B, heads, T, dtype=torch.float32, device=q.device)
     a = _lib.AttnParams()
@@ -240,11 +241,12 @@ def attention_fwd_lse(q, k, v, out, B, T, heads, dim_head, lengths, ldq=None, ld
     a.lengths = _lib.ptr(lengths)
     a.scale = dim_head ** -0.5
     a.lse = lse.data_ptr()
+    a.dropout_p, a.seed_lo, a.seed_hi = float(dropout_p), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     _lib.check(lib.dn_attention(C.byref(a), _stream()), "dn_attention")
     return out, lse
 
 
-def attention_backward(q, k, v, out, dout, lse, B, T, heads, dim_head, lengths, ld_qkv=None):
+def attention_backward(q, k, v, out, dout, lse, B, T, heads, dim_head, lengths, ld_qkv=None, dropout_p=0.0, seed=0):
     """-> (dq, dk, dv) as three column blocks of one [B*T, 3*heads*dim_head] tensor (reference :299-343 differentiated)."""
     lib = _lib.load()
     hd = heads * dim_head
@@ -263,6 +265,7 @@ def attention_backward(q, k, v, out, dout, lse, B, T, heads, dim_head, lengths, 
     a.lengths = _lib.ptr(lengths)
     a.scale = dim_head ** -0.5
     a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+    a.dropout_p, a.seed_lo, a.seed_hi = float(dropout_p), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     _lib.check(lib.dn_attention_backward(C.byref(a), _stream()), "dn_attention_backward")
     return dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:]
 

@@ -26,6 +26,19 @@ def _aligned_empty(nbytes: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return raw, raw[off: off + nbytes]
 
 
+def _dropout_fields(engine):
+    """(attn_dropout, seed_lo, seed_hi, pad) of the next forward: `engine.attn_dropout` (0 = eval mode; the reference trains with
+    0.1, latent_module.py:668) and a 64-bit counter hash of `engine.dropout_seed` and the number of dropout forwards so far, so
+    every micro-batch of every update draws its own mask.  The backward re-derives the mask from the same fields."""
+    p = float(getattr(engine, "attn_dropout", 0.0))
+    if p <= 0.0:
+        return 0.0, 0, 0, 0
+    engine._dropout_calls = getattr(engine, "_dropout_calls", 0) + 1
+    mixed = (int(getattr(engine, "dropout_seed", 0)) * 0x9E3779B97F4A7C15 + engine._dropout_calls * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+    mixed ^= mixed >> 29
+    return p, mixed & 0xFFFFFFFF, (mixed >> 32) & 0xFFFFFFFF, 0
+
+
 class VaeTrainEngine:
     """SpeechVAEEncoderDecoder training on the GPU (reference latent_module.py:1118-1142 + speech_vae_decoder_loss.py:45-95)."""
 
@@ -157,7 +170,7 @@ class VaeTrainEngine:
         recon = torch.empty(B, T, self.dim, dtype=torch.float32, device=dev) if want_recon else None
         b = _lib.VaeTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), noise.data_ptr(), B, T, int(ntokens),
                                float(weights[0]), float(weights[1]), float(weights[2]), float(label_smoothing), float(loss_scale),
-                               stats.data_ptr(), _lib.ptr(logits), _lib.ptr(recon), None)
+                               stats.data_ptr(), _lib.ptr(logits), _lib.ptr(recon), None, *_dropout_fields(self))
         self._batch, self._keep = b, (feat, units, lengths, noise, stats, logits, recon)
         wp, wn = self._workspace(B, T)
         with torch.cuda.device(dev):
@@ -314,7 +327,8 @@ class EpsTrainEngine(_FlatEngine):
         eps = torch.empty(B, T, self.cfg.latent_dim, dtype=torch.float32, device=dev) if want_eps else None
         b = _lib.EpsTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), z.data_ptr(), jitter.data_ptr(), true_noise.data_ptr(),
                                times.data_ptr(), self._sa.data_ptr(), self._s1.data_ptr(), weight.data_ptr(), self._beta0, B, T, n_units,
-                               n_frames, self.timesteps, int(self.multitask), 0.1, 50.0, float(loss_scale), stats.data_ptr(), _lib.ptr(eps))
+                               n_frames, self.timesteps, int(self.multitask), 0.1, 50.0, float(loss_scale), stats.data_ptr(), _lib.ptr(eps),
+                               *_dropout_fields(self))
         self._batch, self._keep = b, (feat, units, lengths, z, jitter, true_noise, times, weight, stats, eps)
         need = int(self.lib.dn_eps_train_workspace_bytes(self.handle, self._vae_handle(), B, T))
         wp, wn = self._ws_ptr(need)
@@ -429,8 +443,9 @@ class VaeTrainer:
 
     def __init__(self, engine: VaeTrainEngine, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-8, weight_decay: float = 0.0,
                  clip_norm: float = 2.0, warmup_updates: int = 10000, warmup_init_lr: float = 1e-7, group=None,
-                 bucket_mb: float = 64.0, adam=None):
+                 bucket_mb: float = 64.0, adam=None, attn_dropout: float = 0.1, seed: int = 1):
         self.engine = engine
+        self.attn_dropout, self.seed = float(attn_dropout), int(seed)  # train mode of the reference: Attention(dropout=0.1)
         # `adam`: anything with set_lr / step(grads, grad_scale, grad_scale_dev) -- the CPU tests of the exchange logic pass a recorder
         self.adam = adam if adam is not None else optim.Adam(
             engine.master, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm,
@@ -448,6 +463,7 @@ class VaeTrainer:
         """samples: the micro-batches of one update (update_freq), each the criterion's sample dict.
         -> (stats [8] of the last micro-batch weighted like the criterion's logging output, grad_norm) as device tensors."""
         eng, red = self.engine, self.reducer
+        eng.attn_dropout, eng.dropout_seed = self.attn_dropout, self.seed + self.num_updates  # fairseq seeds an update with seed + num_updates
         eng.zero_grad()
         totals = torch.zeros(10, dtype=torch.float32, device=eng.device)  # sum_i nsent_i * stats_i [0:8], nsentences, ntokens
         for k, sample in enumerate(samples):

@@ -169,6 +169,12 @@ typedef struct {
   int32_t pad2_;
   float* lse;         /* optional fp32 [B, heads, T]: log2-domain log-sum-exp of the scaled scores of every query
                          (max * scale * log2(e) + log2(sum)), what dn_attention_backward recomputes P from; NULL = not kept */
+  float dropout_p;    /* training only (latent_module.py:338,668: nn.Dropout(0.1) on the attention probabilities): probability of
+                         zeroing a probability; kept ones are scaled by 1 / (1 - p) AFTER the softmax normalisation.  0 = off.
+                         The keep mask is a counter-based hash of (seed, batch, head, query, key) -- dn_attention_backward
+                         regenerates it from the same seed; tests/test_hip_train_ops.py restates the hash on the host         */
+  uint32_t seed_lo, seed_hi;
+  int32_t pad3_;
 } DnAttnParams;
 
 int dn_attention(const DnAttnParams* p, void* stream);
@@ -301,7 +307,7 @@ int dn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * per-query log-sum-exp (DnAttnParams.lse); dq / dk / dv have the layout of q / k / v (row m = b*T+t, head h at columns
  * [h*dh, (h+1)*dh)) with their own row strides, so they can be three column blocks of one [M, 3*heads*dh] buffer.
  * delta: fp32 scratch [B, heads, T] (sum_d dO*O per query, written by the call).  No atomics: dk/dv and dq each have one
- * writer.  Attention dropout (p = 0.1 in the reference's training mode, :338,668) is not applied.                        */
+ * writer.  Attention dropout (p = 0.1 in the reference's training mode, :338,668): dropout_p / seed as in the forward.        */
 typedef struct {
   const void *q, *k, *v, *out, *dout;
   void *dq, *dk, *dv;
@@ -314,6 +320,9 @@ typedef struct {
   int32_t pad2_;
   const float* lse;       /* [B, heads, T] from the forward */
   float* delta;           /* [B, heads, T] scratch */
+  float dropout_p;        /* must equal the forward's (with the same seed): the mask is regenerated, not stored */
+  uint32_t seed_lo, seed_hi;
+  int32_t pad3_;
 } DnAttnBwdParams;
 int dn_attention_backward(const DnAttnBwdParams* p, void* stream);
 
@@ -491,6 +500,10 @@ typedef struct {
   const float* ext_dlogits; /* backward only, optional fp32 [B, T, vocab]: d loss / d logits supplied by the caller (a criterion
                                that differentiates the logits itself) instead of the fused LS-CE gradient; w_mse / w_kl are
                                then d loss / d mse_loss and d loss / d kl_loss                                          */
+  float attn_dropout;       /* dropout on the attention probabilities (latent_module.py:338,668: 0.1 in train mode, 0 in eval) */
+  uint32_t dropout_seed_lo, dropout_seed_hi; /* the mask is a counter hash of (seed, layer, batch, head, query, key): forward and
+                               backward of one step must be given the same seed; change it every update                    */
+  int32_t pad_;
 } DnVaeTrainBatch;
 
 int dn_vae_train_create(const DnVaeConfig* cfg, DnVaeTrain** out);
@@ -551,6 +564,9 @@ typedef struct {
   float loss_scale;
   float* stats;             /* fp32 [8] out: total_loss, nll_loss, recon_mse_loss, noise_loss, acc, n_units, 0, 0          */
   float* eps_out;           /* optional fp32 [B, T, latent]: the predicted noise                                          */
+  float attn_dropout;       /* as in DnVaeTrainBatch; applies to the eps-predictor only: the frozen VAE runs in eval mode (:1530) */
+  uint32_t dropout_seed_lo, dropout_seed_hi;
+  int32_t pad_;
 } DnEpsTrainBatch;
 
 int dn_eps_train_create(const DnEpsConfig* cfg, DnEpsTrain** out);

@@ -199,11 +199,32 @@ def rms_norm(x: Tensor, gamma: Optional[Tensor] = None, cond_wb=None, cond: Opti
     return out
 
 
-def attention(sd: SD, x: Tensor, mask: Optional[Tensor], heads: int, context: Optional[Tensor] = None) -> Tensor:
+_ATTN_DROP = None  # train mode: dict(p, which, keep) set by `attention_dropout`
+
+
+class attention_dropout:
+    """Context manager: train mode of the transformer named `which` ("vae" decoder or "eps" predictor).  The reference applies
+    nn.Dropout(0.1) to the attention probabilities (latent_module.py:338, 668) with torch's generator; a restatement cannot
+    re-draw that stream, so the keep mask is supplied: keep(layer, B, heads, T, Tk) -> bool [B, heads, T, Tk]."""
+
+    def __init__(self, which: str, p: float, keep):
+        self.cfg = dict(which=which, p=float(p), keep=keep)
+
+    def __enter__(self):
+        global _ATTN_DROP
+        self.prev, _ATTN_DROP = _ATTN_DROP, self.cfg
+
+    def __exit__(self, *exc):
+        global _ATTN_DROP
+        _ATTN_DROP = self.prev
+
+
+def attention(sd: SD, x: Tensor, mask: Optional[Tensor], heads: int, context: Optional[Tensor] = None, drop=None) -> Tensor:
     """Attention.forward + Attend.forward (non-flash): latent_module.py:934-950, 299-343.
 
-    Only keys are masked (fill -finfo.max); no biases; eval mode (no dropout).  `context` (cross-attention, :935-943): keys and
-    values come from it, `mask` then masks ITS positions.
+    Only keys are masked (fill -finfo.max); no biases; eval mode unless `drop` = (which, layer) names a transformer that an
+    enclosing `attention_dropout` put into train mode (:338).  `context` (cross-attention, :935-943): keys and values come from
+    it, `mask` then masks ITS positions.
     """
     B, T, _ = x.shape
     ctx = x if context is None else context
@@ -216,7 +237,11 @@ def attention(sd: SD, x: Tensor, mask: Optional[Tensor], heads: int, context: Op
     sim = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     if mask is not None:
         sim = sim.masked_fill(~mask.view(B, 1, 1, Tk), -torch.finfo(sim.dtype).max)
-    out = torch.matmul(sim.softmax(dim=-1), v)
+    attn = sim.softmax(dim=-1)
+    if drop is not None and _ATTN_DROP is not None and _ATTN_DROP["which"] == drop[0]:
+        keep = _ATTN_DROP["keep"](drop[1], B, heads, T, Tk)
+        attn = attn * keep.to(attn.dtype) / (1.0 - _ATTN_DROP["p"])
+    out = torch.matmul(attn, v)
     out = out.transpose(1, 2).reshape(B, T, heads * dh)
     return F.linear(out, sd["to_out.weight"])
 
@@ -234,7 +259,8 @@ def feed_forward(sd: SD, x: Tensor) -> Tensor:
     return F.linear(h, sd["3.weight"], sd["3.bias"])
 
 
-def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor], t: Optional[Tensor], context: Optional[Tensor] = None):
+def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor], t: Optional[Tensor], context: Optional[Tensor] = None,
+                which: Optional[str] = None):
     """ConditionableTransformer.forward latent_module.py:681-706; with `context` the layers carry the cross-attention block
     (:694-700: norm, attend to the resampled prompt latents without a mask, residual)."""
     for layer in range(depth):
@@ -243,7 +269,7 @@ def transformer(sd: SD, x: Tensor, depth: int, heads: int, mask: Optional[Tensor
             n1 = rms_norm(x, None, (sd[p + "0.to_gamma_beta.weight"], sd[p + "0.to_gamma_beta.bias"]), t)
         else:
             n1 = rms_norm(x, sd[p + "0.gamma"])
-        x = attention(sub(sd, p + "1."), n1, mask, heads) + x
+        x = attention(sub(sd, p + "1."), n1, mask, heads, drop=None if which is None else (which, layer)) + x
         if context is not None:
             nc = rms_norm(x, None, (sd[p + "2.to_gamma_beta.weight"], sd[p + "2.to_gamma_beta.bias"]), t)
             x = attention(sub(sd, p + "3."), nc, None, heads, context=context) + x
@@ -266,7 +292,7 @@ def eps_forward(sd: SD, cfg: EpsConfig, x: Tensor, times: Tensor, mask: Tensor) 
     h = causal_conv1d(x, sd["init_conv.weight"], sd["init_conv.bias"])  # 1x1, :734,864
     h = wavenet(sub(sd, "wavenet."), h, cfg.wavenet_stacks, cfg.wavenet_layers, t)
     h = h + positional_embedding(mask, cfg.dim)
-    h = transformer(sub(sd, "transformer."), h, cfg.depth, cfg.heads, mask, t)
+    h = transformer(sub(sd, "transformer."), h, cfg.depth, cfg.heads, mask, t, which="eps")
     return F.linear(h, sd["final_proj.weight"], sd["final_proj.bias"])
 
 
@@ -362,7 +388,7 @@ def vae_decode(sd: SD, cfg: VaeConfig, latent: Tensor, mask: Tensor):
     x = latent
     for n in range(len(cfg.chan_mults())):
         x = wavenet(sub(sd, f"decoder_wave.{n}."), x, cfg.stacks, cfg.layers)
-    dec = transformer(sub(sd, "decoder_tf."), x, cfg.depth, cfg.heads, mask, None)
+    dec = transformer(sub(sd, "decoder_tf."), x, cfg.depth, cfg.heads, mask, None, which="vae")
     return dec, F.linear(dec, sd["decoder_lm.weight"], sd["decoder_lm.bias"])
 
 

@@ -56,10 +56,10 @@ def test_struct_layout_matches_header(lib, tmp_path):
         "DnAdamParams": (_lib.AdamParams, ["lr", "beta1", "beta2", "eps", "weight_decay", "max_norm", "step", "grad_scale",
                                            "grad_scale_dev"]),
         "DnAttnParams": (_lib.AttnParams, ["q", "k", "v", "out", "ldq", "ldk", "ldv", "ldo", "B", "T", "heads", "dim_head",
-                                           "dtype", "Tk", "lengths", "scale", "lse"]),
+                                           "dtype", "Tk", "lengths", "scale", "lse", "dropout_p", "seed_lo", "seed_hi"]),
         "DnAttnBwdParams": (_lib.AttnBwdParams, ["q", "k", "v", "out", "dout", "dq", "dk", "dv", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq",
                                                  "lddk", "lddv", "B", "T", "heads", "dim_head", "dtype", "lengths", "scale", "lse",
-                                                 "delta"]),
+                                                 "delta", "dropout_p", "seed_lo", "seed_hi"]),
         "DnGaussianMoments": (_lib.GaussianMoments, ["x", "model_out", "x_start", "t", "table", "mean", "variance", "log_variance",
                                                       "pred_xstart", "vb", "reverse_sample", "N", "inner", "learned_range", "clip_denoised"]),
         "DnVaeTrainBatch": (_lib.VaeTrainBatch, ["feat", "units", "lengths", "noise", "B", "T", "ntokens", "w_lsce", "w_mse", "w_kl",

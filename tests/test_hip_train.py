@@ -108,7 +108,8 @@ def test_five_update_trajectory_matches_reference_f32(golden):
     feat, units, lens = _batch(g)
     lr, warm, warm_init, b1, b2, clip = (float(v) for v in g["hyper"])
     eng, _ = _engine("f32")
-    tr = training.VaeTrainer(eng, lr=lr, betas=(b1, b2), clip_norm=clip, warmup_updates=int(warm), warmup_init_lr=warm_init)
+    tr = training.VaeTrainer(eng, lr=lr, betas=(b1, b2), clip_norm=clip, warmup_updates=int(warm), warmup_init_lr=warm_init,
+                             attn_dropout=0.0)  # fixtures: reference in eval()
     sample = {"reduce_target": feat, "reduce_target_unit": units, "reduce_target_lengths": lens, "ntokens": int(lens.sum()),
               "nsentences": feat.shape[0]}
     traj = g["traj"]
@@ -136,6 +137,7 @@ def _plugin_objects(dtype="f32"):
     sd = O.make_vae_state_dict(CFG, "train")
     model.load_state_dict({"encoder." + k: v for k, v in sd.items()}, strict=True)
     model.to(DEV)
+    model.encoder.attn_dropout = 0.0  # the gradient fixtures were taken with the reference in eval() (oracle/gen_golden_train.py)
     return task, model, task.build_criterion(args)
 
 
@@ -295,6 +297,94 @@ def test_diffusion_gradients_bf16_follow_the_oracle(golden):
     assert dot / (n1 * n2) > 0.995 and abs(float(n1 / n2) - 1) < 5e-2
 
 
+def _grads_close(got, want, rtol):
+    total = float(torch.sqrt(sum(v.double().pow(2).sum() for v in want.values())))
+    worst = 0.0
+    for k, w in want.items():
+        err = float((got[k].double().cpu() - w.double()).abs().max())
+        scale = max(float(w.abs().max()), 1e-3 * total / max(w.numel(), 1) ** 0.5)
+        worst = max(worst, err / scale)
+        assert err <= rtol * scale, (k, err, scale)
+    return worst
+
+
+def test_train_mode_attention_dropout_vae(golden):
+    """Train mode (Attention(dropout=0.1), latent_module.py:338,668): the engine's counter-hash mask handed to the oracle's
+    autograd gives the same losses and parameter gradients -- every layer's mask, forward and backward, is the one restated in
+    oracle/dropout_mask.py; a second forward draws another mask; eval mode (p = 0) is the fixture case."""
+    from dropout_mask import layer_keep
+
+    g = golden("vae_train")
+    feat, units, lens = _batch(g)
+    noise = torch.from_numpy(g["post_noise"])
+    eng, sd = _engine("f32")
+    eng.attn_dropout, eng.dropout_seed = 0.1, 77
+    stats = eng.forward(feat, units, lens, noise=noise, ntokens=int(lens.sum()))
+    eng.zero_grad()
+    eng.backward()
+    lo, hi = eng._batch.dropout_seed_lo, eng._batch.dropout_seed_hi
+    assert (lo, hi) != (0, 0)
+    with O.attention_dropout("vae", 0.1, layer_keep(0.1, lo, hi)):
+        want_loss, want = TO.vae_loss_and_grads(sd, CFG, feat, units, lens, noise)
+    s = stats.cpu().double().numpy()
+    for i, k in enumerate(("loss", "nll_loss", "mse_loss", "kl_loss")):
+        assert abs(s[i] - want_loss[k]) <= 1e-4 * max(1.0, abs(want_loss[k])), (k, s[i], want_loss[k])
+    assert abs(s[0] - float(g["loss"])) > 1e-4  # not the eval-mode loss
+    print("train-mode VAE: worst relative gradient error vs the oracle with the same mask:", _grads_close(eng.grad_dict(), want, 1e-3))
+    again = eng.forward(feat, units, lens, noise=noise, ntokens=int(lens.sum()))
+    assert (eng._batch.dropout_seed_lo, eng._batch.dropout_seed_hi) != (lo, hi) and float(again[0]) != float(stats[0])
+    eng.attn_dropout = 0.0
+    evald = eng.forward(feat, units, lens, noise=noise, ntokens=int(lens.sum()))
+    assert abs(float(evald[0]) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+
+
+def test_train_mode_attention_dropout_diffusion(golden):
+    """The eps-predictor in train mode, the frozen VAE in eval mode (latent_module.py:1530) -- against the oracle with the mask."""
+    from dropout_mask import layer_keep
+
+    g = golden("eps_train")
+    eps, vae, esd, vsd, ecfg = _eps_setup("f32")
+    feat = seeded((3, 48, CFG.dim), 31)
+    lens, units = torch.from_numpy(g["lens"]), torch.from_numpy(g["units"])
+    mask = O.lengths_to_mask(lens, 48)
+    T = lambda k: torch.from_numpy(g[k])
+    z = O.vae_encode(vsd, CFG, feat, T("post_noise"))
+    eps.attn_dropout, eps.dropout_seed = 0.1, 5
+    stats = eps.forward(feat, units, lens, z, T("times"), T("jitter"), T("true_noise"))
+    eps.zero_grad()
+    eps.backward()
+    lo, hi = eps._batch.dropout_seed_lo, eps._batch.dropout_seed_hi
+    with O.attention_dropout("eps", 0.1, layer_keep(0.1, lo, hi)):
+        want_loss, want = TO.eps_loss_and_grads(esd, ecfg, vsd, CFG, 200, feat, units, mask, T("times"), T("post_noise"), T("jitter"),
+                                                T("true_noise"))
+    for i, k in enumerate(("total_loss", "nll_loss", "recon_mse_loss", "noise_loss")):
+        assert abs(float(stats[i]) - want_loss[k]) <= 2e-4 * max(1.0, abs(want_loss[k])), (k, float(stats[i]), want_loss[k])
+    assert abs(float(stats[0]) - float(g["loss_total_loss"])) > 1e-4
+    print("train-mode diffusion: worst relative gradient error vs the oracle with the same mask:", _grads_close(eps.grad_dict(), want, 1e-3))
+
+
+def test_module_train_eval_modes_switch_dropout(golden):
+    """nn.Module semantics: model.train() turns the attention dropout on (seeded off torch's generator, so a re-seeded step
+    repeats), model.eval() turns it off."""
+    g = golden("vae_train")
+    task, model, criterion = _plugin_objects("f32")
+    model.encoder.attn_dropout = 0.1
+    model.encoder.enable_training()
+    sample = _sample(g, torch.from_numpy(g["post_noise"]))
+    model.eval()
+    with torch.no_grad():
+        ev, _, _ = criterion(model, sample)
+        ev2, _, _ = criterion(model, sample)
+    assert float(ev) == float(ev2)  # eval: no mask, nothing drawn
+    model.train()
+    torch.manual_seed(11)
+    a, _, _ = criterion(model, sample)
+    torch.manual_seed(11)
+    b, _, _ = criterion(model, sample)
+    c, _, _ = criterion(model, sample)
+    assert float(a) == float(b) and float(a) != float(c) and float(a) != float(ev)
+
+
 def test_plugin_diffusion_train_step_matches_reference(golden):
     """--task speech_diffusion_discrete --criterion ddpm_discrete_loss --arch diff_discrete: task.train_step through the plugin
     (criterion -> DiffDiscreteModel -> LatentDiscreteModel.forward -> HIP diffusion engine, loss.backward() = the HIP backward)
@@ -318,6 +408,7 @@ def test_plugin_diffusion_train_step_matches_reference(golden):
     model.load_state_dict(full, strict=True)
     model.to(DEV)
     criterion = task.build_criterion(args)
+    model.encoder.attn_dropout = 0.0  # fixtures: reference in eval()
     eng = model.encoder.enable_training()
     assert set(model.state_dict()) == set(full)
     assert [n for n, p in model.named_parameters() if p.requires_grad] == ["encoder.model.flat_params"]

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import diffnorm_oracle as O
+from dropout_mask import dropout_keep_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +89,55 @@ def test_attention_backward(ops, dtype, heads, dh, B, T, lens):
     # bit-reproducible (no atomics)
     dq2, dk2, dv2 = ops_.attention_backward(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, doa, lse, B, T, heads, dh, l32, ld_qkv=3 * hd)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("heads,dh,B,T,lens,p", [(4, 16, 3, 40, [40, 23, 1], 0.1), (2, 64, 2, 150, [150, 77], 0.1), (8, 64, 2, 200, [130, 200], 0.1),
+                                                 (2, 64, 1, 300, [257], 0.5), (2, 32, 2, 64, [64, 0], 0.25)])
+def test_attention_dropout_forward_backward(ops, dtype, heads, dh, B, T, lens, p):
+    """Train mode of Attend (latent_module.py:338: attn = dropout(softmax(sim)); out = attn @ v): the kernels' counter-hash mask,
+    restated on the host, put into the float64 reference -- forward and the three gradients agree, the drop rate is p, and the
+    backward re-derives the very mask the forward used."""
+    ops_, packing, _lib = ops
+    hd = heads * dh
+    seed = 0x1234ABCD5678EF01 + T
+    rnd = bf16r if dtype == "bf16" else (lambda t: t)
+    q, k, v, do = (rnd(seeded((B, T, hd), 60 + i)) for i in range(4))
+    lens_t = torch.tensor(lens)
+    keep = dropout_keep_mask(B, heads, T, T, p, seed)
+    valid = O.lengths_to_mask(lens_t, T).view(B, 1, 1, T).expand(B, heads, T, T)
+    rate = 1.0 - keep[valid].double().mean().item()
+    assert abs(rate - p) < 4 * (p * (1 - p) / max(int(valid.sum()), 1)) ** 0.5 + 1e-3, rate
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    split = lambda t: t.view(B, T, heads, dh).transpose(1, 2)
+    sim = torch.einsum("bhid,bhjd->bhij", split(qd), split(kd)) * dh ** -0.5
+    sim = sim.masked_fill(~valid, -torch.finfo(sim.dtype).max)
+    attn = sim.softmax(dim=-1) * keep.double() / (1.0 - p)
+    want_o = torch.einsum("bhij,bhjd->bhid", attn, split(vd)).transpose(1, 2).reshape(B, T, hd)
+    want_o.backward(do.double())
+    qkv = act(torch.cat([q, k, v], dim=-1).view(B * T, 3 * hd), dtype)
+    out = torch.empty(B * T, hd, dtype=qkv.dtype, device=DEV)
+    l32 = lens_t.to(DEV, torch.int32)
+    args = (B, T, heads, dh, l32)
+    _, lse = ops_.attention_fwd_lse(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, *args, ldq=3 * hd, ldk=3 * hd, ldv=3 * hd, dropout_p=p, seed=seed)
+    live = torch.tensor([n > 0 for n in lens]).view(B, 1, 1)
+    sel = (live & torch.ones(B, T, 1, dtype=torch.bool)).expand(B, T, hd)  # an empty sequence has no defined softmax: real ones only
+    tol_f = 2e-5 if dtype == "f32" else 1.5e-2
+    assert relerr(out.float().view(B, T, hd).cpu()[sel], want_o.detach()[sel]) < tol_f
+    # the log-sum-exp is that of the undropped softmax: same as without dropout
+    out0 = torch.empty_like(out)
+    _, lse0 = ops_.attention_fwd_lse(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out0, *args, ldq=3 * hd, ldk=3 * hd, ldv=3 * hd)
+    assert torch.equal(lse, lse0) and not torch.equal(out, out0)
+    doa = act(do.view(B * T, hd), dtype)
+    dq, dk, dv = ops_.attention_backward(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, doa, lse, *args, ld_qkv=3 * hd, dropout_p=p, seed=seed)
+    tol = 1e-4 if dtype == "f32" else 2.5e-2
+    for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        e = relerr(got.float().reshape(B, T, hd).cpu()[sel], want[sel])
+        assert e < tol, (name, e)
+    # another seed is another mask
+    out2 = torch.empty_like(out)
+    ops_.attention_fwd_lse(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out2, *args, ldq=3 * hd, ldk=3 * hd, ldv=3 * hd, dropout_p=p, seed=seed + (1 << 32))
+    assert not torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
