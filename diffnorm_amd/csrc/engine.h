@@ -69,15 +69,17 @@ constexpr int kWavenetTensors = 12;
 //   ffconv_W [depth][3][padn(inner)][padk(inner)]                   ffconv_b [depth][padk(inner)]
 //   ffconv_Wkb: the same weights K-blocked, [depth][3][padk(inner)/32][padn(inner)][32] (bf16; DN_LAYOUT_W_KBLOCKED) -- the
 //               form the 256 x 352 tile stages as whole cache lines; any pointer (unused) in f32 mode
+//   ffin_Wkb: ffin_W K-blocked, [depth][padk(D)/32][2*padk(inner)][32] (bf16) -- used when the GEGLU projection lands on the
+//               256 x 256 tile: the split norm's producer then writes its activations K-blocked too (norm_split = 2)
 //   ffout_W [depth][padn(D)][padk(inner)]                           ffout_b [depth][padk(D)]
 //   g1, g2 [depth][D] learned RMSNorm gammas (NULL when time-conditioned)
 //   pred_gamma [D]   pred_W [padn(D)][padk(D)]
 struct TransformerW {
   int dim, depth, heads, dim_head, inner;
-  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W, *ffconv_Wkb;
+  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W, *ffconv_Wkb, *ffin_Wkb;
   const float *ffin_b, *ffconv_b, *ffout_b, *g1, *g2, *pred_gamma;
 };
-constexpr int kTransformerTensors = 13;
+constexpr int kTransformerTensors = 14;
 
 }  // namespace dn
 

@@ -201,6 +201,16 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     return dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, ns.gamma, ns.gb, gb_ld, Dp, s);
   };
   if (!((fuse || split) && xn_ready)) DN_TRY(standalone_norm(0, 0));
+  // The GEGLU projection (K = dim: 16 K-tiles of 64-byte row pieces on the 256 x 256 tile) reads the feed-forward norm's output and
+  // nothing else does: with the split norm its producer (the attention-out contraction) can write row * gamma K-blocked, and the
+  // projection then stages whole cache lines from it and from a K-blocked copy of its weights.
+  bool geglu_kb = false;
+  static const bool geglu_kb_off = getenv("DN_GEGLU_KB") && atoi(getenv("DN_GEGLU_KB")) == 0;  // A/B timing
+  if (!geglu_kb_off && split && !fuse && kblock_mode() != 0 && dtype == DN_BF16 && w.ffin_Wkb && Dp % 32 == 0) {
+    DnGemmParams q = gemm_base(dtype, M, ip, Dp, T);
+    q.epilogue = DN_EPI_GEGLU;
+    geglu_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
+  }
   for (int l = 0; l < w.depth; ++l) {
     {  // to_q ; to_kv in one contraction (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
@@ -225,6 +235,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       const NormSrc ns = norm_src(w, gb, l, 1);
       if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      if (geglu_kb) p.norm_split = 2;  // row * gamma goes out K-blocked: its only reader is the GEGLU projection below
       DN_TRY(dn_conv_gemm(&p, s));
     }
     if (!fuse && !split) DN_TRY(standalone_norm(l, 1));
@@ -250,6 +261,10 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     {  // Linear(D -> 2*inner) + GEGLU (:899,881-884)
       DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
+      if (geglu_kb) {
+        p.terms[0].W = eoff(w.ffin_Wkb, (size_t)l * 2 * ip * Dp, es);
+        p.terms[0].layout = DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED;
+      }
       p.bias = w.ffin_b + (size_t)l * 2 * ip;
       p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
       p.out_layout = kblocked ? DN_LAYOUT_OUT_KBLOCKED : 0;
@@ -290,7 +305,7 @@ const void* const* take_transformer(TransformerW& w, const void* const* t) {
   w.qkv_W = t[0]; w.out_W = t[1]; w.ffin_W = t[2]; w.ffin_b = (const float*)t[3]; w.ffconv_W = t[4];
   w.ffconv_b = (const float*)t[5]; w.ffout_W = t[6]; w.ffout_b = (const float*)t[7];
   w.g1 = (const float*)t[8]; w.g2 = (const float*)t[9]; w.pred_gamma = (const float*)t[10]; w.pred_W = t[11];
-  w.ffconv_Wkb = t[12];
+  w.ffconv_Wkb = t[12]; w.ffin_Wkb = t[13];
   return t + kTransformerTensors;
 }
 

@@ -465,8 +465,10 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
           if (p.norm_split) {  // split norm, producer side: row * gamma for the consuming contraction + this slab's sum of squares
             float4 ga = split_gamma;
             if (p.norm_gb && p.norm_gb_ld) ga = *reinterpret_cast<const float4*>(p.norm_gb + (int64_t)(m / p.T) * p.norm_gb_ld + n);
-            if (p.norm_dtype == DN_BF16) store4t<true>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
-            else store4t<false>(p.norm_out, (int64_t)m * p.norm_ld + n, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
+            // norm_split == 2: K-blocked [norm_ld/32][M][32] for a consumer that stages whole cache lines (a lane's 4 columns stay in one block)
+            const int64_t noff = p.norm_split == 2 ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.norm_ld + n;
+            if (p.norm_dtype == DN_BF16) store4t<true>(p.norm_out, noff, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
+            else store4t<false>(p.norm_out, noff, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             float q = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;  // the row's 16 lanes are lanes (lane & ~15) .. +15
             q = row16_sum(q);
             if ((lane & 15) == 0) p.norm_ssq[(int64_t)m * p.norm_ssq_ld + (n_base >> 6)] = q;
@@ -1783,6 +1785,8 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
   if (p.epilogue == DN_EPI_FILM_GATE && p.gamma_beta) DN_CHECK_ARG(p.gb_half % 4 == 0 && p.gb_ld % 4 == 0, "dn_conv_gemm: gamma_beta strides must be multiples of 4");
   if (p.norm_split) {
     DN_CHECK_ARG(p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB, "dn_conv_gemm: norm_split needs a RESADD or POSEMB epilogue");
+    DN_CHECK_ARG(p.norm_split == 1 || (p.norm_split == 2 && p.norm_dtype == DN_BF16 && p.norm_ld % 32 == 0),
+                 "dn_conv_gemm: norm_split=%d (2 = K-blocked bf16 norm_out, norm_ld a multiple of 32)", p.norm_split);
     DN_CHECK_ARG(p.norm_out && p.norm_ssq && p.N % 64 == 0 && p.norm_ld % 4 == 0 && p.norm_ld >= p.N && p.norm_ssq_ld * 64 >= p.N,
                  "dn_conv_gemm: norm_split needs norm_out, norm_ssq and N a multiple of 64 (N=%d)", p.N);
     DN_CHECK_ARG(p.norm_dtype == DN_F32 || p.norm_dtype == DN_BF16, "dn_conv_gemm: bad norm_dtype");

@@ -1472,7 +1472,7 @@ extern "C" int dn_eps_train_forward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsT
   hipLaunchKernelGGL(dn::eps_post_kernel, dim3((M + 3) / 4), dim3(256), 0, s, pl.eps, b->true_noise, pl.xt, b->times, b->sqrt_ac, b->sqrt_1mac,
                      b->snr_weight, b->lengths, g_noise, M, T, zl, zp, pl.rows, pl.d_eps, pl.x1_act, dtype);
   DN_TRY(dn_colsum(pl.rows, 4, DN_F32, B, T, 4, pl.noise_b, 4, 1.0f, 0, pl.red_scratch, s));
-  hipMemsetAsync(pl.sums, 0, 64 * 4, s);
+  (void)hipMemsetAsync(pl.sums, 0, 64 * 4, s);
   if (b->multitask) {  // x1_hat through the frozen VAE decoder (:1574-1596)
     const Ctx vc = make_ctx(vae, B, T, pl.vae, s, true);
     const int V = vae->cfg.vocab, Dv = vae->cfg.dim;
@@ -1506,7 +1506,7 @@ extern "C" int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEps
   const int ew = (int)std::min<int64_t>(((int64_t)M * zp + 255) / 256, 4096);
   for (int stage = first_stage; stage <= last_stage; ++stage) {
     if (stage == 0) {
-      hipMemsetAsync(pl.d_gb, 0, (size_t)B * m->n_cond * 4, s);
+      (void)hipMemsetAsync(pl.d_gb, 0, (size_t)B * m->n_cond * 4, s);
       const float* dx1 = nullptr;
       if (b->multitask) {  // d total / d x1_hat: the frozen decoder's data gradients (no parameter gradients)
         const Ctx vc = make_ctx(vae, B, T, pl.vae, s, true);

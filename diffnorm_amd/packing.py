@@ -139,6 +139,8 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
         g("to_pred.0.gamma").float().clone(), _mat(g("to_pred.1.weight"), dtype),
         # the FFN conv weights once more, K-blocked, for the 256 x 352 tile (bf16 only; a placeholder in f32 mode)
         kblock(torch.stack(ffc)) if dtype == _lib.DN_BF16 else dummy.clone(),
+        # the GEGLU projection's packed weights K-blocked (its activations arrive K-blocked from the split norm's producer)
+        kblock(torch.stack(ffin)) if dtype == _lib.DN_BF16 else dummy.clone(),
     ]
 
 

@@ -122,6 +122,7 @@ typedef struct {
    * it, so no separate pass over the residual stream remains (x/|x| * sqrt(D) * g + b feeding a Linear W equals
    * (sqrt(D)/|x|) * ((x*g) W^T) + b W^T).
    * Producer (RESADD / POSEMB, N a multiple of 64, any tile): norm_split != 0 makes norm_out receive out_row * gamma
+   * (norm_split == 2: in the K-blocked layout [norm_ld/32][M][32], bf16 -- for a consumer that takes DN_LAYOUT_A_KBLOCKED)
    * (norm_gamma, or the gamma half of norm_gb per sample) WITHOUT the 1/|row| factor, and norm_ssq[m, n/64] the sum of
    * squares of the 64 output columns of row m that one wave produced (no atomics: the consumer adds the partials).
    * Consumer (BIAS / SILU / GEGLU): row_ssq != NULL makes out = acc * sqrt(row_D) / max(sqrt(sum_j row_ssq[m, j]), 1e-12)
