@@ -89,6 +89,18 @@ def traffic_from_profiles():
         return None
 
 
+def train_traffic_from_profiles():
+    """Fabric-side bytes per launch of the training leg's roofline kernel from the committed PMC passes
+    (profiles/*pmc_train_wgrad*.json, tools/collect_traffic_r02.sh); None when absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_train_wgrad*.json")))
+    try:
+        return json.load(open(files[-1]))["hbm_bytes_per_launch"] if files else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def step_traffic_from_profiles():
     """Fabric-side bytes of one denoising step at [32,512] bf16 from the committed PMC passes (profiles/*pmc_step_traffic*.json,
     tools/collect_step_traffic.sh); None when absent."""
@@ -467,7 +479,7 @@ def run_training(args, ctx):
                                                     f"[{roof[3]} x 6144] over the padded frames, accumulated into the fp32 gradient",
                          "achieved": roof[0] / (roof[1] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                          "frac": roof[0] / (roof[1] * 1e-3) / 1e12 / peak, "flops_per_launch": roof[0], "avg_launch_ms": roof[1],
-                         "launches_timed": roof[2], "traffic": None},
+                         "launches_timed": roof[2], "traffic": train_traffic_from_profiles()},
         }
         print(json.dumps(result), flush=True)
 

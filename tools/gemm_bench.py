@@ -91,6 +91,10 @@ if only == "kblock256":  # the 256 x 256 tile's shapes, row-major vs K-blocked, 
             shape("ffn_in GEGLU 512->2x1365", 512, 1365, epi=_lib.EPI_GEGLU, count=12, kb=kb)
             shape("qkv 512->1536", 512, 1536, count=12, kb=kb)
     sys.exit(0)
+if only == "sizes":  # how the causal-conv contraction scales with channel width on each tile variant (DN_BENCH_TILE)
+    for width in (1024, 1365, 1408, 1536, 2048, 2731):
+        shape(f"conv k3 {width}->{width}", width, width, taps=3)
+    sys.exit(0)
 if only == "kblock":
     for a_kb, w_kb in ((False, False), (True, False), (False, True), (True, True)) + ((False, False), (True, True)) * 4:
         ffn_kblocked(a_kb, w_kb)
