@@ -1293,24 +1293,32 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
   uint32_t tap_delta = 0, tap_delta0 = 0, tap_dstep = 0;  // bytes between the unshifted row and the tap's row
   uint64_t tap_wbase = 0, tap_wbase0 = 0;
   int64_t tap_wstride = 0;
+  int tap_akinc = ROWB2;  // bytes from a K-chunk of an activation row to the next
   auto setup_taps = [&]() {
     const DnGemmTerm& t0 = p.terms[0];
     const DnGemmTerm& t1 = p.terms[1];
     const int sh0 = t0.shift_by_group ? (t0.shift << g) : t0.shift, sh1 = t1.shift_by_group ? (t1.shift << g) : t1.shift;
+    // K-blocked operands ([K/32][rows][32], the same layout in every tap: launch_fat checks): rows 64 bytes apart, the next K-chunk a block away
+    const bool a_kb = t0.layout & DN_LAYOUT_A_KBLOCKED, w_kb = t0.layout & DN_LAYOUT_W_KBLOCKED;
+    const uint32_t a_rowb = a_kb ? (uint32_t)ROWB2 : (uint32_t)(t0.lda * ES);
+    const uint32_t w_rowb = w_kb ? (uint32_t)ROWB2 : (uint32_t)(p.K * ES);
     tap_shift0 = sh0; tap_sstep = sh0 - sh1;
-    tap_delta0 = (uint32_t)sh0 * (uint32_t)(t0.lda * ES); tap_dstep = (uint32_t)tap_sstep * (uint32_t)(t0.lda * ES);
-    tap_wbase0 = (uint64_t)(uintptr_t)t0.W + ((uint64_t)t0.w_gstride * g + (uint64_t)n0 * p.K) * ES;
+    tap_delta0 = (uint32_t)sh0 * a_rowb; tap_dstep = (uint32_t)tap_sstep * a_rowb;
+    tap_wbase0 = (uint64_t)(uintptr_t)t0.W + (uint64_t)t0.w_gstride * g * ES + (uint64_t)n0 * w_rowb;
     tap_wstride = (int64_t)((uintptr_t)t1.W - (uintptr_t)t0.W);
     tap_shift = tap_shift0; tap_delta = tap_delta0; tap_wbase = tap_wbase0;
+    tap_akinc = a_kb ? p.M * ROWB2 : ROWB2;
+    w_step = w_kb ? (uint32_t)w_rows * ROWB2 : ROWB2;
+    piece_stride = (uint64_t)16 * w_rowb;
     const char* A = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + schunk * 16;
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
       int m = m0 + (wave * APW + i) * 16 + srow;
       m = m < p.M ? m : p.M - 1;
-      a_ptr[i] = A + (int64_t)m * t0.lda * ES;
+      a_ptr[i] = A + (int64_t)m * a_rowb;
       a_inc[i] = m % p.T;
     }
-    w_voff = (uint32_t)(srow * p.K * ES + schunk * 16);
+    w_voff = (uint32_t)(srow * w_rowb + schunk * 16);
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces.  Two halves (M0 <- LDS address,
@@ -1361,10 +1369,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
       tap_shift = wrap ? tap_shift0 : tap_shift - tap_sstep;
       tap_delta = wrap ? tap_delta0 : tap_delta - tap_dstep;
       tap_wbase = wrap ? tap_wbase0 : tap_wbase + tap_wstride;
-      const int inc = wrap ? ROWB2 : 0;
+      const int inc = wrap ? tap_akinc : 0;
 #pragma unroll
       for (int i = 0; i < APW; ++i) a_ptr[i] += inc;
-      w_voff += inc;
+      w_voff += wrap ? w_step : 0u;
     } else {
       if (++s_kk == ktiles_per_term) {
         s_kk = 0;
@@ -1643,13 +1651,16 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + 255) / 256) * ((np + BNF - 1) / BNF), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
-  // Tap-inner K order (see the kernel): opt-in -- DN_FAT_TAPS_INNER=1 or bit 22 of pad_ -- because it changes the fp32
-  // summation order, and with it the last bits, relative to every other tile variant (which are all term-outer and
-  // therefore bit-identical to each other: shards of a batch that fall on different variants give identical units).
-  // Needs the taps of one causal conv: same activation tensor, shifts and weight addresses in arithmetic progression.
-  static const bool env_taps = getenv("DN_FAT_TAPS_INNER") && atoi(getenv("DN_FAT_TAPS_INNER")) != 0;
-  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && (env_taps || ((p.pad_ >> 22) & 1));
-  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == 0 && p.terms[i].shift >= 0;
+  // Tap-inner K order (see the kernel) is what this tile runs for the taps of one causal conv (same activation tensor, shifts
+  // and weight addresses in arithmetic progression): the activation panel crosses the fabric once instead of once per tap
+  // (234 -> 142 MB read per FFN-conv launch at [32,512]; +0.9 % per denoising step measured in the chain).  It changes the fp32
+  // summation order, and with it the last bits, relative to the other tile variants (all term-outer, bit-identical to each
+  // other): a batch large enough to route here (>= 100 tiles, M >= 6400 at the eps-predictor's width) and a smaller one do not
+  // agree to the last bit; equal-size shards do.  DN_FAT_TAPS_INNER=0 or bit 23 of pad_ restores term-outer (bit 22: force on).
+  const char* env_order = getenv("DN_FAT_TAPS_INNER");  // read per launch (host side): tests switch it
+  const bool env_taps = !(env_order && atoi(env_order) == 0);
+  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && !((p.pad_ >> 23) & 1) && (env_taps || ((p.pad_ >> 22) & 1));
+  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == p.terms[0].layout && p.terms[i].shift >= 0;
   for (int i = 1; i < p.n_terms && taps; ++i) {
     const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
     taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&

@@ -31,7 +31,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               gb_half: int = 0, pos_table: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
               shift_by_group: bool = False, a_grouped: bool = True, norm_out: Optional[torch.Tensor] = None,
               norm_D: int = 0, norm_gamma: Optional[torch.Tensor] = None, norm_gb: Optional[torch.Tensor] = None,
-              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: bool = False,
+              norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: Optional[bool] = None,
               norm_ssq: Optional[torch.Tensor] = None, row_ssq: Optional[torch.Tensor] = None, row_D: int = 0,
               row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False, a_kblocked: bool = False,
               w_kblocked: bool = False, out_kblocked: bool = False):
@@ -93,7 +93,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
             assert row_bias.dtype == torch.float32
             p.row_bias = row_bias.data_ptr()
             p.row_bias_ld = 0 if row_bias_shared else row_bias.stride(0)
-    p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16) | (int(taps_inner) << 22)  # ablation switches (tools/gemm_bench.py) | forced tile / K order (tests)
+    p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16) | (0 if taps_inner is None else (1 << 22) if taps_inner else (1 << 23))  # ablation switches (tools/gemm_bench.py) | forced tile / K order (tests; None = the library's default)
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out
 

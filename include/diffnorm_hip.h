@@ -105,9 +105,10 @@ typedef struct {
                           used bits 0..3 are compile-time now: -DDN_GEMM_ABL); 0 in every product call; bits 8..15: launch tag
                           (DN_TAG_*) matched by dn_profile_start; bits 16..19: force a tile variant (tests: 1 = 128x128,
                           2 = 256x128, 3 = 256x256, 4 = 256x352 when N % 352 == 0, 6 / 7 = hand-scheduled 256x256 with one / two waves per SIMD [bf16]),
-                          0 = chosen from the shape; bit 22: let the
-                          256x352 tile run the taps of a causal conv innermost in K (fewer fabric re-reads of the
-                          activation panel; changes the fp32 summation order, so off unless asked for)          */
+                          0 = chosen from the shape; bits 22 / 23: force the
+                          256x352 tile's K order for the taps of a causal conv -- 22 = taps innermost (its default: the
+                          activation panel crosses the fabric once, not once per tap), 23 = term-outer (the summation
+                          order of every other tile variant)                                                     */
   const int32_t* lengths; /* POSEMB: [B] valid frames per sequence                                  */
   /* RESADD / POSEMB with N <= 512 only: when norm_out != NULL one workgroup owns whole output rows and also emits
    * the NEXT block's RMSNorm of the row it just produced (latent_module.py:620-639, 691, 703):

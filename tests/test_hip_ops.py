@@ -99,7 +99,7 @@ def test_causal_conv_gemm_every_tile_variant(ops, dtype, tile, cin, cout, k, dil
     out = torch.full((B * T, N), float("nan"), device=DEV)
     bias = packing._vec(b, W.shape[1]).to(DEV)
     terms = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
-    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4 if tile == 5 else tile, taps_inner=tile == 5)
+    ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4 if tile == 5 else tile, taps_inner=tile == 5)  # tile 4: term-outer forced
     got = out.cpu().view(B, T, -1)
     if tile > 1:  # every term-outer variant sums K in the same order: bit-identical outputs
         ref_out = torch.empty_like(out)
@@ -295,12 +295,16 @@ def test_random_shapes_every_variant_bit_identical(ops):
         outs = {}
         for tile in (1, 2, 3, 6, 7) + ((4,) if cout % 352 == 0 else ()):
             out = torch.full((B * T, cout), float("nan"), device=DEV)
-            ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=tile)
+            ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=tile, taps_inner=False)  # the hand-scheduled tiles: term-outer forced
             outs[tile] = out
         ref = O.causal_conv1d(bf16r(x), bf16r(w), b, dil)
         assert maxerr(outs[1].cpu().view(B, T, -1), ref) < 3e-4, (case, k, cin, cout, B, T, dil)
         for tile, o in outs.items():
             assert torch.equal(o, outs[1]), (case, tile, k, cin, cout, B, T, dil)
+        if cout % 352 == 0:  # the 256x352 tile's own K order (taps innermost): another fp32 summation order, the same sum
+            out = torch.full((B * T, cout), float("nan"), device=DEV)
+            ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=4)
+            assert maxerr(out.cpu(), outs[1].cpu()) < 1e-5 * max(1.0, outs[1].abs().max().item()), (case, k, cin, cout, B, T, dil)
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (1408, 1408, 3, 1, 4, 512),
@@ -318,14 +322,22 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
     bias = packing._vec(b, W.shape[1]).to(DEV)
     xb, Wb = packing.kblock(xa), packing.kblock(W)
     assert torch.equal(packing.unkblock(xb), xa)
-    ref = torch.empty((B * T, N), device=DEV)
-    ops_.conv_gemm([(xa, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=4)
-    for a_kb, w_kb in ((True, False), (False, True), (True, True)):
-        out = torch.full((B * T, N), float("nan"), device=DEV)
-        terms = [(xb if a_kb else xa, (Wb if w_kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
-        ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4, a_kblocked=a_kb, w_kblocked=w_kb)
-        assert torch.equal(out, ref), (a_kb, w_kb)
-    out = torch.full((B * T, N), float("nan"), device=DEV)  # the 256x256 tile takes them too
+    rowmajor = [(xa, W[j], (k - 1 - j) * dil) for j in range(k)]
+    refs = {}
+    for inner in (True, False):  # both K orders of the tile: taps innermost (its default for a causal conv) and term-outer
+        refs[inner] = torch.empty((B * T, N), device=DEV)
+        ops_.conv_gemm(rowmajor, refs[inner], T, N, bias=bias, tile=4, taps_inner=inner)
+        for a_kb, w_kb in ((True, False), (False, True), (True, True)):
+            out = torch.full((B * T, N), float("nan"), device=DEV)
+            terms = [(xb if a_kb else xa, (Wb if w_kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
+            ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4, a_kblocked=a_kb, w_kblocked=w_kb, taps_inner=inner)
+            assert torch.equal(out, refs[inner]), (inner, a_kb, w_kb)
+    ref = refs[False]
+    assert maxerr(refs[True].cpu(), ref.cpu()) < 1e-5 * max(1.0, ref.abs().max().item())
+    dflt = torch.empty((B * T, N), device=DEV)  # no order forced: taps innermost when there is more than one tap
+    ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], dflt, T, N, bias=bias, tile=4, a_kblocked=True, w_kblocked=True)
+    assert torch.equal(dflt, refs[k > 1])
+    out = torch.full((B * T, N), float("nan"), device=DEV)  # the 256x256 tile takes them too (term-outer)
     ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], out, T, N, bias=bias, tile=3, a_kblocked=True, w_kblocked=True)
     assert torch.equal(out, ref)
     with pytest.raises(RuntimeError, match="K-blocked"):
