@@ -13,6 +13,8 @@
 // 16-lane group).  In f32 mode each v_mfma_f32_16x16x4_f32 takes one P register and one scalar LDS
 // read of V.  LDS rows are 256 B (bf16) / 512 B (f32) with an XOR swizzle that makes the K row reads,
 // the V transposed reads and the f32 scalar reads bank-conflict-free (see lds_off).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -52,10 +54,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int qblk, h, b;
+  if (p.pad3_ & 1) { qblk = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }  // A/B timing only (DN_ATTN_XCD=0): dispatch order
+  else dn_xcd_block_map(qblk, h, b);
   const int T = p.T, dh = p.dim_head;
   const int Tk = p.Tk > 0 ? p.Tk : T;  // cross-attention: the keys are another sequence of Tk rows per batch element
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qblk * 128 + wave * 32;
   const int dhb = dh * ES;  // valid bytes per head row
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
@@ -337,7 +341,11 @@ static int launch_attn(const DnAttnParams& p, hipStream_t s) {
 
 extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   DN_CHECK_ARG(pp != nullptr, "dn_attention: null params");
-  const DnAttnParams& p = *pp;
+  DnAttnParams p = *pp;
+  {
+    const char* e = getenv("DN_ATTN_XCD");
+    p.pad3_ = e && atoi(e) == 0 ? 1 : 0;
+  }
   DN_CHECK_ARG(p.q && p.k && p.v && p.out, "dn_attention: null tensor");
   DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.Tk >= 0, "dn_attention: bad shape");
   DN_CHECK_ARG(!(p.lse && p.Tk > 0 && p.Tk != p.T), "dn_attention: the backward pass (lse) covers self-attention only");

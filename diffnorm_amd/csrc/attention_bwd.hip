@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int rblk, h, b;  // this workgroup's row block of (batch b, head h), XCD-aware order
+  dn_xcd_block_map(rblk, h, b);
   const int T = p.T, dh = p.dim_head;
-  const int k0 = blockIdx.x * 128 + wave * 32;  // this wave's 32 keys
+  const int k0 = rblk * 128 + wave * 32;  // this wave's 32 keys
   const int dhb = dh * ES;
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
@@ -341,9 +342,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int rblk, h, b;  // this workgroup's row block of (batch b, head h), XCD-aware order
+  dn_xcd_block_map(rblk, h, b);
   const int T = p.T, dh = p.dim_head;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = rblk * 128 + wave * 32;
   const int dhb = dh * ES;
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;

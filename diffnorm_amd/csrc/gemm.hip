@@ -728,7 +728,12 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
 // Schedule: the same staggered two-group L / C segments as above, one K-tile per segment pair.
 constexpr int ROWB2 = 64;
 
-template <typename E, int EPI>
+// TAPS: the terms are the taps of ONE causal conv (launch_big checks: same activation tensor and layout, shifts and weight
+// addresses in arithmetic progression) and run innermost in K -- K-tile n is tap n % n_terms of K-chunk n / n_terms, the order of
+// the 256 x 352 tile (same 32-deep K-tiles: bit-identical to it), so the taps of a chunk read (nearly) the same activation rows
+// back to back and the XCD's L2 serves all but one of them: the dilated WaveNet conv's activation panels cross the fabric once
+// instead of three times (measured 516 MB of reads per launch at [32,512], 402 MB of them the panels).
+template <typename E, int EPI, bool TAPS>
 __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
@@ -793,10 +798,53 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
       w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
     }
   };
+  // tap-inner: the per-tap uniforms are affine in the tap index and carried as running scalars (a_ptr / w_ptr then hold the
+  // UNSHIFTED row and tap 0's weight row of the current K-chunk, a_t the frame index that decides the zero page per tap)
+  int tap_shift = 0, tap_shift0 = 0, tap_sstep = 0;
+  int64_t tap_delta = 0, tap_delta0 = 0, tap_dstep = 0, tap_woff = 0, tap_wstride = 0;
+  int tap_ainc = ROWB2;
+  auto setup_taps = [&]() {
+    const DnGemmTerm& t0 = p.terms[0];
+    const DnGemmTerm& t1 = p.terms[1];
+    const int sh0 = t0.shift_by_group ? (t0.shift << g) : t0.shift, sh1 = t1.shift_by_group ? (t1.shift << g) : t1.shift;
+    const bool a_kb = t0.layout & DN_LAYOUT_A_KBLOCKED, w_kb = t0.layout & DN_LAYOUT_W_KBLOCKED;
+    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)t0.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)p.K * ES;
+    tap_shift0 = sh0; tap_sstep = sh0 - sh1;
+    tap_delta0 = sh0 * a_rowb; tap_dstep = tap_sstep * a_rowb;
+    tap_wstride = (int64_t)((intptr_t)t1.W - (intptr_t)t0.W);
+    tap_shift = tap_shift0; tap_delta = tap_delta0; tap_woff = 0;
+    tap_ainc = a_kb ? p.M * ROWB2 : ROWB2;
+    w_inc = w_kb ? w_rows * ROWB2 : ROWB2;
+    const char* A = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + schunk * 16;
+    const char* W = reinterpret_cast<const char*>(t0.W) + (t0.w_gstride * g) * ES + schunk * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a_ptr[i] = A + (int64_t)a_row[i] * a_rowb;
+      w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
+    }
+  };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   auto stage = [&](int slot) {
     const uint32_t wbase = lds_base + slot * STAGE_BYTES + wave * 2048;
     const uint32_t abase = wbase + TILE;
+    if constexpr (TAPS) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(w_ptr[i] + tap_woff, wbase + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(a_t[i] >= tap_shift ? a_ptr[i] - tap_delta : zero_src, abase + i * 1024);
+      const bool wrap = s_term + 1 == p.n_terms;  // uniform selects, no branch
+      s_term = wrap ? 0 : s_term + 1;
+      tap_shift = wrap ? tap_shift0 : tap_shift - tap_sstep;
+      tap_delta = wrap ? tap_delta0 : tap_delta - tap_dstep;
+      tap_woff = wrap ? 0 : tap_woff + tap_wstride;
+      const int ai = wrap ? tap_ainc : 0, wi = wrap ? w_inc : 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a_ptr[i] += ai;
+        w_ptr[i] += wi;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(w_ptr[i], wbase + i * 1024);
 #pragma unroll
@@ -844,7 +892,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   //        vmcnt ahead of the barrier that ends odd segment 2k+1 (tiles k+2, k+3 may stay in flight: 2*PER_STAGE).
   //   WAR: tile k+3 overwrites the slot of tile k-1, last read in segment 2k-1; it is issued in segments >= 2k.
   const RowSsqReq rs_req = row_scale_request<EPI>(p, m0 + wm * 64, lane);
-  setup_term(0);
+  if constexpr (TAPS) setup_taps(); else setup_term(0);
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
@@ -1594,21 +1642,54 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
+// Are the terms the taps of one causal conv, to be run innermost in K by the two tiles with 32-deep K-tiles (256 x 352, 256 x 256)?
+// Same activation tensor and layout, non-negative shifts and weight addresses in arithmetic progression.  That order is those
+// tiles' default: the activation panel crosses the fabric once instead of once per tap.  It changes the fp32 summation order, and
+// with it the last bits, relative to the 128-byte-K-tile variants (term-outer): a batch large enough to route to these tiles and
+// a smaller one do not agree to the last bit; equal-size shards do.  DN_TAPS_INNER=0 (or DN_FAT_TAPS_INNER=0, the older name)
+// or bit 23 of pad_ restores term-outer everywhere (bit 22 forces tap-inner).
+static bool terms_are_taps(const DnGemmParams& p) {
+  const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
+  if (!e) e = getenv("DN_FAT_TAPS_INNER");
+  const bool env_taps = !(e && atoi(e) == 0);
+  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && !((p.pad_ >> 23) & 1) && (env_taps || ((p.pad_ >> 22) & 1));
+  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == p.terms[0].layout && p.terms[i].shift >= 0;
+  for (int i = 1; i < p.n_terms && taps; ++i) {
+    const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
+    taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&
+           a.shift_by_group == t0.shift_by_group && b.shift - a.shift == t0.shift - t1.shift && t0.shift >= t1.shift &&
+           (intptr_t)a.W - (intptr_t)b.W == (intptr_t)t1.W - (intptr_t)t0.W;
+  }
+  return taps;
+}
+
+template <typename E, int EPI, bool TAPS>
+static void launch_big_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI, TAPS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI, TAPS>), grid, dim3(512), lds, s, p);
+}
+
 template <typename E, int EPI>
 static int launch_big(const DnGemmParams& p, hipStream_t s) {
   constexpr int ring = 4 * 2 * 256 * ROWB2, slabs = 8 * 64 * EP_LD * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + 255) / 256) * ((np + 255) / 256), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI>), grid, dim3(512), lds, s, p);
+  bool tapped = false;
+  if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_FILM_GATE) {  // the epilogues a causal conv has (CausalConv1d + bias; the WaveNet block)
+    if (terms_are_taps(p)) {
+      launch_big_variant<E, EPI, true>(p, grid, lds, s);
+      tapped = true;
+    }
+  }
+  if (!tapped) launch_big_variant<E, EPI, false>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm");
   return DN_OK;
@@ -1651,22 +1732,7 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
   dim3 grid(((p.M + 255) / 256) * ((np + BNF - 1) / BNF), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
-  // Tap-inner K order (see the kernel) is what this tile runs for the taps of one causal conv (same activation tensor, shifts
-  // and weight addresses in arithmetic progression): the activation panel crosses the fabric once instead of once per tap
-  // (234 -> 142 MB read per FFN-conv launch at [32,512]; +0.9 % per denoising step measured in the chain).  It changes the fp32
-  // summation order, and with it the last bits, relative to the other tile variants (all term-outer, bit-identical to each
-  // other): a batch large enough to route here (>= 100 tiles, M >= 6400 at the eps-predictor's width) and a smaller one do not
-  // agree to the last bit; equal-size shards do.  DN_FAT_TAPS_INNER=0 or bit 23 of pad_ restores term-outer (bit 22: force on).
-  const char* env_order = getenv("DN_FAT_TAPS_INNER");  // read per launch (host side): tests switch it
-  const bool env_taps = !(env_order && atoi(env_order) == 0);
-  bool taps = p.n_terms >= 2 && p.n_terms <= 4 && !((p.pad_ >> 23) & 1) && (env_taps || ((p.pad_ >> 22) & 1));
-  for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == p.terms[0].layout && p.terms[i].shift >= 0;
-  for (int i = 1; i < p.n_terms && taps; ++i) {
-    const DnGemmTerm &a = p.terms[i], &b = p.terms[i - 1], &t0 = p.terms[0], &t1 = p.terms[1];
-    taps = a.A == t0.A && a.lda == t0.lda && a.a_gstride == t0.a_gstride && a.w_gstride == t0.w_gstride &&
-           a.shift_by_group == t0.shift_by_group && b.shift - a.shift == t0.shift - t1.shift && t0.shift >= t1.shift &&
-           (intptr_t)a.W - (intptr_t)b.W == (intptr_t)t1.W - (intptr_t)t0.W;
-  }
+  const bool taps = terms_are_taps(p);  // tap-inner K order for the taps of one causal conv (see the kernel and terms_are_taps)
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
   if (taps) launch_fat_variant<E, EPI, true, NTW, WAVES>(p, grid, lds, s);
   else launch_fat_variant<E, EPI, false, NTW, WAVES>(p, grid, lds, s);

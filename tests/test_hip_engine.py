@@ -91,6 +91,9 @@ def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
     the eps-predictor (tiny and BASELINE config 2 shapes) and for both VAE ends."""
     engine, _ = eng
     outs = {}
+    # term-outer K order on every tile: forcing the layout also forces the 256x256 tile, whose default order for a causal conv
+    # (taps innermost) differs in the last bits from the small tiles these test sizes otherwise route to
+    monkeypatch.setenv("DN_TAPS_INNER", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("DN_KBLOCK", mode)
         g = golden("eps_tiny")

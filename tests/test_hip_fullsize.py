@@ -48,7 +48,7 @@ def test_config3_chain_graph_and_split_are_bit_identical(models):
 def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeypatch):
     """[B=16,T=1024] features: VAE encode -> noise at start_step -> DDIM -> VAE decode -> units.  (a) the 16-utterance
     batch and two 8-utterance shards (the multi-GPU sharding): with every contraction in term-outer K order
-    (DN_FAT_TAPS_INNER=0) units and recon are identical bit for bit whatever tile variants the shard sizes route to; in the
+    (DN_TAPS_INNER=0) units and recon are identical bit for bit whatever tile variants the shard sizes route to; in the
     default order the 256x352 tile sums the FFN conv's taps innermost, so shards small enough to leave that tile (here the
     half-batch streams of an 8-utterance shard: M = 4096 rows) differ from the big batch in the last bits of fp32 sums --
     units agree but for rare near-ties (<= 1 %), recon within the bf16 rounding level (3e-2 of its scale); (b) a truncated chain (start_step=3) on 2 utterances matches the CPU oracle
@@ -78,12 +78,12 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeyp
         recon, logits, units = vae.decode(x, l)
         return recon.cpu(), logits.cpu(), units.cpu()
 
-    monkeypatch.setenv("DN_FAT_TAPS_INNER", "0")
+    monkeypatch.setenv("DN_TAPS_INNER", "0")
     full = run(slice(0, 16))
     a, b = run(slice(0, 8)), run(slice(8, 16))
     assert torch.equal(torch.cat([a[2], b[2]]), full[2])
     assert torch.equal(torch.cat([a[0], b[0]]), full[0])
-    monkeypatch.delenv("DN_FAT_TAPS_INNER")
+    monkeypatch.delenv("DN_TAPS_INNER")
     strict = full
     full = run(slice(0, 16))
     a, b = run(slice(0, 8)), run(slice(8, 16))

@@ -301,10 +301,15 @@ def test_random_shapes_every_variant_bit_identical(ops):
         assert maxerr(outs[1].cpu().view(B, T, -1), ref) < 3e-4, (case, k, cin, cout, B, T, dil)
         for tile, o in outs.items():
             assert torch.equal(o, outs[1]), (case, tile, k, cin, cout, B, T, dil)
-        if cout % 352 == 0:  # the 256x352 tile's own K order (taps innermost): another fp32 summation order, the same sum
-            out = torch.full((B * T, cout), float("nan"), device=DEV)
-            ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=4)
-            assert maxerr(out.cpu(), outs[1].cpu()) < 1e-5 * max(1.0, outs[1].abs().max().item()), (case, k, cin, cout, B, T, dil)
+        # the default K order of the two tiles with 32-deep K-tiles (taps innermost): another fp32 summation order, the same sum,
+        # and the same bits on both tiles
+        inner = {}
+        for tile in (3,) + ((4,) if cout % 352 == 0 else ()):
+            inner[tile] = torch.full((B * T, cout), float("nan"), device=DEV)
+            ops_.conv_gemm(terms, inner[tile], T, cout, bias=bias, tile=tile)
+            assert maxerr(inner[tile].cpu(), outs[1].cpu()) < 1e-5 * max(1.0, outs[1].abs().max().item()), (case, tile, k, cin, cout, B, T, dil)
+        if 4 in inner:
+            assert torch.equal(inner[3], inner[4]), (case, k, cin, cout, B, T, dil)
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (1408, 1408, 3, 1, 4, 512),
@@ -337,9 +342,12 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
     dflt = torch.empty((B * T, N), device=DEV)  # no order forced: taps innermost when there is more than one tap
     ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], dflt, T, N, bias=bias, tile=4, a_kblocked=True, w_kblocked=True)
     assert torch.equal(dflt, refs[k > 1])
-    out = torch.full((B * T, N), float("nan"), device=DEV)  # the 256x256 tile takes them too (term-outer)
-    ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], out, T, N, bias=bias, tile=3, a_kblocked=True, w_kblocked=True)
-    assert torch.equal(out, ref)
+    for inner in (True, False):  # the 256x256 tile takes them too, in either K order: its tap-inner order is the 256x352 tile's
+        for kb in (True, False):
+            out = torch.full((B * T, N), float("nan"), device=DEV)
+            terms = [(xb if kb else xa, (Wb if kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
+            ops_.conv_gemm(terms, out, T, N, bias=bias, tile=3, a_kblocked=kb, w_kblocked=kb, taps_inner=inner)
+            assert torch.equal(out, refs[inner]), (inner, kb)
     with pytest.raises(RuntimeError, match="K-blocked"):
         ops_.conv_gemm([(xb, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=1, a_kblocked=True)
 

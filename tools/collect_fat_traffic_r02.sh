@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 for mode in inner outer; do
-  if [ $mode = outer ]; then export DN_FAT_TAPS_INNER=0; fi
+  if [ $mode = outer ]; then export DN_TAPS_INNER=0; fi
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fat_$mode/$c -o p -- python3 $R/tools/gemm_bench.py bf16 ffn > $R/gpurun_out/pmc_fat_${mode}_$c.log 2>&1
   done
