@@ -11,6 +11,7 @@
 // 128-byte zero page, so activations stay dense [M, ld] with no per-sequence padding.  Weights are the
 // MFMA A operand and activations the B operand, so each lane ends up with 4 consecutive output columns
 // of one row: bias/FiLM vectors load as float4 and stores are 8/16 bytes per lane.
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -99,6 +100,23 @@ __device__ __forceinline__ void pipe_sync() {
 // m_base + r, slab column c is packed weight row n_base + c (n_base a multiple of 64).  16 lanes cover the 64
 // columns of a row, so bias / FiLM / residual loads and the output stores are whole 128-256 B row segments.
 constexpr int EP_LD = 68;
+
+// Logical tile index -> (row tile, column tile).  band = 1: column tiles fastest (the tiles that share one activation row panel
+// are neighbours: right when the weights fit the L2 and the activations stream).  band > 1 (launch(): weights much larger than
+// an L2): bands of `band` row tiles, inside a band row tiles fastest -- the tiles an XCD runs together then form a
+// (band x concurrency / band) block, so each weight column panel serves `band` row tiles per fetch instead of one.
+__device__ __forceinline__ void tile_coords(int logical, int n_tiles_n, int m_tiles, int band, int& mt, int& nt) {
+  if (band <= 1) {
+    mt = logical / n_tiles_n;
+    nt = logical - mt * n_tiles_n;
+    return;
+  }
+  const int per_band = band * n_tiles_n;
+  const int b = logical / per_band, r = logical - b * per_band;
+  const int rows = min(band, m_tiles - b * band);  // the last band may be short
+  nt = r / rows;
+  mt = b * band + (r - nt * rows);
+}
 
 template <bool BF>
 __device__ __forceinline__ void store4t(void* base, int64_t off, float a, float b, float c, float d) {
@@ -549,8 +567,10 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m0 = (logical / n_tiles_n) * BM;
-  const int n0 = (logical % n_tiles_n) * BN;  // packed weight row of the tile
+  int mt_, nt_;
+  tile_coords(logical, n_tiles_n, (p.M + BM - 1) / BM, (p.pad_ >> 24) & 0xff, mt_, nt_);
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;  // packed weight row of the tile
 
   // ---- staging geometry: wave w stages A rows [32w, 32w+32) and W rows [8*WPW*w, ...), 8 rows per piece ----
   const int srow = lane >> 3;                 // row within the 8-row piece
@@ -756,8 +776,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m0 = (logical / n_tiles_n) * BMB;
-  const int n0 = (logical % n_tiles_n) * BNB;
+  int mt_, nt_;
+  tile_coords(logical, n_tiles_n, (p.M + BMB - 1) / BMB, (p.pad_ >> 24) & 0xff, mt_, nt_);
+  const int m0 = mt_ * BMB;
+  const int n0 = nt_ * BNB;
   const int w_rows = (np_total + 127) / 128 * 128;  // rows the packed weight really has: clamp the ragged last tile
 
   // ---- staging: wave w stages rows [32w, 32w+32) of both tiles, 16 rows x 64 B per piece
@@ -1789,14 +1811,43 @@ static int choose_tile(const DnGemmParams& p) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
   };
-  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = 0.92 * fill(tiles_small, 2);
+  // weights much larger than an L2 (they stream): the 128 x 128 tile re-fetches them twice as often per flop and becomes
+  // fabric-bound (VAE FFN conv, 25 MB of weights, M = 12288: 293 us on 128 x 128, 274 on 256 x 128 / 256 x 256)
+  const double w_bytes = (double)np * p.K * p.n_terms * (bf ? 2 : 4);
+  const double k_small = w_bytes >= 6.0e6 ? 0.85 : 0.92;
+  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = k_small * fill(tiles_small, 2);
   if (s_big >= s_mid && s_big >= s_small) return 3;
   return s_mid > s_small ? 2 : 1;
 }
 
+// Row-tile band of the tile order (tile_coords) for the 128 x 128 / 256 x 128 / 256 x 256 tiles: 1 unless the weights of one
+// group are much larger than an XCD's 4 MB L2 -- then the tiles an XCD runs together (32 CUs x workgroups per CU) should form a
+// block that balances activation-panel bytes against weight-panel bytes, band = sqrt(concurrency x weight panel / row panel).
+// (The VAE's FFN conv -- 25 MB of weights on 128 x 128 tiles -- re-streamed its weights once per four row tiles: 1.1 GB of fabric
+// traffic per launch at 5.3 TB/s.)  DN_GEMM_BAND forces a value for every launch (0 / 1 = column tiles fastest).
+static int choose_band(const DnGemmParams& p, int tile) {
+  static const int env_band = getenv("DN_GEMM_BAND") ? atoi(getenv("DN_GEMM_BAND")) : -1;
+  if (env_band >= 0) return env_band < 255 ? env_band : 255;
+  const int es = p.dtype == DN_BF16 ? 2 : 4;
+  const int bm = tile == 1 ? 128 : 256, bn = tile == 3 ? 256 : 128, conc = 32 * (tile == 1 ? 2 : 1);
+  const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
+  const double w_total = (double)np * p.K * p.n_terms * es;
+  if (w_total < 6.0e6) return 1;
+  bool same_a = true;
+  for (int i = 1; i < p.n_terms; ++i) same_a = same_a && p.terms[i].A == p.terms[0].A;
+  const double a_panel = (double)bm * p.K * es * (same_a ? 1 : p.n_terms), w_panel = (double)bn * p.K * p.n_terms * es;
+  int band = (int)(sqrt(conc * w_panel / a_panel) + 0.5);
+  const int m_tiles = (p.M + bm - 1) / bm;
+  band = band < 1 ? 1 : band > m_tiles ? m_tiles : band;
+  return band < 255 ? band : 255;
+}
+
 template <typename E, int EPI>
-static int launch(const DnGemmParams& p, hipStream_t s) {
+static int launch(const DnGemmParams& p0, hipStream_t s) {
+  DnGemmParams p = p0;
   const int tile = choose_tile(p);
+  if (tile >= 1 && tile <= 3 && ((p.pad_ >> 24) & 0xff) == 0)  // bits 24..31 of pad_: a band forced by the caller (tests)
+    p.pad_ = (p.pad_ & 0x00ffffff) | (choose_band(p, tile) << 24);
   DN_CHECK_ARG(tile > 0, "dn_conv_gemm: K-blocked operands are taken by the 256 x 352 and 256 x 256 tiles only (bf16; forced tile %d)",
                forced_tile(p));
   if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {

@@ -312,6 +312,26 @@ def test_random_shapes_every_variant_bit_identical(ops):
             assert torch.equal(inner[3], inner[4]), (case, k, cin, cout, B, T, dil)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_band_blocked_tile_order_is_a_permutation(ops, tile):
+    """The tile order used when the weights exceed an L2 (bands of row tiles, row tiles fastest inside a band; gemm.hip
+    tile_coords / choose_band) visits every tile exactly once: identical outputs for any band, ragged last band and ragged M."""
+    ops_, packing, _lib = ops
+    B, T, cin, cout, k = 5, 333, 128, 416, 3
+    x, w, b = seeded((B, T, cin), 31), seeded((cout, cin, k), 32, (1.0 / (cin * k)) ** 0.5), seeded((cout,), 33, 0.1)
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+    W = packing._conv(w, _lib.DN_BF16).to(DEV)
+    bias = packing._vec(b, W.shape[1]).to(DEV)
+    terms = [(xa, W[j], k - 1 - j) for j in range(k)]
+    ref = torch.full((B * T, cout), float("nan"), device=DEV)
+    ops_.conv_gemm(terms, ref, T, cout, bias=bias, tile=tile, band=1)
+    assert maxerr(ref.cpu().view(B, T, -1), O.causal_conv1d(bf16r(x), bf16r(w), b, 1)) < 3e-4
+    for band in (2, 3, 5, 13, 127):
+        out = torch.full((B * T, cout), float("nan"), device=DEV)
+        ops_.conv_gemm(terms, out, T, cout, bias=bias, tile=tile, band=band)
+        assert torch.equal(out, ref), band
+
+
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(192, 704, 3, 1, 3, 100), (64, 352, 3, 2, 2, 300), (1408, 1408, 3, 1, 4, 512),
                                                 (128, 1056, 1, 1, 1, 515)])
 def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
