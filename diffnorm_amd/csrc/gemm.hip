@@ -1811,11 +1811,7 @@ static int choose_tile(const DnGemmParams& p) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
   };
-  // weights much larger than an L2 (they stream): the 128 x 128 tile re-fetches them twice as often per flop and becomes
-  // fabric-bound (VAE FFN conv, 25 MB of weights, M = 12288: 293 us on 128 x 128, 274 on 256 x 128 / 256 x 256)
-  const double w_bytes = (double)np * p.K * p.n_terms * (bf ? 2 : 4);
-  const double k_small = w_bytes >= 6.0e6 ? 0.85 : 0.92;
-  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = k_small * fill(tiles_small, 2);
+  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = 0.92 * fill(tiles_small, 2);
   if (s_big >= s_mid && s_big >= s_small) return 3;
   return s_mid > s_small ? 2 : 1;
 }
