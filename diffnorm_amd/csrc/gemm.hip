@@ -330,9 +330,13 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
   }
 }
 
-template <int EPI, bool OUT_BF, bool RES_BF, bool FULL>
+// pre_res (HAS_PRE, RESADD only): the residual rows of this lane, requested by the caller before its K loop in this
+// function's own (row batch, lane) pattern -- v[r] = res[m_base + 4 r + (lane >> 4)][n_base + 4 (lane & 15) ..+3]; `on` false:
+// not requested (A/B timing), load here.
+struct ResPre { float4 v[16]; bool on = false; };
+template <int EPI, bool OUT_BF, bool RES_BF, bool FULL, bool HAS_PRE = false>
 __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
-                                                   int ncols, bool prescaled) {
+                                                   int ncols, bool prescaled, const ResPre pre_res = ResPre()) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
   char* out = reinterpret_cast<char*>(p.out) + p.out_gstride * g * (OUT_BF ? 2 : 4);
   if constexpr (EPI == DN_EPI_GEGLU) {
@@ -426,7 +430,14 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         ga[i] = gas;
         be[i] = bes;
         if (!FULL && m >= p.M) continue;
-        if constexpr (HAS_RES) rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
+        if constexpr (HAS_RES) {
+          if constexpr (HAS_PRE) {
+            if (pre_res.on) rv[i] = pre_res.v[jb + i];
+            else rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
+          } else {
+            rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
+          }
+        }
         if constexpr (EPI == DN_EPI_FILM_GATE) {
           if (gbb && !gb_shared) {
             const float* gr = gbb + (int64_t)b0 * p.gb_ld;
@@ -499,7 +510,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
 
 template <int EPI>
 __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
-                                              int ncols = 64, float row_scale = -1.f) {
+                                              int ncols = 64, float row_scale = -1.f, const ResPre pre_res = ResPre()) {
   if constexpr ((DN_GEMM_ABL & 16) != 0) return;  // diagnostic build: no epilogue (LDS reads, math and stores skipped)
   const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
   const bool obf = p.out_dtype == DN_BF16;       // kernel arguments: uniform
@@ -514,7 +525,8 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
   }
 #define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F>(p, ep, m_base, n_base, g, lane, ncols, prescaled)
   if constexpr (RESADD) {
-    if (full) DN_EP(false, false, true); else DN_EP(false, false, false);
+    if (full) wave_epilogue_impl<EPI, false, false, true, true>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
+    else wave_epilogue_impl<EPI, false, false, false, true>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
   } else if constexpr (EPI == DN_EPI_FILM_GATE) {
     if (obf && rbf) { if (full) DN_EP(true, true, true); else DN_EP(true, true, false); }
     else if (!obf && !rbf) { if (full) DN_EP(false, false, true); else DN_EP(false, false, false); }
@@ -586,6 +598,24 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   const int ktiles_per_term = p.K / KT;
   const int nkt = p.n_terms * ktiles_per_term;
   const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+
+  // Residual-closing contractions (RESADD; N = 512: one round of tiles, every workgroup a bare latency chain of staging, a short
+  // K loop and a load-add-store epilogue): the wave's residual rows are requested here, in the epilogue's own access pattern,
+  // so their round trip runs under the staging prologue and the K loop instead of in front of the stores.  Plain loads: they
+  // are older than every LDS-DMA piece (in-order return: the K loop's counted waits cover them) and first used after it.
+  ResPre pre_res;
+  pre_res.on = false;
+  if constexpr (EPI == DN_EPI_RESADD && BM == 128) {  // (the 8-wave tile has no 64 registers to spare)
+    pre_res.on = !(p.pad_ & 32);  // pad_ bit 5: A/B timing without the prefetch
+    const int n_ = n0 + wn * 64 + (lane & 15) * 4;
+    const char* resb = reinterpret_cast<const char*>(p.res) + p.res_gstride * g * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m_ = m0 + wm * 64 + r * 4 + (lane >> 4);
+      pre_res.v[r] = make_float4(0, 0, 0, 0);
+      if (pre_res.on && m_ < p.M && n_ < p.N) pre_res.v[r] = load4t<false>(resb, (int64_t)m_ * p.ldr + n_);
+    }
+  }
 
   // Per-lane source pointers of the term being staged; they advance by one K-tile (128 B) per stage and
   // are rebuilt only at a term boundary, so the steady-state loop carries a few pointer adds, no multiplies.
@@ -734,7 +764,10 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
       *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = scaled(acc[nt][mt], sc4[mt]);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in-order: writes precede the reads below
 
-  wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
+  if constexpr (EPI == DN_EPI_RESADD)
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale, pre_res);
+  else
+    wave_epilogue<EPI>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
 }
 
 // ------------------------------------------------------------------------------------------ 256 x 256 tile
@@ -1842,6 +1875,8 @@ template <typename E, int EPI>
 static int launch(const DnGemmParams& p0, hipStream_t s) {
   DnGemmParams p = p0;
   const int tile = choose_tile(p);
+  static const bool no_res_prefetch = getenv("DN_RES_PREFETCH") && atoi(getenv("DN_RES_PREFETCH")) == 0;  // A/B timing
+  if (no_res_prefetch) p.pad_ |= 32;
   if (tile >= 1 && tile <= 3 && ((p.pad_ >> 24) & 0xff) == 0)  // bits 24..31 of pad_: a band forced by the caller (tests)
     p.pad_ = (p.pad_ & 0x00ffffff) | (choose_band(p, tile) << 24);
   DN_CHECK_ARG(tile > 0, "dn_conv_gemm: K-blocked operands are taken by the 256 x 352 and 256 x 256 tiles only (bf16; forced tile %d)",
