@@ -1828,6 +1828,7 @@ static int choose_tile(const DnGemmParams& p) {
   if (kblocked) return bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them
   if (bf && (force == 6 || force == 7)) return force;
   if (force >= 1 && force <= 3) return force;
+
   const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
   const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
   const long tiles_big = mt256 * ((np + 255) / 256) * p.groups;
@@ -1840,6 +1841,11 @@ static int choose_tile(const DnGemmParams& p) {
   static const int heur = getenv("DN_GEMM_HEUR") ? atoi(getenv("DN_GEMM_HEUR")) : 1;
   if (heur == 0)  // previous rule, kept for A/B timing
     return tiles_big >= 360 ? 3 : tiles_mid >= 192 ? 2 : 1;
+  // The GEGLU projection goes to the 256 x 256 tile as soon as that gives every CU a tile: there the engine feeds it K-blocked
+  // operands (whole cache lines), and in the two-stream chain the other half-batch's launches fill its partial last round, which
+  // the fill model below cannot see.  Measured at M = 8192 (a half-batch stream of [32,512]): 38.7-40.9 us against 41.6-42.3 on
+  // the 128 x 128 tile in isolation, +2.2 % per denoising step in the chain (176.9 vs 173.1 steps/s, two alternating runs).
+  if (bf && p.epilogue == DN_EPI_GEGLU && tiles_big >= 256 && heur != 3) return 3;  // DN_GEMM_HEUR=3: scored like the rest (A/B)
   auto fill = [](long tiles, int per_cu) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
