@@ -223,9 +223,13 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
   const int64_t cols = (int64_t)B * p.Tp;
   const int64_t tiles = (int64_t)((cout + 255) / 256) * ((p.N + 255) / 256);
   int ks = 1;
-  // fill the chip with K-slices of >= 4 K-tiles; a contraction with >= 160 output tiles runs unsliced and accumulates
-  // straight into the gradient (no partial sums to write, re-read and reduce)
-  while (ks < 64 && tiles * ks < (ks == 1 ? 160 : 256) && cols / (ks * 2) >= 256) ks *= 2;
+  // K-slices of >= 4 K-tiles until about half the chip has a tile-slice; a contraction with >= 160 output tiles runs unsliced and
+  // accumulates straight into the gradient (no partial sums to write, re-read and reduce).  Half the chip, not all of it: the
+  // sliced contractions move 4.6-5 TB/s through the fabric, most of it their fp32 partial sums (slices x the weight's size, written
+  // and read back by the reduction), so halving the slices beats filling the last CUs -- measured on the training bench: target
+  // 256 tile-slices 1153 samples/s, 160: 1199, 128: 1207, 64: 1207, 32: 1188, 1 (never slice): 1119.  DN_WGRAD_FILL overrides.
+  static const int fill_target = getenv("DN_WGRAD_FILL") ? atoi(getenv("DN_WGRAD_FILL")) : 128;
+  while (ks < 64 && tiles * ks < (ks == 1 ? 160 : fill_target) && cols / (ks * 2) >= 256) ks *= 2;
   p.k_slices = ks;
   p.cols_total = (cols + (int64_t)64 * ks - 1) / ((int64_t)64 * ks) * ((int64_t)64 * ks);
   p.chunk = (int)(p.cols_total / ks);
