@@ -229,7 +229,8 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
   // and read back by the reduction), so halving the slices beats filling the last CUs -- measured on the training bench: target
   // 256 tile-slices 1153 samples/s, 160: 1199, 128: 1207, 64: 1207, 32: 1188, 1 (never slice): 1119.  DN_WGRAD_FILL overrides.
   static const int fill_target = getenv("DN_WGRAD_FILL") ? atoi(getenv("DN_WGRAD_FILL")) : 128;
-  while (ks < 64 && tiles * ks < (ks == 1 ? 160 : fill_target) && cols / (ks * 2) >= 256) ks *= 2;
+  static const int unsliced_min = getenv("DN_WGRAD_UNSLICED") ? atoi(getenv("DN_WGRAD_UNSLICED")) : 160;
+  while (ks < 64 && tiles * ks < (ks == 1 ? unsliced_min : fill_target) && cols / (ks * 2) >= 256) ks *= 2;
   p.k_slices = ks;
   p.cols_total = (cols + (int64_t)64 * ks - 1) / ((int64_t)64 * ks) * ((int64_t)64 * ks);
   p.chunk = (int)(p.cols_total / ks);
