@@ -71,15 +71,17 @@ constexpr int kWavenetTensors = 12;
 //               form the 256 x 352 tile stages as whole cache lines; any pointer (unused) in f32 mode
 //   ffin_Wkb: ffin_W K-blocked, [depth][padk(D)/32][2*padk(inner)][32] (bf16) -- used when the GEGLU projection lands on the
 //               256 x 256 tile: the split norm's producer then writes its activations K-blocked too (norm_split = 2)
+//   qkv_Wkb: qkv_W K-blocked, [depth][padk(D)/32][padn(3*hd)][32] (bf16) -- layers >= 1 when the projection lands on the 256 x 256
+//               tile: the previous layer's residual-closing contraction then writes the attention norm's row * gamma K-blocked
 //   ffout_W [depth][padn(D)][padk(inner)]                           ffout_b [depth][padk(D)]
 //   g1, g2 [depth][D] learned RMSNorm gammas (NULL when time-conditioned)
 //   pred_gamma [D]   pred_W [padn(D)][padk(D)]
 struct TransformerW {
   int dim, depth, heads, dim_head, inner;
-  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W, *ffconv_Wkb, *ffin_Wkb;
+  const void *qkv_W, *out_W, *ffin_W, *ffconv_W, *ffout_W, *pred_W, *ffconv_Wkb, *ffin_Wkb, *qkv_Wkb;
   const float *ffin_b, *ffconv_b, *ffout_b, *g1, *g2, *pred_gamma;
 };
-constexpr int kTransformerTensors = 14;
+constexpr int kTransformerTensors = 15;
 
 }  // namespace dn
 

@@ -211,10 +211,22 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     q.epilogue = DN_EPI_GEGLU;
     geglu_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
   }
+  // The same for the q/kv projection of layers >= 1 (layer 0's norm comes from the caller, row-major): its activations are the
+  // attention norm's row * gamma, written by the previous layer's feed-forward-out contraction and read by nothing else.
+  bool qkv_kb = false;
+  static const bool qkv_kb_off = getenv("DN_QKV_KB") && atoi(getenv("DN_QKV_KB")) == 0;  // A/B timing
+  if (!qkv_kb_off && split && !fuse && kblock_mode() != 0 && dtype == DN_BF16 && w.qkv_Wkb && Dp % 32 == 0) {
+    DnGemmParams q = gemm_base(dtype, M, 3 * hd, Dp, T);
+    qkv_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
+  }
   for (int l = 0; l < w.depth; ++l) {
     {  // to_q ; to_kv in one contraction (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
       p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
+      if (qkv_kb && l >= 1) {
+        p.terms[0].W = eoff(w.qkv_Wkb, (size_t)l * padn(3 * hd) * Dp, es);
+        p.terms[0].layout = DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED;
+      }
       p.out = tb.qkv; p.ldo = 3 * hd;
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
@@ -280,6 +292,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       const NormSrc ns = norm_src(w, gb, l + 1, 0);
       if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+      if (qkv_kb && l + 1 < w.depth) p.norm_split = 2;  // the next layer's q/kv projection reads it K-blocked (to_pred: row-major)
       DN_TRY(dn_conv_gemm(&p, s));
     }
     if (!fuse && !split) DN_TRY(standalone_norm(l + 1, 0));
@@ -305,7 +318,7 @@ const void* const* take_transformer(TransformerW& w, const void* const* t) {
   w.qkv_W = t[0]; w.out_W = t[1]; w.ffin_W = t[2]; w.ffin_b = (const float*)t[3]; w.ffconv_W = t[4];
   w.ffconv_b = (const float*)t[5]; w.ffout_W = t[6]; w.ffout_b = (const float*)t[7];
   w.g1 = (const float*)t[8]; w.g2 = (const float*)t[9]; w.pred_gamma = (const float*)t[10]; w.pred_W = t[11];
-  w.ffconv_Wkb = t[12]; w.ffin_Wkb = t[13];
+  w.ffconv_Wkb = t[12]; w.ffin_Wkb = t[13]; w.qkv_Wkb = t[14];
   return t + kTransformerTensors;
 }
 

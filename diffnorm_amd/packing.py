@@ -141,6 +141,8 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
         kblock(torch.stack(ffc)) if dtype == _lib.DN_BF16 else dummy.clone(),
         # the GEGLU projection's packed weights K-blocked (its activations arrive K-blocked from the split norm's producer)
         kblock(torch.stack(ffin)) if dtype == _lib.DN_BF16 else dummy.clone(),
+        # and the q/kv projection's (layers >= 1 read the attention norm's output K-blocked from the previous layer's last contraction)
+        kblock(torch.stack(qkv)) if dtype == _lib.DN_BF16 else dummy.clone(),
     ]
 
 
