@@ -342,14 +342,15 @@ static int launch_attn(const DnAttnParams& p, hipStream_t s) {
 extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   DN_CHECK_ARG(pp != nullptr, "dn_attention: null params");
   DnAttnParams p = *pp;
-  {
-    const char* e = getenv("DN_ATTN_XCD");
-    p.pad3_ = e && atoi(e) == 0 ? 1 : 0;
-  }
+  static const int xcd_off = getenv("DN_ATTN_XCD") && atoi(getenv("DN_ATTN_XCD")) == 0 ? 1 : 0;  // A/B timing knob, read once
+  p.pad3_ = xcd_off;
   DN_CHECK_ARG(p.q && p.k && p.v && p.out, "dn_attention: null tensor");
   DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.Tk >= 0, "dn_attention: bad shape");
   DN_CHECK_ARG(!(p.lse && p.Tk > 0 && p.Tk != p.T), "dn_attention: the backward pass (lse) covers self-attention only");
-  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16, "dn_attention: bad dtype");
+  // DN_BF16X3: q / k / v are plain fp32 (the engine keeps them out of the split layout), the products run in exact fp32 MFMA and only
+  // the output -- the operand of the to_out contraction -- is written as split rows (store4 on p.dtype)
+  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16 || p.dtype == DN_BF16X3, "dn_attention: bad dtype");
+  if (p.dtype == DN_BF16X3) DN_CHECK_ARG(p.ldo % 32 == 0 && (p.heads * p.dim_head) % 4 == 0 && ((uintptr_t)p.out & 127) == 0, "dn_attention: split-row output needs ldo %% 32 == 0");
   DN_CHECK_ARG(p.dropout_p >= 0.f && p.dropout_p < 1.f, "dn_attention: dropout_p %g", (double)p.dropout_p);
   const int es = p.dtype == DN_BF16 ? 2 : 4;
   DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);

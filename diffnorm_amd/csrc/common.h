@@ -13,10 +13,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct BF16 {};  // tag types selecting the contraction arithmetic
 struct F32 {};
+struct BF16X3 {};  // split operands: (hi, lo) bf16 pairs in "split rows" (include/diffnorm_hip.h), three bf16 MFMAs per product
 
 template <typename E> struct Elem;
 template <> struct Elem<BF16> { static constexpr int bytes = 2; static constexpr int kDtype = DN_BF16; };
 template <> struct Elem<F32> { static constexpr int bytes = 4; static constexpr int kDtype = DN_F32; };
+template <> struct Elem<BF16X3> { static constexpr int bytes = 4; static constexpr int kDtype = DN_BF16X3; };
 
 // One "k-step" = 64 bytes of K per row; a fragment is the 16 bytes a lane holds of it:
 // lane l -> row (l & 15), 16-byte chunk (l >> 4) of the 64-byte k-step.
@@ -49,9 +51,39 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// DN_BF16X3 split rows: element `off` of a tensor (row strides multiples of 32) lives as hi at byte (off / 32) * 128 +
+// (off % 32) * 2 and lo 64 bytes further on; hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32).
+__device__ __forceinline__ int64_t split_byte(int64_t off) { return ((off >> 5) << 7) + ((off & 31) << 1); }
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// 4 consecutive elements (off a multiple of 4: they stay inside one 32-element group)
+__device__ __forceinline__ void store4_split(void* base, int64_t off, float a, float b, float c, float d) {
+  uint32_t h0, l0, h1, l1;
+  split_pair(a, b, h0, l0);
+  split_pair(c, d, h1, l1);
+  char* p = reinterpret_cast<char*>(base) + split_byte(off);
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + 64) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ void store1_split(void* base, int64_t off, float v) {
+  uint32_t h, l;
+  split_pair(v, 0.f, h, l);
+  char* p = reinterpret_cast<char*>(base) + split_byte(off);
+  *reinterpret_cast<uint16_t*>(p) = (uint16_t)h;
+  *reinterpret_cast<uint16_t*>(p + 64) = (uint16_t)l;
+}
+__device__ __forceinline__ float load1_split(const void* base, int64_t off) {
+  const char* p = reinterpret_cast<const char*>(base) + split_byte(off);
+  return bf16_to_f32(*reinterpret_cast<const uint16_t*>(p)) + bf16_to_f32(*reinterpret_cast<const uint16_t*>(p + 64));
+}
+
 // store 4 consecutive fp32 values as out_dtype at element pointer (row base + col)
 __device__ __forceinline__ void store4(void* base, int64_t elem_off, int out_dtype, float a, float b, float c, float d) {
-  if (out_dtype == DN_BF16) {
+  if (out_dtype == DN_BF16X3) {
+    store4_split(base, elem_off, a, b, c, d);
+  } else if (out_dtype == DN_BF16) {
     uint2 v = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem_off) = v;
   } else {

@@ -33,7 +33,7 @@ inline DnGemmParams gemm_base(int dtype, int M, int N, int K, int T) {
   p.n_terms = 1;
   p.epilogue = DN_EPI_BIAS;
   p.out_dtype = dtype;
-  p.res_dtype = dtype;
+  p.res_dtype = dtype == DN_BF16X3 ? DN_F32 : dtype;  // (an epilogue's residual input is never split rows)
   return p;
 }
 

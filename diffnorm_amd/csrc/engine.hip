@@ -17,20 +17,23 @@ namespace {
 // The residual-closing contractions can also emit the next block's RMSNorm (64 x 512 whole-row tile, dn_conv_gemm's
 // norm_out).  Measured on [32,512] x dim 512 it loses to 256 x 128 tiles + a standalone norm kernel (one workgroup
 // re-reads the whole weight for 64 rows): 6.85 vs 6.63 ms per denoising step.  Off unless DN_FUSE_NORM=1.
-inline bool fuse_norm_enabled(int Dp) {
+inline bool fuse_norm_enabled(int Dp, int dtype) {
   const char* e = getenv("DN_FUSE_NORM");  // read per call: tests toggle it
   const bool on = e && atoi(e) != 0;
-  return on && Dp <= 512;
+  return on && Dp <= 512 && dtype != DN_BF16X3;  // (the whole-row tile is not built for split operands)
 }
 
 // Split RMSNorm (DnGemmParams.norm_split / row_ssq): every RMSNorm of the transformer is divided between the residual-
 // closing contraction that produces its input and the projection that consumes its output, so the 2*depth+1 norm passes
 // over the residual stream disappear (measured: -6 % per denoising step at [32,512] x dim 512).  DN_NO_SPLIT_NORM=1 runs
 // the standalone norm kernel instead (A/B timing, and the reference point of the parity tests).
-inline bool split_norm_enabled(int Dp) {
+inline bool split_norm_enabled(int Dp, int dtype) {
   const char* e = getenv("DN_NO_SPLIT_NORM");  // read per call: tests toggle it
-  return !(e && atoi(e) != 0) && Dp % 64 == 0 && !fuse_norm_enabled(Dp);
+  return !(e && atoi(e) != 0) && Dp % 64 == 0 && !fuse_norm_enabled(Dp, dtype);
 }
+// DN_BF16X3: tensors that are read by an epilogue or by the attention kernel rather than staged as a contraction operand stay
+// plain fp32 (the WaveNet block's residual branch, q / k / v)
+inline int side_dtype(int dtype) { return dtype == DN_BF16X3 ? DN_F32 : dtype; }
 
 // DN_KBLOCK: unset = K-blocked buffers where the consuming contraction lands on a tile that gains from them, 0 = never,
 // 1 = always (the contraction then runs on a tile that takes them; tests).  Read per call (host side, once per capture).
@@ -94,7 +97,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
       p.terms[0].W = eoff(kb ? w.res_Wkb : w.res_W, (size_t)st * L * mat, es); p.terms[0].w_gstride = (int64_t)mat;
       p.terms[0].layout = a_layout;
       p.bias = w.res_b + (size_t)st * L * cp; p.bias_gstride = cp;
-      p.out = wb.resb; p.ldo = cp; p.out_gstride = plane;
+      p.out = wb.resb; p.ldo = cp; p.out_gstride = plane; p.out_dtype = side_dtype(dtype);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {  // dilated conv k=3 (dilation 2^block) + FiLM + tanh*sigmoid + residual (:509,523-530)
@@ -109,7 +112,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
       }
       p.bias = w.conv_b + (size_t)st * L * cp; p.bias_gstride = cp;
       p.epilogue = DN_EPI_FILM_GATE;
-      p.res = wb.resb; p.ldr = cp; p.res_gstride = plane;
+      p.res = wb.resb; p.ldr = cp; p.res_gstride = plane; p.res_dtype = side_dtype(dtype);
       if (gb) {
         p.gamma_beta = gb + (size_t)st * L * 2 * cp; p.gb_ld = gb_ld; p.gb_half = cp; p.gb_gstride = 2 * cp;
       }
@@ -192,8 +195,8 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
                     const float* rb, const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
   const int es = esize(dtype), M = B * T;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
-  const bool fuse = fuse_norm_enabled(Dp);
-  const bool split = split_norm_enabled(Dp);
+  const bool fuse = fuse_norm_enabled(Dp, dtype);
+  const bool split = split_norm_enabled(Dp, dtype);
   const int rb_layer = 3 * hd + 2 * ip;
   bool scaled = split && xn_ready;  // tb.xn holds row*gamma + tb.ssq its sums of squares (else: the finished norm)
   auto standalone_norm = [&](int l, int j) -> int {
@@ -227,7 +230,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
         p.terms[0].W = eoff(w.qkv_Wkb, (size_t)l * padn(3 * hd) * Dp, es);
         p.terms[0].layout = DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED;
       }
-      p.out = tb.qkv; p.ldo = 3 * hd;
+      p.out = tb.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
@@ -323,7 +326,7 @@ const void* const* take_transformer(TransformerW& w, const void* const* t) {
 }
 
 int check_dims(const char* who, int dtype, int dim, int heads, int dim_head, int layers) {
-  DN_CHECK_ARG(dtype == DN_F32 || dtype == DN_BF16, "%s: bad dtype %d", who, dtype);
+  DN_CHECK_ARG(dtype == DN_F32 || dtype == DN_BF16 || dtype == DN_BF16X3, "%s: bad dtype %d", who, dtype);
   DN_CHECK_ARG(dim > 0 && dim % 4 == 0, "%s: dim=%d must be a positive multiple of 4", who, dim);
   DN_CHECK_ARG((heads * dim_head) % 64 == 0, "%s: heads*dim_head=%d must be a multiple of 64", who, heads * dim_head);
   DN_CHECK_ARG(layers >= 1 && layers <= DN_MAX_TERMS, "%s: wavenet layers=%d must be in 1..%d", who, layers, DN_MAX_TERMS);
@@ -344,7 +347,7 @@ EpsBufs plan_eps(const DnEps* m, int B, int T, int Bt, Arena& ar) {
   EpsBufs b;
   b.cond = (float*)ar.take((size_t)Bt * C * 4);
   b.gb = (float*)ar.take((size_t)Bt * m->n_row * 4);
-  b.gbh = es == 4 ? nullptr : ar.take((size_t)Bt * m->n_cond * es);
+  b.gbh = m->cfg.dtype == DN_F32 ? nullptr : ar.take((size_t)Bt * m->n_cond * es);
   b.xin = ar.take((size_t)M * zp * es);
   b.h0 = ar.take((size_t)M * Dp * es);
   b.wv = plan_wave(m->wn, M, es, ar);
@@ -436,7 +439,7 @@ int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, floa
   p.terms[0].A = cond; p.terms[0].lda = C; p.terms[0].W = m->cond_W;
   p.bias = m->cond_b; p.out = gb; p.ldo = m->n_row; p.out_dtype = DN_F32;
   DN_TRY(dn_conv_gemm(&p, s));
-  if (!split_norm_enabled(Dp)) return DN_OK;
+  if (!split_norm_enabled(Dp, dtype)) return DN_OK;
   // Split RMSNorm: the beta of an adaptive norm reaches its consumer as beta . W^T, which depends on t only -- two grouped
   // contractions (one group per layer) append it to the row: [q/kv columns | GEGLU columns (packed order)] per layer.
   const TransformerW& w = m->tf;
@@ -444,7 +447,7 @@ int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, floa
   const size_t tf_off = (size_t)m->cfg.wn_stacks * m->cfg.wn_layers * 2 * Dp;  // first transformer norm's [gamma ; beta]
   const void* A = gb;
   int lda = m->n_row;
-  if (es != 4) {  // operands in the arithmetic dtype
+  if (dtype != DN_F32) {  // operands in the arithmetic dtype
     DN_TRY(dn_convert_rows(gb, DN_F32, m->n_row, gbh, dtype, m->n_cond, n, m->n_cond, s));
     A = gbh; lda = m->n_cond;
   }
@@ -480,12 +483,12 @@ int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const i
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
     // layer 0's attention norm rides on the contraction that opens the residual stream
     const float* gb0 = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-    if (fuse_norm_enabled(Dp)) set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb0, gb_ld);
-    else if (split_norm_enabled(Dp)) set_split_norm(fin, b.tf, Dp, D, dtype, nullptr, gb0, gb_ld);
+    if (fuse_norm_enabled(Dp, dtype)) set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb0, gb_ld);
+    else if (split_norm_enabled(Dp, dtype)) set_split_norm(fin, b.tf, Dp, D, dtype, nullptr, gb0, gb_ld);
     DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, gb, gb_ld, b.wv, fin, s));
   }
   const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-  const bool xn_ready = fuse_norm_enabled(Dp) || split_norm_enabled(Dp);
+  const bool xn_ready = fuse_norm_enabled(Dp, dtype) || split_norm_enabled(Dp, dtype);
   DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, gb + m->n_cond, b.tf, b.tp, Dp, dtype, xn_ready, s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
@@ -528,7 +531,7 @@ extern "C" int dn_eps_forward(DnEps* m, const float* x, const int32_t* t, const 
 
 static size_t ddim_extra_bytes(const DnEps* m, int B, int T, int start_step) {
   const size_t C = (size_t)m->cfg.dim * m->cfg.cond_mult;
-  return (size_t)B * T * m->cfg.latent * 4 + (size_t)start_step * (m->n_row + C) * 4 + (size_t)start_step * m->n_cond * 2 +
+  return (size_t)B * T * m->cfg.latent * 4 + (size_t)start_step * (m->n_row + C) * 4 + (size_t)start_step * m->n_cond * 4 +
          (size_t)(B + start_step) * 4 + 4096;
 }
 
@@ -580,7 +583,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   int32_t* counter = (int32_t*)ar.take(64);
   float* table = (float*)ar.take((size_t)start_step * m->n_row * 4);  // conditioning rows for t = 0..start_step-1
   float* cond_all = (float*)ar.take((size_t)start_step * C * 4);
-  void* table_h = esize(m->cfg.dtype) == 4 ? nullptr : ar.take((size_t)start_step * m->n_cond * 2);
+  void* table_h = m->cfg.dtype == DN_F32 ? nullptr : ar.take((size_t)start_step * m->n_cond * esize(m->cfg.dtype));
   int32_t* tall = (int32_t*)ar.take((size_t)start_step * 4);
   const int last = start_step == 1 ? 0 : 1;  // the loop breaks after the t == 1 update (:1444-1445)
   int n_eval = start_step - last;             // t = start_step-1 ... last
@@ -704,9 +707,12 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const void* __restrict_
     const bool use_alt = alt && flag && flag[b] != 0;
     const void* sp = use_alt ? alt : src;
     const int64_t so = (use_alt ? 0 : (int64_t)b * src_bstride) + (int64_t)j * ld + c;
-    const float v = src_dtype == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(sp)[so]) : reinterpret_cast<const float*>(sp)[so];
+    const float v = src_dtype == DN_BF16X3 ? load1_split(sp, so)
+                    : src_dtype == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(sp)[so]) : reinterpret_cast<const float*>(sp)[so];
     const int64_t o = ((int64_t)b * rows_total + row0 + j) * ld + c;
-    if (dst_dtype == DN_BF16)
+    if (dst_dtype == DN_BF16X3)
+      store1_split(dst, o, v);
+    else if (dst_dtype == DN_BF16)
       reinterpret_cast<uint16_t*>(dst)[o] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
     else
       reinterpret_cast<float*>(dst)[o] = v;
@@ -825,13 +831,13 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     {
       DnGemmParams p = gemm_base(dtype, B * ml, hd, Dp, ml);
       p.terms[0].A = b.lat_act; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->rq_W, (size_t)l * padn(hd) * Dp, es);
-      p.out = b.rq; p.ldo = hd;
+      p.out = b.rq; p.ldo = hd; p.out_dtype = side_dtype(dtype);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {
       DnGemmParams p = gemm_base(dtype, B * Lk, 2 * hd, Dp, Lk);
       p.terms[0].A = b.kvsrc; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->rkv_W, (size_t)l * padn(2 * hd) * Dp, es);
-      p.out = b.rkv; p.ldo = 2 * hd;
+      p.out = b.rkv; p.ldo = 2 * hd; p.out_dtype = side_dtype(dtype);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     DN_TRY(attn_call(dtype, b.rq, hd, b.rkv, eoff(b.rkv, hd, es), 2 * hd, b.rao, hd, B, ml, Lk, c.heads, c.dim_head, b.klen, s));
@@ -865,7 +871,7 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     p.groups = c.depth;
     p.terms[0].A = b.c_act; p.terms[0].lda = Dp; p.terms[0].a_gstride = 0;
     p.terms[0].W = m->ckv_W; p.terms[0].w_gstride = (int64_t)padn(2 * hd) * Dp;
-    p.out = b.ckv; p.ldo = 2 * hd; p.out_gstride = (int64_t)B * ml * 2 * hd;
+    p.out = b.ckv; p.ldo = 2 * hd; p.out_gstride = (int64_t)B * ml * 2 * hd; p.out_dtype = side_dtype(dtype);
     DN_TRY(dn_conv_gemm(&p, s));
   }
   // ---- the eps-predictor proper (:861-876)
@@ -892,7 +898,7 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     {
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
       p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
-      p.out = b.qkv; p.ldo = 3 * hd;
+      p.out = b.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     DN_TRY(attn_call(dtype, b.qkv, 3 * hd, eoff(b.qkv, hd, es), eoff(b.qkv, 2 * hd, es), 3 * hd, b.ao, hd, B, T, 0, c.heads, c.dim_head, lengths, s));
@@ -907,7 +913,7 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     {
       DnGemmParams p = gemm_base(dtype, M, hd, Dp, T);
       p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->cq_W, (size_t)l * padn(hd) * Dp, es);
-      p.out = b.cq; p.ldo = hd;
+      p.out = b.cq; p.ldo = hd; p.out_dtype = side_dtype(dtype);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const int32_t* __restric
       const float v = silu(s + bias[c]);
       out[(int64_t)b * ldo + c] = v;
       if (out_act) {
-        if (act_dtype == DN_BF16)
+        if (act_dtype == DN_BF16X3)
+          store1_split(out_act, (int64_t)b * ldo + c, v);
+        else if (act_dtype == DN_BF16)
           reinterpret_cast<uint16_t*>(out_act)[(int64_t)b * ldo + c] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
         else
           reinterpret_cast<float*>(out_act)[(int64_t)b * ldo + c] = v;
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const int32_t* __restric
 
 // ------------------------------------------------------------------------------------------ scheduler
 __device__ __forceinline__ void store_act1(void* p, int64_t off, int dtype, float v) {
-  if (dtype == DN_BF16)
+  if (dtype == DN_BF16X3)
+    store1_split(p, off, v);
+  else if (dtype == DN_BF16)
     reinterpret_cast<uint16_t*>(p)[off] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
   else
     reinterpret_cast<float*>(p)[off] = v;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
     float v = 0.f;
     if (c < C) {
       const int64_t so = (int64_t)m * lds + c;
-      v = sdt == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[so]) : reinterpret_cast<const float*>(src)[so];
+      v = sdt == DN_BF16X3 ? load1_split(src, so) : sdt == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[so]) : reinterpret_cast<const float*>(src)[so];
     }
     store_act1(dst, i, ddt, v);
   }

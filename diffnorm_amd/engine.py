@@ -14,11 +14,17 @@ from . import _lib, packing
 
 
 def _dtype_code(dtype) -> int:
-    if dtype in (_lib.DN_BF16, "bf16", torch.bfloat16):
+    if isinstance(dtype, str):
+        names = {"bf16": _lib.DN_BF16, "f32": _lib.DN_F32, "fp32": _lib.DN_F32, "bf16x3": _lib.DN_BF16X3}
+        if dtype in names:
+            return names[dtype]
+    elif dtype is torch.bfloat16:
         return _lib.DN_BF16
-    if dtype in (_lib.DN_F32, "f32", "fp32", torch.float32):
+    elif dtype is torch.float32:
         return _lib.DN_F32
-    raise ValueError(f"unsupported arithmetic dtype {dtype!r} (use 'bf16' or 'f32')")
+    elif isinstance(dtype, int) and dtype in (_lib.DN_F32, _lib.DN_BF16, _lib.DN_BF16X3):
+        return dtype
+    raise ValueError(f"unsupported arithmetic dtype {dtype!r} (use 'bf16', 'bf16x3' or 'f32')")
 
 
 def _require_cuda(device) -> torch.device:

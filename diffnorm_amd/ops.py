@@ -34,37 +34,43 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               norm_gb_shared: bool = False, norm_gb_half: int = 0, tile: int = 0, taps_inner: Optional[bool] = None,
               norm_ssq: Optional[torch.Tensor] = None, row_ssq: Optional[torch.Tensor] = None, row_D: int = 0,
               row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False, a_kblocked: bool = False,
-              w_kblocked: bool = False, out_kblocked: bool = False, band: int = 0):
+              w_kblocked: bool = False, out_kblocked: bool = False, band: int = 0, x3: bool = False):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
     a_grouped=False), W, bias, out, res and gamma_beta ([Bc, G, 2*half]) is the group.
+    x3: DN_BF16X3 -- A and W are split rows (packing.split_rows: bf16 tensors of twice the element count per row); a bf16 `out` /
+    `norm_out` is then written as split rows too, an fp32 one plainly.
     """
     lib = _lib.load()
     p = _lib.GemmParams()
     A0, W0, _ = terms[0]
     M = A0.shape[-2]
     p.n_terms = len(terms)
-    p.dtype = _code(A0)
+    p.dtype = _lib.DN_BF16X3 if x3 else _code(A0)
+    sw = 2 if x3 else 1  # a split row stores 2 bf16 per element
+    assert not x3 or (A0.dtype == torch.bfloat16 and not (a_kblocked or w_kblocked or out_kblocked))
+    code_o = lambda t: _lib.DN_BF16X3 if (x3 and t.dtype == torch.bfloat16) else _code(t)
+    wid = lambda t: t.shape[-1] // 2 if (x3 and t.dtype == torch.bfloat16) else t.shape[-1]
     # K-blocked operands (packing.kblock): [K/32, rows, 32]
-    K = W0.shape[-3] * 32 if w_kblocked else W0.shape[-1]
+    K = W0.shape[-3] * 32 if w_kblocked else W0.shape[-1] // sw
     p.M, p.N, p.K, p.T = M, N, K, T
     p.groups, p.epilogue = groups, epilogue
     for i, (A, W, shift) in enumerate(terms):
         assert A.is_contiguous() and W.is_contiguous() and A.dtype == W.dtype
         t = p.terms[i]
-        t.A, t.W, t.lda, t.shift = A.data_ptr(), W.data_ptr(), (K if a_kblocked else A.shape[-1]), shift
+        t.A, t.W, t.lda, t.shift = A.data_ptr(), W.data_ptr(), (K if a_kblocked else A.shape[-1] // sw), shift
         t.layout = (_lib.LAYOUT_A_KBLOCKED if a_kblocked else 0) | (_lib.LAYOUT_W_KBLOCKED if w_kblocked else 0)
-        t.a_gstride = A.shape[-2] * A.shape[-1] if (groups > 1 and a_grouped and A.dim() == 3) else 0
-        t.w_gstride = W.shape[-2] * W.shape[-1] if (groups > 1 and W.dim() == 3) else 0
+        t.a_gstride = A.shape[-2] * A.shape[-1] // sw if (groups > 1 and a_grouped and A.dim() == 3) else 0
+        t.w_gstride = W.shape[-2] * W.shape[-1] // sw if (groups > 1 and W.dim() == 3) else 0
         t.shift_by_group = int(shift_by_group)
     if bias is not None:
         assert bias.dtype == torch.float32
         p.bias = bias.data_ptr()
         p.bias_gstride = bias.shape[-1] if groups > 1 else 0
-    p.out, p.ldo, p.out_dtype = out.data_ptr(), (N if out_kblocked else out.shape[-1]), _code(out)
+    p.out, p.ldo, p.out_dtype = out.data_ptr(), (N if out_kblocked else wid(out)), code_o(out)
     p.out_layout = _lib.LAYOUT_OUT_KBLOCKED if out_kblocked else 0
-    p.out_gstride = (M * N if out_kblocked else out.shape[-2] * out.shape[-1]) if groups > 1 else 0
+    p.out_gstride = (M * N if out_kblocked else out.shape[-2] * wid(out)) if groups > 1 else 0
     if res is not None:
         p.res, p.ldr, p.res_dtype = res.data_ptr(), res.shape[-1], _code(res)
         p.res_gstride = res.shape[-2] * res.shape[-1] if groups > 1 else 0
@@ -78,7 +84,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
         p.pos_table, p.pos_ld = pos_table.data_ptr(), pos_table.shape[-1]
         p.lengths = lengths.data_ptr()
     if norm_out is not None:  # fused RMSNorm of the produced rows (RESADD / POSEMB, N <= 512)
-        p.norm_out, p.norm_ld, p.norm_dtype, p.norm_D = norm_out.data_ptr(), norm_out.shape[-1], _code(norm_out), norm_D
+        p.norm_out, p.norm_ld, p.norm_dtype, p.norm_D = norm_out.data_ptr(), wid(norm_out), code_o(norm_out), norm_D
         p.norm_gamma = _lib.ptr(norm_gamma)
         p.norm_gb = _lib.ptr(norm_gb)
         p.norm_gb_ld = 0 if (norm_gb is None or norm_gb_shared) else norm_gb.stride(0)

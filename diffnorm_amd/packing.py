@@ -5,7 +5,7 @@ weights [out,in]).  Output: the ordered tensor tables `dn_eps_create` / `dn_vae_
 (diffnorm_amd/csrc/engine.h documents each entry).  Packing rules:
 
 * every weight becomes [rows padded to 128][K padded to 64] with K contiguous, in the arithmetic
-  dtype (bf16 or fp32); pads are zeros, so padded channels stay exactly zero through the network;
+  dtype (bf16, fp32, or DN_BF16X3 split rows: hi / lo bf16 halves per 32 elements, `split_rows`); pads are zeros, so padded channels stay exactly zero through the network;
 * a k-tap causal conv becomes k matrices, tap j multiplying the frame t-(k-1-j)*dilation;
 * Linear(D, 2*inner) of the GEGLU is interleaved per 16-row MFMA tile = [8 value rows ; 8 gate rows of the same output
   columns], so every tile is self-contained and one wave holds value and gate of a column (epilogue DN_EPI_GEGLU);
@@ -35,12 +35,40 @@ def _act_dtype(dtype: int):
     return torch.bfloat16 if dtype == _lib.DN_BF16 else torch.float32
 
 
+def split_rows(t: torch.Tensor, weight: bool = False) -> torch.Tensor:
+    """fp32 [..., K] (K a multiple of 32) -> DN_BF16X3 "split rows" (include/diffnorm_hip.h): a bf16 tensor [..., 2 K] of the same
+    byte size as the fp32 one, every group of 32 elements stored as two 64-byte halves: hi = bf16(x) and lo = bf16(x - hi) (the
+    difference is exact in fp32), so x = hi + lo to 16 mantissa bits.  Activations store [hi | lo], weights [lo | hi]: a
+    contraction that walks a row in 64-byte K-tiles then meets (w_lo, a_hi) and (w_hi, a_lo) and has to keep only the
+    activations' hi fragments across the pair for its three products w_lo a_hi + w_hi a_lo + w_hi a_hi."""
+    t = t.float()
+    assert t.shape[-1] % 32 == 0, t.shape
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    halves = [lo, hi] if weight else [hi, lo]
+    g = torch.stack([h.reshape(*t.shape[:-1], -1, 32) for h in halves], dim=-2)  # [..., K/32, 2, 32]
+    return g.reshape(*t.shape[:-1], 2 * t.shape[-1]).contiguous()
+
+
+def unsplit_rows(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of split_rows (either order; tests): bf16 [..., 2 K] -> fp32 [..., K] = hi + lo."""
+    g = t.reshape(*t.shape[:-1], -1, 2, 32).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*t.shape[:-1], t.shape[-1] // 2)
+
+
+def _arith(t: torch.Tensor, dtype: int, weight: bool = True) -> torch.Tensor:
+    """fp32 tensor (last dim = K, padded) -> the arithmetic dtype's storage (weight: a packed weight matrix, else activation rows)."""
+    if dtype == _lib.DN_BF16X3:
+        return split_rows(t, weight=weight)
+    return t.to(_act_dtype(dtype))
+
+
 def _mat(w: torch.Tensor, dtype: int, rows: int = None, cols: int = None) -> torch.Tensor:
     """[N,K] -> zero-padded [rows or padn(N), cols or padk(K)] in the arithmetic dtype."""
     n, k = w.shape
     out = torch.zeros(rows or padn(n), cols or padk(k), dtype=torch.float32)
     out[:n, :k] = w.float()
-    return out.to(_act_dtype(dtype))
+    return _arith(out, dtype)
 
 
 def _vec(b: torch.Tensor, n: int) -> torch.Tensor:
@@ -122,7 +150,7 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
         bp = torch.zeros(2 * ip)
         wp[keep, :dim] = w[rows[keep]]
         bp[keep] = b[rows[keep]]
-        ffin.append(wp.to(_act_dtype(dtype)))
+        ffin.append(_arith(wp, dtype))
         ffin_b.append(bp)
         ffc.append(_conv(g(p + "5.2.1.weight"), dtype))
         ffc_b.append(_vec(g(p + "5.2.1.bias"), ip))
@@ -216,14 +244,14 @@ def pack_eps_cond(sd: SD, cfg, dtype: int) -> List[torch.Tensor]:
         w, b = sd[f + "0.weight"].float(), sd[f + "0.bias"].float()
         wp, bp = torch.zeros(2 * ip, Dp), torch.zeros(2 * ip)
         wp[keep, :D], bp[keep] = w[rows[keep]], b[rows[keep]]
-        rffin.append(wp.to(_act_dtype(dtype)))
+        rffin.append(_arith(wp, dtype))
         rffin_b.append(bp)
         rffout.append(_mat(sd[f + "2.weight"], dtype))
         rffout_b.append(_vec(sd[f + "2.bias"], Dp))
     t = "transformer.layers."
     return [
         _mat(sd["to_prompt_cond.1.weight"], _lib.DN_F32), sd["to_prompt_cond.1.bias"].float().clone(), sd["null_prompt_cond"].float().clone(),
-        pad_rows(sd["null_prompt_tokens"].float()).to(_act_dtype(dtype)),
+        _arith(pad_rows(sd["null_prompt_tokens"].float()), dtype, weight=False),
         _mat(sd[r + "proj_context.weight"], dtype), _vec(sd[r + "proj_context.bias"], Dp), lat_pos,
         torch.stack(rq), torch.stack(rkv), torch.stack(rout), torch.stack(rffin), torch.stack(rffin_b), torch.stack(rffout),
         torch.stack(rffout_b), sd[r + "norm.gamma"].float().clone(),

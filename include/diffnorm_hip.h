@@ -15,7 +15,18 @@
  *   - activations are channels-last row-major: row m = b*T + t, `ld` elements between rows.
  *   - `dtype` selects the arithmetic of the contractions: DN_BF16 = bf16 MFMA operands with fp32
  *     accumulation (activations that feed a contraction are stored bf16, the transformer residual
- *     stream stays fp32); DN_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.
+ *     stream stays fp32); DN_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end;
+ *     DN_BF16X3 = split-operand bf16: every contraction operand is stored as a bf16 pair (hi, lo) with x ~ hi + lo
+ *     (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) and a product runs as three bf16 MFMAs into one fp32
+ *     accumulator, a_hi b_hi + a_lo b_hi + a_hi b_lo (the dropped a_lo b_lo term is 2^-18 relative), i.e. fp32-class
+ *     results (1e-3 budget of north_star's fp32 column) at a third of the bf16 MFMA rate instead of a sixteenth.
+ *     Everything that is not a contraction operand is fp32 exactly as in DN_F32 mode.
+ *   - DN_BF16X3 storage ("split rows"): an element takes 4 bytes like fp32 and ld / K / column offsets count elements, but
+ *     every group of 32 consecutive elements of a row is laid out as two 64-byte halves of 32 bf16 each: ACTIVATIONS
+ *     (everything a kernel of this library writes, and every A operand) store [hi | lo], packed WEIGHTS (W operands)
+ *     store [lo | hi].  A K-tile of 128 bytes per row then reads as two bf16 k-steps, and a kernel that walks a row in
+ *     64-byte K-tiles meets (w_lo, a_hi) then (w_hi, a_lo): it keeps only a_hi across the pair for its three products.
+ *     Row strides, K and column offsets of such tensors are multiples of 32 elements; bases are 128-byte aligned.
  */
 #ifndef DIFFNORM_HIP_H
 #define DIFFNORM_HIP_H
@@ -27,7 +38,7 @@
 extern "C" {
 #endif
 
-enum { DN_F32 = 0, DN_BF16 = 1 };
+enum { DN_F32 = 0, DN_BF16 = 1, DN_BF16X3 = 2 };
 
 enum {
   DN_OK = 0,
@@ -79,7 +90,7 @@ enum { DN_LAYOUT_A_KBLOCKED = 1, DN_LAYOUT_W_KBLOCKED = 2, DN_LAYOUT_OUT_KBLOCKE
 typedef struct {
   DnGemmTerm terms[DN_MAX_TERMS];
   int32_t n_terms;
-  int32_t dtype;       /* DN_F32 | DN_BF16: element type of A and W                                 */
+  int32_t dtype;       /* DN_F32 | DN_BF16 | DN_BF16X3: element type of A and W                     */
   int32_t M, N, K;     /* rows (B*T), stored output columns (multiple of 4), K per term (multiple of
                           64 for bf16 / 32 for f32)                                                 */
   int32_t T;           /* frames per sequence: row m -> (b = m / T, t = m % T)                      */
@@ -89,7 +100,7 @@ typedef struct {
   int64_t bias_gstride;
   void* out;           /* [M, ldo]                                                                  */
   int32_t ldo;
-  int32_t out_dtype;   /* DN_F32 | DN_BF16                                                          */
+  int32_t out_dtype;   /* DN_F32 | DN_BF16 | DN_BF16X3 (split rows: ldo, N offsets multiples of 32)  */
   int64_t out_gstride;
   const void* res;     /* FILM_GATE: [M, ldr] in res_dtype; RESADD: fp32 [M, ldr] (may alias out)   */
   int32_t ldr;

@@ -40,7 +40,7 @@ def eng():
 # its ablation (profiles/r02_bf16_rounding_ablation.txt) shows no single rounding point dominating -- weights 1.2e-2 alone, every
 # activation kept fp32 still 1.0e-2 -- so only a split-operand mode (3 MFMAs per product) would close it.  The thresholds below
 # are the measured values + 15 %, not a loose band; f32 mode carries the strict 1e-3 check everywhere.
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 1e-2)])
 def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
     engine, _ = eng
     g = golden("eps_tiny")
@@ -50,7 +50,7 @@ def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
     got = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
     mask = O.lengths_to_mask(lens, x.shape[1])
     ref = T_(g["eps"])
-    if dtype == "f32":
+    if dtype != "bf16":
         assert maxerr(got[mask], ref[mask]) < tol
         # padded frames are computed like upstream too (dense), so the whole tensor matches
         assert maxerr(got, ref) < tol * 3
@@ -60,7 +60,7 @@ def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
         assert maxerr(got[mask], ref[mask]) < 3.9e-2            # measured 3.3e-2 at t = 500 (see the note above)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 1e-2)])
 def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
     """DN_FUSE_NORM=1 routes the residual-closing contractions through the whole-row tile that also emits the next
     block's RMSNorm (off by default: slower at dim 512): same golden, and the same numbers as the default path."""
@@ -75,7 +75,7 @@ def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
     monkeypatch.delenv("DN_FUSE_NORM")
     mask = O.lengths_to_mask(lens, x.shape[1])
     ref = T_(g["eps"])
-    if dtype == "f32":
+    if dtype != "bf16":
         assert maxerr(got[mask], ref[mask]) < tol
         assert maxerr(got, base) < 1e-4
     else:
@@ -118,7 +118,7 @@ def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
     assert ((outs["1"][1] - T_(g2["eps"]))[mask] ** 2).mean().item() < 1e-4
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "bf16"])
 def test_eps_properties(eng, dtype):
     """Reference properties: valid frames are invariant to the content of right-padded frames,
     samples are independent across the batch, shared_t equals per-sample t."""
@@ -141,7 +141,7 @@ def test_eps_properties(eng, dtype):
     assert maxerr(single[0][mask[1]], a[1][mask[1]]) < 1e-6
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 1e-2)])
 def test_eps_full_cfg2_vs_reference_golden(eng, golden, dtype, tol):
     """BASELINE config 2: [8,256,128] latents, t=500, full-size eps-predictor, eps-MSE and max-abs vs the reference."""
     engine, _ = eng
@@ -157,13 +157,13 @@ def test_eps_full_cfg2_vs_reference_golden(eng, golden, dtype, tol):
     err = maxerr(got[mask], ref[mask])
     mse = ((got - ref)[mask] ** 2).mean().item()
     print(f"cfg2 {dtype}: max abs {err:.3e}  mse {mse:.3e}  ref rms {ref[mask].pow(2).mean().sqrt().item():.3f}")
-    if dtype == "f32":
+    if dtype != "bf16":
         assert err < tol and mse < tol
     else:  # eps-MSE is BASELINE config 2's criterion (1e-2): measured 1.08e-5; max-abs measured 1.41e-2 = 1.4x the 1e-2 budget (note above)
         assert mse < 2e-5 and err < 1.65e-2
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)])
 def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
     """VAE encode/decode + DDIM chains (start_step 1, 5, 50; T=200) with the reference's recorded noise."""
     engine, scheduler = eng
@@ -195,10 +195,10 @@ def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
             recon, logits, u = ve.decode(xs, lens)
             err = maxerr(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask])
             print(f"chain start={start} {dtype} graph={use_graph}: recon max abs err {err:.3e}")
-            assert err < (5e-3 if dtype == "f32" else 1.45e-2)  # measured: f32 2.4e-6; bf16 1.06e-2 / 1.19e-2 / 1.23e-2 (start 1 / 5 / 50)
+            assert err < (5e-3 if dtype != "bf16" else 1.45e-2)  # measured: f32 2.4e-6; bf16 1.06e-2 / 1.19e-2 / 1.23e-2 (start 1 / 5 / 50)
             got_units = torch.cat([u[i, : int(lens[i])] for i in range(B)]).cpu().numpy()
             agree = (got_units == g[f"s{start}_units"]).mean()
-            assert agree >= (0.99 if dtype == "f32" else 0.9), agree
+            assert agree >= (0.99 if dtype != "bf16" else 0.9), agree
         if start == 50:  # the same chain in two calls (max_evals, then continue on the kept conditioning table): bit-identical
             xc = x.clone()
             assert ee.ddim_loop(xc, lens.to(DEV).int(), start, coef, max_evals=7) == 7
@@ -213,7 +213,7 @@ def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
             assert maxerr(xe, xs) < tol * 5
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)])
 def test_vae_full_cfg1_vs_reference_golden(eng, golden, dtype, tol):
     """BASELINE config 1: 64 x [128,768] encode -> posterior sample -> decode -> 1004-way logits."""
     engine, _ = eng
@@ -235,12 +235,12 @@ def test_vae_full_cfg1_vs_reference_golden(eng, golden, dtype, tol):
     assert maxerr(rc[:2, :, :96][m2], T_(g["recon_head"])[m2]) < tol
     assert maxerr(lg[:2, :16], T_(g["logits_head"])) < tol
     margin = T_(g["margin"])
-    safe = mask & (margin > (1e-3 if dtype == "f32" else 5e-2))
+    safe = mask & (margin > (1e-3 if dtype != "bf16" else 5e-2))
     assert (units.cpu()[safe] == T_(g["units"]).int()[safe]).all()
     assert (units.cpu() == (lg.argmax(-1) - 4).int()).all()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)])
 @pytest.mark.parametrize("latent_flag", [16, 32])
 def test_vae_cascaded_encoders(eng, dtype, tol, latent_flag):
     """latent_dim = 16 / 32 build three / two cascaded WaveNet encoders and decoders (reference latent_module.py:1044-1081):
@@ -262,7 +262,7 @@ def test_vae_cascaded_encoders(eng, dtype, tol, latent_flag):
     assert maxerr(recon.cpu()[mask], r_ref[mask]) < tol and maxerr(logits.cpu()[mask], l_ref[mask]) < tol
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)])
 def test_eps_conditional_variant_vs_reference_golden(eng, golden, dtype, tol):
     """SURVEY 8 f3 (use_cond=True): Model.forward with condition_on_prompt -- pooled-prompt condition (2x conditioning width),
     PerceiverResampler, cross-attention in every layer -- and classifier-free guidance, against the reference's outputs

@@ -148,3 +148,22 @@ def test_sharded_normalisation_world2_matches_single_rank():
         results[world] = dict(got)
     assert len(results[1][0]) == 11
     assert results[2][0] == results[2][1] == results[1][0]
+
+
+def test_split_rows_round_trip_on_host():
+    """split_rows / unsplit_rows: x = hi + lo to 2^-16 relative, the layout is 32 hi then 32 lo per group of 32."""
+    from diffnorm_amd import packing
+
+    def seeded(shape, seed):
+        return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+    x = seeded((5, 96), 1) * torch.logspace(-6, 6, 96)
+    s = packing.split_rows(x)
+    assert s.dtype == torch.bfloat16 and s.shape == (5, 192)
+    back = packing.unsplit_rows(s)
+    assert ((back - x).abs() <= x.abs() * 2.0 ** -16).all()
+    assert torch.equal(s[:, :32].float(), x[:, :32].to(torch.bfloat16).float())       # hi of group 0
+    assert torch.equal(s[:, 64:96].float(), x[:, 32:64].to(torch.bfloat16).float())   # hi of group 1
+    w = packing.split_rows(x, weight=True)                                              # weights: lo half first
+    assert torch.equal(w[:, 32:64], s[:, :32]) and torch.equal(w[:, :32], s[:, 32:64])
+    assert torch.equal(packing.unsplit_rows(w), back)
