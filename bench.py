@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md; bf16x3 = three bf16 MFMAs per product
 
 
 def parse():
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--timesteps", type=int, default=1000)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="one stream per chain instead of two forked half-batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,18 +58,24 @@ def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
     inner, ip = 1365, packing.padk(1365)
     M = B * T
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
-    a = torch.randn(M, ip, device=dev).to(tdt)
+    a = torch.randn(M, ip, device=dev)
     a[:, inner:] = 0
-    w = (torch.randn(3, packing.padn(inner), ip, device=dev) * 0.02).to(tdt)
+    w = torch.randn(3, packing.padn(inner), ip, device=dev) * 0.02
+    x3 = dtype == "bf16x3"
+    if x3:  # split rows: (hi, lo) bf16 pairs, twice the bf16 count per row
+        a, w = packing.split_rows(a.cpu()).to(dev), packing.split_rows(w.cpu(), weight=True).to(dev)
+        out = torch.empty(M, 2 * ip, device=dev, dtype=torch.bfloat16)
+    else:
+        a, w = a.to(tdt), w.to(tdt)
+        out = torch.empty(M, ip, device=dev, dtype=tdt)
     bias = torch.zeros(ip, device=dev)
-    out = torch.empty(M, ip, device=dev, dtype=tdt)
     terms = [(a, w[j], 2 - j) for j in range(3)]
     for _ in range(3):
-        ops.conv_gemm(terms, out, T, ip, bias=bias)
+        ops.conv_gemm(terms, out, T, ip, bias=bias, x3=x3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.conv_gemm(terms, out, T, ip, bias=bias)
+        ops.conv_gemm(terms, out, T, ip, bias=bias, x3=x3)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters, 2.0 * M * (3 * inner) * inner

@@ -318,6 +318,284 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ split-operand (DN_BF16X3) attention
+// q / k / v are plain fp32 in memory (the engine keeps them out of the split layout); every product runs as three bf16 MFMAs
+// on (hi, lo) bf16 pairs made on the fly: Q is split once per workgroup into register fragments, a K / V tile is split when
+// it goes from its staging registers to LDS -- a tile row holds the hi halves of the head's dims in bytes [0, 128) and the lo
+// halves in [128, 256), i.e. the bf16 kernel's 256-byte rows and swizzle with "dims 64..127" = lo -- and P is split from the
+// fp32 softmax output.  S^T = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi, O^T += V_lo P_hi + V_hi P_lo + V_hi P_hi; softmax, masks
+// and the denominators are fp32 as in the exact-fp32 kernel.  96 bf16 MFMAs per 64-key tile instead of 256 fp32 ones.
+// dim_head <= 64 (larger heads run the exact-fp32 kernel).
+template <int DHP, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(DHP == 32 || DHP == 64, "padded head dim");
+  using L = BF16;                     // LDS geometry and swizzle of the bf16 kernel
+  constexpr int ROWB = AttnGeom<L>::ROWB, LO = 128;
+  constexpr int KS_D = DHP / 32;      // 32-dim k-steps of QK^T
+  constexpr int NCH = DHP / 4;        // 16-byte (4 x fp32) chunks per K / V row in memory
+  constexpr int DT = DHP / 16;
+  constexpr int TILE_LDS = KV_TILE * ROWB;
+  char* k_lds = smem;
+  char* v_lds = smem + 2 * TILE_LDS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  int qblk, h, b;
+  if (p.pad3_ & 1) { qblk = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+  else dn_xcd_block_map(qblk, h, b);
+  const int T = p.T, dh = p.dim_head;
+  const int Tk = p.Tk > 0 ? p.Tk : T;
+  const int q0 = qblk * 128 + wave * 32;
+  const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)b * T * p.ldq + h * dh;
+  const float* kp = reinterpret_cast<const float*>(p.k) + (int64_t)b * Tk * p.ldk + h * dh;
+  const float* vp = reinterpret_cast<const float*>(p.v) + (int64_t)b * Tk * p.ldv + h * dh;
+
+  auto split4 = [](const float4 v, uint2& hi, uint2& lo) {
+    split_pair(v.x, v.y, hi.x, lo.x);
+    split_pair(v.z, v.w, hi.y, lo.y);
+  };
+  // Q fragments (B operand): lane (fr, fg) holds dims ks*32 + fg*8 .. +7 of query fr, as hi and lo halves
+  uint4 qh[2][KS_D], ql[2][KS_D];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int q = q0 + qt * 16 + fr;
+    q = q < T ? q : T - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS_D; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      const float* src = qp + (int64_t)q * p.ldq + d;
+      const float4 a = d < dh ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
+      const float4 c = d + 4 < dh ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0, 0, 0, 0);
+      uint2 h0, l0, h1, l1;
+      split4(a, h0, l0);
+      split4(c, h1, l1);
+      qh[qt][ks] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      ql[qt][ks] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+  }
+
+  f32x4 acc_o[DT][2];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i][0] = acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+
+  int len = p.lengths ? p.lengths[b] : Tk;
+  len = len < Tk ? len : Tk;
+  float sc = p.scale * 1.44269504088896340736f;
+  if (len <= 0) {
+    len = Tk;
+    sc = 0.f;
+  }
+  uint32_t drop_thr = 0, drop_row[2] = {0, 0};
+  float drop_inv = 1.f;
+  if constexpr (DROP) {
+    drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
+    drop_inv = 1.0f / (1.0f - p.dropout_p);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      drop_row[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fr)), p.seed_lo);
+  }
+  auto dropped = [&](float pv, int qt, int key) -> float {
+    if constexpr (DROP) return dn_drop_keep(drop_row[qt], (uint32_t)key, p.seed_hi, drop_thr) ? pv * drop_inv : 0.f;
+    return pv;
+  };
+
+  // fp32 K / V tiles travel global -> registers ONE tile ahead (a tile's three-product work, ~2.5k cycles, covers a loaded L2
+  // round trip; a second register set would cost the second workgroup per CU) and are split into bf16 halves on the way to LDS
+  constexpr int NPT = KV_TILE * NCH / 256;  // 16-byte chunks per thread per tensor per tile
+  constexpr int RSTEP = 256 / NCH;          // tile rows between a thread's chunks: its chunk column is the same in all of them
+  static_assert(RSTEP % 8 == 0, "a thread's rows share one swizzle key");
+  const int ld_r0 = tid / NCH, ld_ch = tid - ld_r0 * NCH;
+  const bool ld_col = ld_ch * 4 < dh;
+  const float* kp_t = kp + (int64_t)ld_r0 * p.ldk + ld_ch * 4;  // per-thread bases; the tile / chunk row offsets are uniform
+  const float* vp_t = vp + (int64_t)ld_r0 * p.ldv + ld_ch * 4;
+  const int wr_h = lds_off<L>(ld_r0, ld_ch * 8), wr_l = lds_off<L>(ld_r0, LO + ld_ch * 8);
+  float4 kreg[NPT], vreg[NPT];
+  auto issue_loads = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int key = kv0 + i * RSTEP;  // + ld_r0
+      kreg[i] = vreg[i] = make_float4(0, 0, 0, 0);
+      if (ld_col && key + ld_r0 < Tk) {
+        kreg[i] = *reinterpret_cast<const float4*>(kp_t + (int64_t)key * p.ldk);
+        vreg[i] = *reinterpret_cast<const float4*>(vp_t + (int64_t)key * p.ldv);
+      }
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int o = buf * TILE_LDS + i * RSTEP * ROWB;
+      uint2 hi, lo;
+      split4(kreg[i], hi, lo);
+      *reinterpret_cast<uint2*>(k_lds + wr_h + o) = hi;
+      *reinterpret_cast<uint2*>(k_lds + wr_l + o) = lo;
+      split4(vreg[i], hi, lo);
+      *reinterpret_cast<uint2*>(v_lds + wr_h + o) = hi;
+      *reinterpret_cast<uint2*>(v_lds + wr_l + o) = lo;
+    }
+  };
+  int k_base_h[KS_D], k_base_l[KS_D], v_base_h[DT], v_base_l[DT];
+#pragma unroll
+  for (int ks = 0; ks < KS_D; ++ks) {
+    k_base_h[ks] = lds_off<L>(fr, ks * 64 + fg * 16);
+    k_base_l[ks] = lds_off<L>(fr, LO + ks * 64 + fg * 16);
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    v_base_h[dt] = lds_off<L>(fg * 4 + (fr >> 2), dt * 32 + (fr & 3) * 8);
+    v_base_l[dt] = lds_off<L>(fg * 4 + (fr >> 2), LO + dt * 32 + (fr & 3) * 8);
+  }
+  using SET0 = std::integral_constant<int, 0>;
+  using SET1 = std::integral_constant<int, 1>;
+  issue_loads(0);
+  write_tile(0);
+  __syncthreads();
+  auto tr_read = [&](const char* base) -> uint2 {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    return __builtin_bit_cast(uint2, r);
+  };
+  auto key_tile = [&](auto cur_c, int kv0) {
+    constexpr int buf = decltype(cur_c)::value;
+    const bool more = kv0 + KV_TILE < len;
+    if (more) issue_loads(kv0 + KV_TILE);  // lands under this tile's products; written to the other buffer at the end
+    const char* kt_lds = k_lds + buf * TILE_LDS;
+    const char* vt_lds = v_lds + buf * TILE_LDS;
+
+    // ---- S^T = K . Q^T, three bf16 products, small terms first
+    f32x4 acc_s[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc_s[kt][0] = acc_s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS_D; ++ks) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const uint4 kh = *reinterpret_cast<const uint4*>(kt_lds + k_base_h[ks] + kt * 16 * ROWB);
+        const uint4 kl = *reinterpret_cast<const uint4*>(kt_lds + k_base_l[ks] + kt * 16 * ROWB);
+        mma_kstep<BF16>(acc_s[kt][0], kl, qh[0][ks]);
+        mma_kstep<BF16>(acc_s[kt][1], kl, qh[1][ks]);
+        mma_kstep<BF16>(acc_s[kt][0], kh, ql[0][ks]);
+        mma_kstep<BF16>(acc_s[kt][1], kh, ql[1][ks]);
+        mma_kstep<BF16>(acc_s[kt][0], kh, qh[0][ks]);
+        mma_kstep<BF16>(acc_s[kt][1], kh, qh[1][ks]);
+      }
+    }
+    // ---- online softmax in fp32 (log2 domain), as the other kernels
+    auto softmax_tile = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (MASKED) {
+              const int key = kv0 + kt * 16 + fg * 4 + r;
+              acc_s[kt][qt][r] = key < len ? acc_s[kt][qt][r] : NEG_BIG;
+            }
+            mx = fmaxf(mx, acc_s[kt][qt][r]);
+          }
+        mx = quad_xor_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc);
+        const float neg_ms = -m_new * sc;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            acc_s[kt][qt][r] = pv;
+            rs += pv;
+          }
+        rs = quad_xor_sum(rs);
+        l_run[qt] = l_run[qt] * alpha + rs;
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) acc_o[dt][qt] *= alpha;
+        }
+        m_run[qt] = m_new;
+      }
+    };
+    if (kv0 + KV_TILE > len) softmax_tile(std::true_type{});
+    else softmax_tile(std::false_type{});
+
+    // ---- O^T += V^T . P^T with P split into its bf16 halves
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 ph[2], pl[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int ka = kv0 + (2 * kk) * 16 + fg * 4, kb = ka + 16;
+        float v8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v8[r] = dropped(acc_s[2 * kk][qt][r], qt, ka + r);
+          v8[4 + r] = dropped(acc_s[2 * kk + 1][qt][r], qt, kb + r);
+        }
+        split_pair(v8[0], v8[1], ph[qt].x, pl[qt].x);
+        split_pair(v8[2], v8[3], ph[qt].y, pl[qt].y);
+        split_pair(v8[4], v8[5], ph[qt].z, pl[qt].z);
+        split_pair(v8[6], v8[7], ph[qt].w, pl[qt].w);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const uint2 h0 = tr_read(vt_lds + v_base_h[dt] + (2 * kk) * 16 * ROWB), h1 = tr_read(vt_lds + v_base_h[dt] + (2 * kk + 1) * 16 * ROWB);
+        const uint2 l0 = tr_read(vt_lds + v_base_l[dt] + (2 * kk) * 16 * ROWB), l1 = tr_read(vt_lds + v_base_l[dt] + (2 * kk + 1) * 16 * ROWB);
+        const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        mma_kstep<BF16>(acc_o[dt][0], vl, ph[0]);
+        mma_kstep<BF16>(acc_o[dt][1], vl, ph[1]);
+        mma_kstep<BF16>(acc_o[dt][0], vh, pl[0]);
+        mma_kstep<BF16>(acc_o[dt][1], vh, pl[1]);
+        mma_kstep<BF16>(acc_o[dt][0], vh, ph[0]);
+        mma_kstep<BF16>(acc_o[dt][1], vh, ph[1]);
+      }
+    }
+    if (more) write_tile(1 - buf);
+    __syncthreads();
+  };
+  for (int kv0 = 0; kv0 < len; kv0 += 2 * KV_TILE) {
+    key_tile(SET0{}, kv0);
+    if (kv0 + KV_TILE < len) key_tile(SET1{}, kv0 + KV_TILE);
+  }
+
+  char* op = reinterpret_cast<char*>(p.out);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + fr;
+    if (q >= T) continue;
+    const float inv = 1.0f / l_run[qt];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + fg * 4;
+      if (d >= dh) continue;
+      const f32x4 o = acc_o[dt][qt];
+      store4(op, ((int64_t)b * T + q) * p.ldo + h * dh + d, p.dtype, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    }
+    if (p.lse && fg == 0) p.lse[((int64_t)b * p.heads + h) * T + q] = m_run[qt] * sc + __builtin_amdgcn_logf(l_run[qt]);
+  }
+}
+
+template <int DHP, bool DROP>
+static int launch_attn_x3_v(const DnAttnParams& p, hipStream_t s) {
+  constexpr int lds = 4 * KV_TILE * AttnGeom<BF16>::ROWB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  dim3 grid((p.T + 127) / 128, p.heads, p.B);
+  hipLaunchKernelGGL((attn_x3_kernel<DHP, DROP>), grid, dim3(256), lds, s, p);
+  DN_CHECK_LAUNCH("dn_attention (split operands)");
+  return DN_OK;
+}
+template <int DHP>
+static int launch_attn_x3(const DnAttnParams& p, hipStream_t s) {
+  return p.dropout_p > 0.f ? launch_attn_x3_v<DHP, true>(p, s) : launch_attn_x3_v<DHP, false>(p, s);
+}
+
 template <typename E, int DHP, bool DROP>
 static int launch_attn_v(const DnAttnParams& p, hipStream_t s) {
   constexpr int lds = 4 * KV_TILE * AttnGeom<E>::ROWB;  // K and V, double-buffered
@@ -347,8 +625,9 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   DN_CHECK_ARG(p.q && p.k && p.v && p.out, "dn_attention: null tensor");
   DN_CHECK_ARG(p.B > 0 && p.T > 0 && p.heads > 0 && p.dim_head > 0 && p.Tk >= 0, "dn_attention: bad shape");
   DN_CHECK_ARG(!(p.lse && p.Tk > 0 && p.Tk != p.T), "dn_attention: the backward pass (lse) covers self-attention only");
-  // DN_BF16X3: q / k / v are plain fp32 (the engine keeps them out of the split layout), the products run in exact fp32 MFMA and only
-  // the output -- the operand of the to_out contraction -- is written as split rows (store4 on p.dtype)
+  // DN_BF16X3: q / k / v are plain fp32 (the engine keeps them out of the split layout); the products run as three bf16 MFMAs on
+  // halves split on the fly (attn_x3_kernel; heads over 64 dims: exact fp32 MFMA) and only the output -- the operand of the to_out
+  // contraction -- is written as split rows (store4 on p.dtype)
   DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16 || p.dtype == DN_BF16X3, "dn_attention: bad dtype");
   if (p.dtype == DN_BF16X3) DN_CHECK_ARG(p.ldo % 32 == 0 && (p.heads * p.dim_head) % 4 == 0 && ((uintptr_t)p.out & 127) == 0, "dn_attention: split-row output needs ldo %% 32 == 0");
   DN_CHECK_ARG(p.dropout_p >= 0.f && p.dropout_p < 1.f, "dn_attention: dropout_p %g", (double)p.dropout_p);
@@ -360,6 +639,11 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
                "dn_attention: tensors must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int dh = p.dim_head;
+  if (p.dtype == DN_BF16X3) {  // heads up to 64 dims: three bf16 products on the fly; larger heads: the exact-fp32 kernel
+    static const bool x3_off = getenv("DN_ATTN_X3") && atoi(getenv("DN_ATTN_X3")) == 0;  // A/B: exact-fp32 products for every head size
+    if (!x3_off && dh <= 32) return dn::launch_attn_x3<32>(p, s);
+    if (!x3_off && dh <= 64) return dn::launch_attn_x3<64>(p, s);
+  }
   if (p.dtype == DN_BF16) {
     if (dh <= 32) return dn::launch_attn<dn::BF16, 32>(p, s);
     if (dh <= 64) return dn::launch_attn<dn::BF16, 64>(p, s);

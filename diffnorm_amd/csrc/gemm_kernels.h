@@ -817,15 +817,23 @@ constexpr int ROWB2 = 64;
 // the 256 x 352 tile (same 32-deep K-tiles: bit-identical to it), so the taps of a chunk read (nearly) the same activation rows
 // back to back and the XCD's L2 serves all but one of them: the dilated WaveNet conv's activation panels cross the fabric once
 // instead of three times (measured 516 MB of reads per launch at [32,512], 402 MB of them the panels).
-template <typename E, int EPI, bool TAPS>
+// BNB = 192: the same kernel on a 256 x 192 tile (waves 64 x 96) for widths that quantise badly on 256 columns -- N = 1408 is 5.5
+// column tiles of 256 (384 workgroups = 1.5 rounds of the 256 CUs) but 7.33 of 192 (512 workgroups = 2 full rounds, 8 % of
+// them padding).  The weight tile's 12 staging pieces go 2 per wave to waves 0-3 and 1 per wave to waves 4-7, so the two wave
+// groups count different numbers of DMA pieces per stage.  Epilogues whose bookkeeping assumes 64-aligned wave columns (the
+// split norm's producer) do not run on it.
+template <typename E, int EPI, bool TAPS, int BNB = 256>
 __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
-  constexpr int BMB = 256, BNB = 256, STAGES = 4;
-  constexpr int TILE = 256 * ROWB2;          // 16 KiB per operand tile
-  constexpr int STAGE_BYTES = 2 * TILE;      // W tile then A tile
-  constexpr int PER_STAGE = 4;               // DMA pieces per wave per stage (2 W + 2 A, 16 rows each)
+  static_assert(BNB == 256 || BNB == 192, "tile width");
+  constexpr int BMB = 256, STAGES = 4;
+  constexpr int TILE = BNB * ROWB2;               // the weight tile (16 KiB at 256 columns); the row tile follows it
+  constexpr int STAGE_BYTES = TILE + 256 * ROWB2;
+  constexpr int PER_STAGE = 4;                    // DMA pieces per wave per stage (2 W + 2 A, 16 rows each) ...
+  constexpr int PER_LATE = BNB == 256 ? 4 : 3;    // ... waves 4-7 of the 192-column tile: 1 W + 2 A
+  constexpr int NTW = BNB / 32;                   // 16-column accumulator tiles per wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     m = m < p.M ? m : p.M - 1;
     a_row[i] = m;
     a_t[i] = m % p.T;
-    int n = n0 + wave * 32 + i * 16 + srow;
+    int n = n0 + (BNB == 256 || wave < 4 ? wave * 32 + i * 16 : 128 + (wave - 4) * 16) + srow;  // (192: waves 4-7 stage one piece, i = 0)
     w_row[i] = n < w_rows ? n : w_rows - 1;
   }
   const int ktiles_per_term = p.K / KT;
@@ -911,11 +919,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   auto stage = [&](int slot) {
-    const uint32_t wbase = lds_base + slot * STAGE_BYTES + wave * 2048;
-    const uint32_t abase = wbase + TILE;
+    const bool one_w = BNB != 256 && wave >= 4;  // uniform
+    const uint32_t wbase = lds_base + slot * STAGE_BYTES + (one_w ? 8192 + (wave - 4) * 1024 : wave * 2048);
+    const uint32_t abase = lds_base + slot * STAGE_BYTES + TILE + wave * 2048;
     if constexpr (TAPS) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(w_ptr[i] + tap_woff, wbase + i * 1024);
+      for (int i = 0; i < 2; ++i)
+        if (i == 0 || !one_w) glds16(w_ptr[i] + tap_woff, wbase + i * 1024);
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16(a_t[i] >= tap_shift ? a_ptr[i] - tap_delta : zero_src, abase + i * 1024);
       const bool wrap = s_term + 1 == p.n_terms;  // uniform selects, no branch
@@ -932,7 +942,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(w_ptr[i], wbase + i * 1024);
+    for (int i = 0; i < 2; ++i)
+      if (i == 0 || !one_w) glds16(w_ptr[i], wbase + i * 1024);
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(a_ptr[i], abase + i * 1024);
     if (++s_kk == ktiles_per_term) {
@@ -947,16 +958,16 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     }
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[NTW][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment reads: row (l & 15) of a 16-row sub-tile, 16-byte chunk (l >> 4) of the 64-byte row, swizzled
   const int frow = lane & 15, fq = lane >> 4;
   const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
-  const int w_rd = (wn * 128 + frow) * ROWB2 + coff;
+  const int w_rd = (wn * (BNB / 2) + frow) * ROWB2 + coff;
   const int a_rd = TILE + (wm * 64 + frow) * ROWB2 + coff;
   // Split operands (DN_BF16X3): the 64-byte K-tiles of a row alternate between the two halves of a 32-element group -- even
   // K-tiles hold the weights' lo and the activations' hi half, odd ones the weights' hi and the activations' lo half (that is
@@ -966,12 +977,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   // wave groups pair up, one group's long segment running beside the other's short one.
   constexpr bool X3 = std::is_same<E, BF16X3>::value;
   using ME = typename std::conditional<X3, BF16, E>::type;  // the MFMA's operand type
-  uint4 wf[8], af[4], ah[X3 ? 4 : 1];
+  uint4 wf[NTW], af[4], ah[X3 ? 4 : 1];
   auto load_frags = [&](int slot, auto par_c) {
     constexpr int PAR = decltype(par_c)::value;  // 0: plain operands; 1 / 2: even / odd K-tile of split operands
     const char* sb = smem + slot * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB2);
+    for (int i = 0; i < NTW; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) (PAR == 1 ? ah[i] : af[i]) = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB2);
   };
@@ -979,13 +990,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     constexpr int PAR = decltype(par_c)::value;
     if constexpr (PAR != 1) {
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) mma_kstep<ME>(acc[nt][mt], wf[nt], af[mt]);
     }
     if constexpr (PAR != 0) {
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) mma_kstep<ME>(acc[nt][mt], wf[nt], ah[mt]);
     }
@@ -1001,7 +1012,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
-  if (nkt > 2) pipe_sync<2 * PER_STAGE>(); else if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();  // tile 0 landed
+  if (BNB != 256 && __builtin_amdgcn_readfirstlane(wave) >= 4) {  // (tile 0 landed; these waves carry PER_LATE pieces per stage)
+    if (nkt > 2) pipe_sync<2 * PER_LATE>(); else if (nkt > 1) pipe_sync<PER_LATE>(); else pipe_sync<0>();
+  } else {
+    if (nkt > 2) pipe_sync<2 * PER_STAGE>(); else if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+  }
   const float row_scale = row_scale_finish(p, rs_req);
   __builtin_amdgcn_sched_barrier(0);
   if (late) pipe_sync<63>();  // the stagger
@@ -1029,6 +1044,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     int slot = 0, fill = STAGES - 1, kt = 0;
     auto adv = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; fill = fill == STAGES - 1 ? 0 : fill + 1; };
     using P0 = integral_constant<int, 0>;
+    constexpr int PER = decltype(late_c)::value ? PER_LATE : PER_STAGE;  // DMA pieces this wave issues per stage
     if constexpr (X3) {
       // K-tiles come in (even, odd) pairs, nkt is even; the staging tiles 0 .. nkt-4 end on an even one, so the drain is
       // [even: stages][odd: two tiles follow][even][odd]
@@ -1036,17 +1052,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
       using OD = integral_constant<int, 2>;
       if (nkt >= 4) {
         for (; kt + 4 < nkt; kt += 2) {
-          ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER_STAGE>{}, slot, fill, EV{}); adv();
-          ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER_STAGE>{}, slot, fill, OD{}); adv();
+          ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER>{}, slot, fill, EV{}); adv();
+          ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER>{}, slot, fill, OD{}); adv();
         }
-        ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER_STAGE>{}, slot, fill, EV{}); adv();
-        ktile(late_c, std::false_type{}, integral_constant<int, PER_STAGE>{}, slot, fill, OD{}); adv();
+        ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER>{}, slot, fill, EV{}); adv();
+        ktile(late_c, std::false_type{}, integral_constant<int, PER>{}, slot, fill, OD{}); adv();
       }
       ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill, EV{}); adv();
       ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill, OD{});
     } else {
-    for (; kt + 3 < nkt; ++kt) { ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER_STAGE>{}, slot, fill, P0{}); adv(); }
-    if (nkt >= 3) { ktile(late_c, std::false_type{}, integral_constant<int, PER_STAGE>{}, slot, fill, P0{}); adv(); }  // two tiles follow
+    for (; kt + 3 < nkt; ++kt) { ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER>{}, slot, fill, P0{}); adv(); }
+    if (nkt >= 3) { ktile(late_c, std::false_type{}, integral_constant<int, PER>{}, slot, fill, P0{}); adv(); }  // two tiles follow
     if (nkt >= 2) { ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill, P0{}); adv(); }
     ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill, P0{});
     }
@@ -1062,13 +1078,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   slab_row_scales(row_scale, lane, sc4);
   auto half = [&](auto hc) {
     constexpr int H = decltype(hc)::value;
+    constexpr int NTS = NTW - 4 * H < 4 ? NTW - 4 * H : 4;  // accumulator tiles of this half (192 columns: 4, then 2)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < NTS; ++nt)
         *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = scaled(acc[H * 4 + nt][mt], sc4[mt]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m0 + wm * 64, n0 + wn * 128 + H * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
+    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m0 + wm * 64, n0 + wn * (BNB / 2) + H * 64, g, lane, NTS * 16, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
   };
   half(std::integral_constant<int, 0>{});
@@ -1785,33 +1802,33 @@ static bool terms_are_taps(const DnGemmParams& p) {
   return taps;
 }
 
-template <typename E, int EPI, bool TAPS>
+template <typename E, int EPI, bool TAPS, int BNB = 256>
 static void launch_big_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI, TAPS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI, TAPS, BNB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI, TAPS>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI, TAPS, BNB>), grid, dim3(512), lds, s, p);
 }
 
-template <typename E, int EPI>
+template <typename E, int EPI, int BNB = 256>
 static int launch_big(const DnGemmParams& p, hipStream_t s) {
-  constexpr int ring = 4 * 2 * 256 * ROWB2, slabs = 8 * 64 * EP_LD * 4;
+  constexpr int ring = 4 * (BNB + 256) * ROWB2, slabs = 8 * 64 * EP_LD * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
   const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
-  dim3 grid(((p.M + 255) / 256) * ((np + 255) / 256), p.groups);
+  dim3 grid(((p.M + 255) / 256) * ((np + BNB - 1) / BNB), p.groups);
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
   bool tapped = false;
-  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_FILM_GATE) && !std::is_same<E, BF16X3>::value) {  // the epilogues a causal conv has (CausalConv1d + bias; the WaveNet block); split operands pair K-tiles along a row: term-outer only
+  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_FILM_GATE) && !std::is_same<E, BF16X3>::value && BNB == 256) {  // the epilogues a causal conv has (CausalConv1d + bias; the WaveNet block); split operands pair K-tiles along a row: term-outer only
     if (terms_are_taps(p)) {
       launch_big_variant<E, EPI, true>(p, grid, lds, s);
       tapped = true;
     }
   }
-  if (!tapped) launch_big_variant<E, EPI, false>(p, grid, lds, s);
+  if (!tapped) launch_big_variant<E, EPI, false, BNB>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm");
   return DN_OK;
@@ -1892,7 +1909,7 @@ static int choose_tile(const DnGemmParams& p) {
   if (p.dtype == DN_BF16X3) {  // split operands run on the two 128-byte-K-tile kernels (row-major operands only)
     for (int i = 0; i < p.n_terms; ++i)
       if (p.terms[i].layout != 0) return -1;
-    if (force >= 1 && force <= 3) return force;
+    if ((force >= 1 && force <= 3) || (force == 8 && p.epilogue == DN_EPI_BIAS)) return force;
     const int npx = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
     const long mt2 = (p.M + 255) / 256, t_big = mt2 * ((npx + 255) / 256) * p.groups, t_mid = mt2 * ((npx + BN - 1) / BN) * p.groups,
                t_small = (long)((p.M + 127) / 128) * ((npx + BN - 1) / BN) * p.groups;
@@ -1900,6 +1917,16 @@ static int choose_tile(const DnGemmParams& p) {
     // three MFMAs per product against twice the staged bytes: the 256 x 256 tile is the one that stays matrix-bound (its fill
     // path needs 21 B/cycle per CU; 256 x 128 needs 31, two 128 x 128 workgroups 43 of the ~30 available)
     const double sb = 1.00 * fill2(t_big, 1), sm = 0.80 * fill2(t_mid, 1), ss = 0.70 * fill2(t_small, 2);
+    // The 256 x 192 tile (tile 8, BIAS epilogue; N = 1408 -> 512 workgroups = two full rounds instead of 1.5) is forced-only
+    // (DN_X3_192=1 lets the score pick it): isolated, the FFN conv + q/kv pair of a layer drops 552 -> 513 us at [32,512], but
+    // in the two-stream chain each half-batch launch is then exactly one round and the halves stop filling each other's ragged
+    // rounds: 77.9 vs 80.4 steps/s, three alternating same-box runs.
+    static const bool use192 = getenv("DN_X3_192") && atoi(getenv("DN_X3_192")) != 0;
+    if (p.epilogue == DN_EPI_BIAS && force == 0 && use192) {
+      const int c192 = (npx + 191) / 192;
+      const double s192 = 0.97 * fill2(mt2 * c192 * p.groups, 1) * npx / (192.0 * c192) / (npx / (256.0 * ((npx + 255) / 256)));
+      if (s192 > sb && s192 > sm && s192 > ss) return 8;
+    }
     if (sb >= sm && sb >= ss) return 3;
     return sm > ss ? 2 : 1;
   }
@@ -1969,7 +1996,10 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   DN_CHECK_ARG(tile > 0, "dn_conv_gemm: K-blocked operands are taken by the 256 x 352 and 256 x 256 tiles only (bf16; forced tile %d)",
                forced_tile(p));
   if constexpr (std::is_same<E, BF16X3>::value) {  // split operands: the 128-byte-K-tile kernels (both halves in one K-tile) and the 256 x 256 tile (K-tile pairs)
-    if (tile == 3) return launch_big<E, EPI>(p, s);
+    if constexpr (EPI == DN_EPI_BIAS) {
+      if (tile == 8) return launch_big<E, EPI, 192>(p, s);
+    }
+    if (tile == 3 || tile == 8) return launch_big<E, EPI>(p, s);
     if (tile == 2) return launch_tile<E, EPI, 256, 3>(p, s);
     return launch_tile<E, EPI, 128, 2>(p, s);
   } else {

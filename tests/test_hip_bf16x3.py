@@ -41,7 +41,7 @@ def ops():
     return ops, packing, _lib
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8])
 @pytest.mark.parametrize("cin,cout,k,dil,B,T", [(64, 64, 3, 1, 2, 40), (96, 200, 3, 4, 3, 37), (128, 64, 1, 1, 1, 300),
                                                 (64, 128, 3, 64, 2, 50), (192, 704, 3, 1, 3, 100), (1408, 1408, 3, 1, 2, 512)])
 def test_causal_conv_gemm_x3(ops, tile, cin, cout, k, dil, B, T):
@@ -105,7 +105,7 @@ def test_x3_chain_of_two_contractions_and_epilogues(ops):
     fc = packing.split_rows(out.cpu()).to(DEV)
     ops_.conv_gemm([(fc, packing._mat(w_o, _lib.DN_BF16X3).to(DEV), 0)], stream, T, padk(D), epilogue=_lib.EPI_RESADD, res=stream,
                    norm_out=xn, norm_D=D, norm_gamma=pad_cols(gamma, padk(D)).to(DEV), norm_ssq=ssq, x3=True)
-    want_s = res[:, :D] + want.view(B * T, -1) @ w_o.t()
+    want_s = res[:, :D] + want.reshape(B * T, -1) @ w_o.t()
     assert maxerr(stream.cpu()[:, :D], want_s) < 3e-4
     assert maxerr(packing.unsplit_rows(xn.cpu())[:, :D], want_s * gamma) < 5e-4
     assert maxerr(ssq.cpu()[:, : padk(D) // 64].sum(-1), want_s.pow(2).sum(-1)) < 1e-2
