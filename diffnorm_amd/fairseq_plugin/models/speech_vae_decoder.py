@@ -32,7 +32,7 @@ class SpeechVAEDecoder(FairseqEncoderModel):
     def add_args(parser):
         add_inherited_args(parser)
         parser.add_argument("--latent_dim", type=int, default=16)
-        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "f32"], help="MFMA arithmetic of the HIP engine")
+        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "bf16x3", "f32"], help="MFMA arithmetic of the HIP engine (bf16x3: split-operand bf16, fp32-class results)")
 
     def max_positions(self):
         return self.encoder.max_positions()

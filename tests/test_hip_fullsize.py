@@ -116,6 +116,71 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeyp
     assert agree > 0.9
 
 
+def test_bf16x3_fullsize_chain_is_shard_invariant_and_matches_the_oracle(models):
+    """The split-operand mode at BASELINE's full sizes.  (a) configs[2] shape [32,512]: eager == hipGraph == forked half-batch
+    replay, bit for bit.  (b) configs[4] shape [16,1024] end to end: every split-operand tile sums K in the same (term-outer)
+    order, so the 16-utterance batch and its two 8-utterance shards -- the multi-GPU sharding -- agree BIT FOR BIT in the default
+    configuration (no environment switch), whatever tiles the shard sizes route to.  (c) the truncated chain on two utterances
+    against the CPU oracle at the fp32 budget: reconstruction within 1e-3 of its scale, units identical where the oracle's
+    top-2 logit margin is clear."""
+    from diffnorm_amd import engine, ops
+
+    sched, cfg = models["sched"], models["cfg"]
+    eps = engine.EpsEngine(models["esd"], cfg, dtype="bf16x3", device=DEV)
+    vae = engine.VaeEngine(models["vsd"], dtype="bf16x3", device=DEV)
+    coef = sched.ddim_coef_table(DEV)
+    x0 = ops.randn((32, 512, 128), seed=5, device=DEV)
+    lens32 = torch.full((32,), 512, dtype=torch.int32, device=DEV)
+    lens32[3], lens32[17] = 300, 1
+    outs = []
+    for graph, split in ((False, False), (True, False), (True, True)):
+        x = x0.clone()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            assert eps.ddim_loop(x, lens32, 999, coef, use_graph=graph, max_evals=6, split=split) == 6
+        torch.cuda.synchronize()
+        assert torch.isfinite(x).all()
+        outs.append(x)
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]) and not torch.equal(outs[0], x0)
+
+    sa, s1 = sched.f32("sqrt_alphas_cumprod", DEV), sched.f32("sqrt_one_minus_alphas_cumprod", DEV)
+    B, T, start = 16, 1024, 3
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(B, T, 768, generator=g)
+    lens = torch.randint(400, T + 1, (B,), generator=g)
+    lens[0] = T
+    post = torch.randn(B, T, 128, generator=g)
+    noise = torch.randn(B, T, 128, generator=g)
+
+    def run(sl):
+        f, l = feat[sl].to(DEV), lens[sl]
+        z = vae.sample_posterior(vae.encode_params(f), post[sl])
+        ts = torch.full((f.shape[0],), start, dtype=torch.int32, device=DEV)
+        x = ops.q_sample(z, noise[sl].to(DEV), sa, s1, ts, T)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            eps.ddim_loop(x, l.to(DEV).int(), start, coef, use_graph=False)
+        torch.cuda.synchronize()
+        recon, logits, units = vae.decode(x, l)
+        return recon.cpu(), logits.cpu(), units.cpu()
+
+    full = run(slice(0, 16))
+    a, b = run(slice(0, 8)), run(slice(8, 16))
+    assert torch.equal(torch.cat([a[2], b[2]]), full[2])
+    assert torch.equal(torch.cat([a[0], b[0]]), full[0]) and torch.equal(torch.cat([a[1], b[1]]), full[1])
+    n = 2
+    mask = O.lengths_to_mask(lens[:n], T)
+    with torch.no_grad():
+        units_o, _, _, recon_o, = O.ddim_sample(models["esd"], O.EpsConfig(), models["vsd"], O.VaeConfig(), 1000, feat[:n], mask,
+                                                torch.zeros(n, T, dtype=torch.long), start, post[:n], noise[:n])
+    err = (full[0][:n] - recon_o)[mask].abs().max().item()
+    scale = recon_o[mask].abs().max().item()
+    print(f"bf16x3 config5 slice: recon max abs err {err:.3e} of scale {scale:.3e}")
+    assert err < 1e-3 * max(scale, 1.0)
+    got = [full[2][i, : int(lens[i])] for i in range(n)]
+    agree = np.mean([(g_.long() == u_).float().mean().item() for g_, u_ in zip(got, units_o)])
+    print(f"bf16x3 config5 slice: unit agreement with the oracle {agree:.4f}")
+    assert agree > 0.995
+
+
 def test_manifests_to_normalised_unit_tsv_through_the_hip_path(tmp_path):
     """SURVEY 8 f1 on the GPU: on-disk unit TSVs + per-utterance feature .npy files -> data.load_normalization_inputs ->
     normalize() driving the REAL LatentDiscreteModel.ddim_sample on the HIP engines (pinned staging buffer + async H2D per batch,

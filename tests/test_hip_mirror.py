@@ -23,20 +23,24 @@ def close(a, b, tol):
     assert err <= tol, f"max abs err {err} > {tol}"
 
 
-@pytest.fixture(scope="module")
-def ldm():
+# every mirror test runs in the three arithmetic modes: exact fp32 and split-operand bf16x3 at the fp32 budget (1e-3, exact
+# unit sequences), plain bf16 at the distances the engine-level tests state (tests/test_hip_engine.py)
+@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16"])
+def ldm(request):
     from diffnorm_amd.latent_module import LatentDiscreteModel, SpeechVAEEncoderDecoder
 
-    vae = SpeechVAEEncoderDecoder(dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="f32")
+    dtype = request.param
+    vae = SpeechVAEEncoderDecoder(dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype=dtype)
     vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
     assert set(vae.state_dict()) == set(vsd), "VAE state-dict keys differ from the reference layout"
     vae.load_state_dict(vsd, strict=True)
-    m = LatentDiscreteModel(types.SimpleNamespace(encoder=vae), CHAIN_EPS.dim, CHAIN_VAE.z, timesteps=200, dtype="f32")
+    m = LatentDiscreteModel(types.SimpleNamespace(encoder=vae), CHAIN_EPS.dim, CHAIN_VAE.z, timesteps=200, dtype=dtype)
     esd = O.make_eps_state_dict(CHAIN_EPS, "chain")
     assert set(m.model.state_dict()) == set(esd) | {"pos_embed._float_tensor"}
     m.model.load_state_dict(dict(esd, **{"pos_embed._float_tensor": torch.zeros(1)}), strict=True)
     # the diffusion checkpoint layout: model.* + speech_decoder.* 
     assert any(k.startswith("speech_decoder.decoder_lm") for k in m.state_dict()) and any(k.startswith("model.wavenet") for k in m.state_dict())
+    m.test_dtype = dtype
     return m.to(DEV).eval()
 
 
@@ -49,9 +53,14 @@ def test_ddim_sample_matches_reference(ldm, golden):
         toks, match, total, recon = ldm.ddim_sample(feat.to(DEV), input_mask=mask.to(DEV), ref_units=(units - 4).to(DEV),
                                                     start_step=start, post_noise=T_(g[f"s{start}_post_noise"]),
                                                     start_noise=T_(g[f"s{start}_start_noise"]))
-        assert total == int(g[f"s{start}_total"]) and match == int(g[f"s{start}_match"])
-        assert torch.cat(toks).cpu().tolist() == g[f"s{start}_units"].tolist()
-        close(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask], 1e-3)
+        assert total == int(g[f"s{start}_total"])
+        if ldm.test_dtype == "bf16":  # measured 1.06-1.23e-2 on these chains (tests/test_hip_engine.py); flat random-init logits flip a few units
+            assert (torch.cat(toks).cpu().numpy() == g[f"s{start}_units"]).mean() >= 0.9
+            close(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask], 1.45e-2)
+        else:
+            assert match == int(g[f"s{start}_match"])
+            assert torch.cat(toks).cpu().tolist() == g[f"s{start}_units"].tolist()
+            close(recon.cpu()[mask], T_(g[f"s{start}_recon"])[mask], 1e-3)
         assert [t.shape[0] for t in toks] == lens.tolist()
 
 
@@ -63,7 +72,7 @@ def test_reference_rng_draw_order(ldm, golden):
     torch.manual_seed(105)  # the generator state the golden run used for start_step=5
     z = ldm.speech_decoder.encode_feature(feat.to(DEV)).transpose(1, 2)
     want = O.vae_encode(O.make_vae_state_dict(CHAIN_VAE, "chain"), CHAIN_VAE, feat, T_(g["s5_post_noise"]))
-    close(z, want, 1e-3)
+    close(z, want, 1e-3 if ldm.test_dtype != "bf16" else 1e-2)
 
 
 def test_training_forward_losses_match_reference(ldm, golden):
@@ -74,12 +83,13 @@ def test_training_forward_losses_match_reference(ldm, golden):
     with torch.no_grad():
         ld = ldm(feat.to(DEV), units.to(DEV), tgt_mask=mask.to(DEV), times=T_(g["train_times"]), post_noise=T_(g["train_post"]),
                  jitter_noise=T_(g["train_jitter"]), true_noise=T_(g["train_true"]))
-    for k, tol in (("total_loss", 1e-3), ("nll_loss", 1e-3), ("recon_mse_loss", 1e-3), ("noise_loss", 1e-3), ("acc", 0.02)):
+    f = 1.0 if ldm.test_dtype != "bf16" else 20.0  # bf16: scalar losses within 2e-2, logits within the engine tests' 2e-2
+    for k, tol in (("total_loss", 1e-3 * f), ("nll_loss", 1e-3 * f), ("recon_mse_loss", 1e-3 * f), ("noise_loss", 1e-3 * f), ("acc", 0.02)):
         close(ld[k], g["train_" + k], tol)
     mse, logits, kl = ldm.speech_decoder(feat.to(DEV), units, mask.to(DEV), noise=T_(g["vae_post"]))
-    close(mse, g["vae_mse"], 1e-3)
-    close(kl, g["vae_kl"], 1e-4)
-    close(logits[:, :8], g["vae_logits_head"], 1e-3)
+    close(mse, g["vae_mse"], 1e-3 * f)
+    close(kl, g["vae_kl"], 1e-4 * f)
+    close(logits[:, :8], g["vae_logits_head"], 1e-3 * f)
 
 
 def test_plugin_vae_criterion_end_to_end():
