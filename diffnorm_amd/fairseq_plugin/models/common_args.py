@@ -64,3 +64,14 @@ def apply_arch_defaults(args):
     for k, src in (("decoder_output_dim", "decoder_embed_dim"), ("decoder_input_dim", "decoder_embed_dim")):
         if getattr(args, k, None) is None:
             setattr(args, k, getattr(args, src))
+
+
+def is_training_run(args) -> bool:
+    """Is this namespace a training run's (fairseq_cli/train.py: it carries --optimizer / --lr; generation and
+    diff_norm_synthesis namespaces do not)?  `--hip-train-engine` / `hip_train_engine=True` forces it.  A training run's model
+    switches to the HIP training engine -- ONE flat parameter -- the moment it is moved to the GPU, i.e. before the reference
+    trainer snapshots `model.parameters()` into its optimizer (fairseq/trainer.py:292)."""
+    if getattr(args, "hip_train_engine", None) is not None:
+        return bool(args.hip_train_engine)
+    return getattr(args, "optimizer", None) is not None
+

@@ -5,7 +5,7 @@ import torch
 
 from ...latent_module import LatentDiscreteModel, SpeechVAEEncoderDecoder, lengths_to_mask
 from ..registry import HAVE_FAIRSEQ, FairseqEncoderModel, register_model, register_model_architecture
-from .common_args import add_inherited_args, apply_arch_defaults
+from .common_args import add_inherited_args, apply_arch_defaults, is_training_run
 
 
 def _load_speech_decoder(args):
@@ -58,6 +58,7 @@ class DiffDiscreteModel(FairseqEncoderModel):
         z = vae.latent_channels() if hasattr(vae, "latent_channels") else args.latent_dim
         encoder = LatentDiscreteModel(speech_decoder, getattr(args, "denoiser_dim", 512), z, timesteps=getattr(args, "diffusion_timesteps", 200),
                                       multitask=args.multitask, dtype=getattr(args, "hip_dtype", "bf16"))
+        encoder.train_on_move = is_training_run(args)  # the training engine (one flat parameter) comes up with model.to(device)
         return cls(args, encoder)
 
     @staticmethod

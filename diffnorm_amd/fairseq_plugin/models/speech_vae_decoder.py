@@ -3,7 +3,7 @@ import torch
 
 from ...latent_module import SpeechVAEEncoderDecoder, lengths_to_mask
 from ..registry import FairseqEncoderModel, register_model, register_model_architecture
-from .common_args import add_inherited_args, apply_arch_defaults
+from .common_args import add_inherited_args, apply_arch_defaults, is_training_run
 
 
 @register_model("speech_vae_decoder")
@@ -26,6 +26,7 @@ class SpeechVAEDecoder(FairseqEncoderModel):
     def build_model(cls, args, task):
         encoder = SpeechVAEEncoderDecoder(dim=getattr(args, "feature_dim", 768), latent_dim=args.latent_dim,
                                           dtype=getattr(args, "hip_dtype", "bf16"))
+        encoder.train_on_move = is_training_run(args)  # the training engine (one flat parameter) comes up with model.to(device)
         return cls(args, encoder)
 
     @staticmethod

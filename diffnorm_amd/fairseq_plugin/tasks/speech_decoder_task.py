@@ -45,6 +45,27 @@ class SyntheticReprUnitDataset(torch.utils.data.Dataset):
                 "ntokens": int(lens.sum()), "nsentences": B}
 
 
+def _check_optimizer_holds_flat_params(enc, optimizer):
+    """The HIP training engine's ONE parameter must be what the optimizer updates.  An optimizer that was built from
+    `model.parameters()` BEFORE the switch to the training engine holds the deleted per-tensor parameters and would train
+    nothing, silently: refuse that here.  (Optimizers over the engine's flat buffers -- optim.FlatOptimizer -- carry `engine`.)"""
+    flat = getattr(getattr(enc, "model", enc), "flat_params", None)
+    if flat is None or optimizer is None:
+        return
+    eng = getattr(optimizer, "engine", None)
+    if eng is not None:
+        if eng is not enc._train_engine:
+            raise RuntimeError("the optimizer was built over another training engine than the model's")
+        return
+    params = getattr(optimizer, "params", None)  # FairseqOptimizer.params
+    if params is None and hasattr(optimizer, "param_groups"):
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+    if params is not None and not any(p is flat for p in params):
+        raise RuntimeError("the optimizer does not hold the HIP training engine's `flat_params`: it was built before the model switched to "
+                           "the training engine.  Build the model from a training namespace (--optimizer set, or hip_train_engine=True) so that "
+                           "model.to(device) makes the switch, or call model.encoder.enable_training() before building the optimizer")
+
+
 class _SpeechTaskBase(FairseqTask):
     @classmethod
     def add_args(cls, parser):
@@ -116,7 +137,8 @@ class _SpeechTaskBase(FairseqTask):
         model.train()
         enc = getattr(model, "encoder", None)
         if hasattr(enc, "enable_training"):
-            enc.enable_training()
+            enc.enable_training()  # (a training run's model did this when it was moved to the GPU: models/common_args.is_training_run)
+            _check_optimizer_holds_flat_params(enc, optimizer)
         loss, sample_size, logging_output = criterion(model, sample)
         if ignore_grad:
             loss = loss * 0

@@ -195,19 +195,49 @@ def _set_dropout(engine, p: float):
         engine.dropout_seed, engine._dropout_calls = int(torch.randint(0, 2 ** 31 - 1, (1,))), 0
 
 
+def _prepare_step(flat, eng, holder) -> bool:
+    """Before a training forward.  (1) The master buffer may have been updated by an optimizer that is not the HIP one (fairseq's
+    Adam on `flat_params`, an in-place update: the tensor's version counter moves): the engine's bf16 working copy and its
+    transposed weights are refreshed from it.  (2) fairseq's FairseqOptimizer.zero_grad sets `p.grad = None`
+    (fairseq/optim/fairseq_optimizer.py:129-133), which drops the alias `flat_params.grad is engine.grads`: that IS the zeroing,
+    so the engine's gradient buffer is cleared here and the alias is restored by the backward.  -> whether the alias was dropped."""
+    if flat._version != getattr(holder, "_seen_version", flat._version):
+        eng.sync_work()
+    holder._seen_version = flat._version
+    dropped = flat.grad is None
+    if dropped:
+        eng.zero_grad()
+    return dropped
+
+
+def _scaled_backward(eng, c: float, fresh: bool, run):
+    """The engine's backward ADDS d loss / d theta into its gradient buffer; an upstream gradient c != 1 (fairseq's fp16 / amp loss
+    scale, `optimizer.backward(loss)` on a scaled loss) must add c times that: g_old + c g = c (g_old / c + g) -- two elementwise
+    passes over the flat buffer around the same kernels, exact for the power-of-two scales loss scalers use; a buffer that was
+    just zeroed (`fresh`) skips the first pass."""
+    if c == 1.0:
+        return run()
+    if not fresh:
+        eng.grads.div_(c)
+    run()
+    eng.grads.mul_(c)
+
+
 class _VaeStepFn(torch.autograd.Function):
     """Autograd node around the HIP training engine: forward = dn_vae_train_forward (activations stay in the engine's
     workspace), backward = dn_vae_train_backward, which ADDS the parameter gradients into the flat gradient buffer that is
-    `flat_params.grad` (so nothing is returned for the parameter).  Outputs: stats [8] (loss, nll, mse, kl, acc, ...) and the
-    logits.  Two ways to differentiate it: through stats[0], the criterion's own loss (fused LS-CE gradient; the incoming
-    gradient must be 1, or 0 for fairseq's ignore_grad), or through (stats[2], logits, stats[3]) = (mse_loss, lm_logits,
-    kl_loss), the reference model's return values, for a caller that builds its loss itself."""
+    `flat_params.grad` (so nothing is returned for the parameter; the alias is restored when a zero_grad had set it to None).
+    Outputs: stats [8] (loss, nll, mse, kl, acc, ...) and the logits.  Two ways to differentiate it: through stats[0], the
+    criterion's own loss (fused LS-CE gradient; any scalar upstream gradient: 1, a loss scale, or 0 for fairseq's ignore_grad), or
+    through (stats[2], logits, stats[3]) = (mse_loss, lm_logits, kl_loss), the reference model's return values, for a caller that
+    builds its loss itself."""
 
     @staticmethod
     def forward(ctx, flat, module, feat, units, lengths, noise, ntokens):
         eng = module._train_engine
+        ctx.fresh = _prepare_step(flat, eng, module)
         stats, logits, _ = eng.forward(feat, units, lengths, noise=noise, ntokens=ntokens, want_logits=True)
-        ctx.module = module
+        ctx.module, ctx.flat = module, flat
         return stats.clone(), logits
 
     @staticmethod
@@ -215,32 +245,39 @@ class _VaeStepFn(torch.autograd.Function):
         eng = ctx.module._train_engine
         gs = [0.0] * 8 if g_stats is None else [float(v) for v in g_stats.tolist()]  # one host read of 8 floats
         if gs[0] != 0.0:
-            if gs[0] != 1.0 or any(v != 0.0 for v in gs[1:]):
-                raise NotImplementedError("the fused criterion loss of the HIP VAE is differentiated with gradient 1 (no loss scaling)")
-            eng.backward()
+            if any(v != 0.0 for v in gs[1:]):
+                raise NotImplementedError("differentiate the HIP VAE either through its fused criterion loss (stats[0]) or through (mse, logits, kl), not both")
+            _scaled_backward(eng, gs[0], ctx.fresh, eng.backward)
         elif gs[2] != 0.0 or gs[3] != 0.0 or (g_logits is not None and bool(g_logits.ne(0).any())):  # zero: fairseq's ignore_grad
             ext = g_logits if g_logits is not None else torch.zeros_like(eng._keep[5])
             eng.backward(ext_dlogits=ext, d_mse=gs[2], d_kl=gs[3])
+        if ctx.flat.grad is None:
+            ctx.flat.grad = eng.grads
         return None, None, None, None, None, None, None
 
 
 class _EpsStepFn(torch.autograd.Function):
     """Autograd node around the HIP diffusion training engine (dn_eps_train_forward / _backward): the loss dict's total_loss is
-    stats[0]; its backward ADDS the eps-predictor's gradients into `flat_params.grad` (nothing is returned for the parameter)."""
+    stats[0]; its backward ADDS the eps-predictor's gradients into `flat_params.grad` (nothing is returned for the parameter) for
+    any scalar upstream gradient (1, a loss scale, 0 = ignore_grad)."""
 
     @staticmethod
     def forward(ctx, flat, owner, feat, units, lengths, z, times, jitter, true_noise):
+        ctx.fresh = _prepare_step(flat, owner._train_engine, owner)
         stats = owner._train_engine.forward(feat, units, lengths, z, times, jitter, true_noise)
-        ctx.owner = owner
+        ctx.owner, ctx.flat = owner, flat
         return stats.clone()
 
     @staticmethod
     def backward(ctx, g_stats):
         gs = [float(v) for v in g_stats.tolist()]
-        if any(v != 0.0 for v in gs[1:]) or gs[0] not in (0.0, 1.0):
-            raise NotImplementedError("the HIP diffusion loss is differentiated through total_loss with gradient 1 (no loss scaling)")
-        if gs[0] == 1.0:
-            ctx.owner._train_engine.backward()
+        if any(v != 0.0 for v in gs[1:]):
+            raise NotImplementedError("the HIP diffusion loss is differentiated through total_loss")
+        eng = ctx.owner._train_engine
+        if gs[0] != 0.0:
+            _scaled_backward(eng, gs[0], ctx.fresh, eng.backward)
+        if ctx.flat.grad is None:
+            ctx.flat.grad = eng.grads
         return (None,) * 9
 
 
@@ -253,6 +290,7 @@ class SpeechVAEEncoderDecoder(_ParamTree):
         self.dim, self.latent_dim = dim, latent_dim
         self.arith = dtype
         self._train_engine = None
+        self.train_on_move = False  # the plugin's build_model sets it for a training run: see _apply
         self.attn_dropout = 0.1  # Attention(dropout=0.1) of the decoder transformer (:668); active in train() mode with the training engine
         self._adopt(synthetic.random_vae_state_dict(dim, latent_dim, seed=seed))
 
@@ -267,6 +305,16 @@ class SpeechVAEEncoderDecoder(_ParamTree):
         for m in vae_mults(self.latent_dim):
             z //= m
         return z // 2
+
+    def _apply(self, fn, recurse=True):
+        """`model.to(device)`: in a training run (train_on_move) the switch to the training engine happens HERE, because the
+        reference trainer moves the model first and then builds its optimizer from `model.parameters()` (fairseq/trainer.py:
+        292) -- long before the first train_step: the optimizer must see `flat_params`, not per-tensor parameters that a later
+        switch would delete."""
+        out = super()._apply(fn, recurse)
+        if self.train_on_move and self._train_engine is None and self.device.type == "cuda":
+            self.enable_training()
+        return out
 
     # ---- training (SURVEY 8 f2): the flat packed master buffer of the HIP training engine becomes THE parameter ----
     def enable_training(self):
@@ -286,6 +334,7 @@ class SpeechVAEEncoderDecoder(_ParamTree):
             del self._modules[name]
         self.flat_params = nn.Parameter(eng.master)
         self.flat_params.grad = eng.grads
+        self._seen_version = self.flat_params._version
         self._train_engine = eng
         self._engine = None
         return eng
@@ -397,7 +446,14 @@ class LatentDiscreteModel(nn.Module):
         return None
 
     _train_engine = None
+    train_on_move = False  # set by the plugin's build_model for a training run (see SpeechVAEEncoderDecoder._apply)
     attn_dropout = 0.1  # the eps-predictor's Attention(dropout=0.1) (:668); the frozen VAE stays in eval mode (:1530)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if self.train_on_move and self._train_engine is None and not self.use_cond and self.device.type == "cuda":
+            self.enable_training()
+        return out
 
     def enable_training(self):
         """Switches the eps-predictor to the HIP diffusion training engine (diffnorm_amd/training.py::EpsTrainEngine): `self.model`
@@ -418,6 +474,7 @@ class LatentDiscreteModel(nn.Module):
         eng = training.EpsTrainEngine(esd, self.model.cfg, self._frozen_vae, timesteps=self.timesteps, dtype=self.model.arith, device=dev,
                                       multitask=self.multitask)
         self.model._adopt_flat(eng)
+        self._seen_version = self.model.flat_params._version
         self._train_engine = eng
         return eng
 

@@ -70,23 +70,17 @@ def load_reference():
     _pkg("fairseq.criterions")
     ls = types.ModuleType("fairseq.criterions.label_smoothed_cross_entropy")
 
-    # the real file drags omegaconf; this is the build's own restatement of the
-    # label-smoothed NLL (reference: fairseq/criterions/label_smoothed_cross_entropy.py:34-51)
-    def label_smoothed_nll_loss(lprobs, target, epsilon, ignore_index=None, reduce=True):
-        tgt = target.unsqueeze(-1) if target.dim() == lprobs.dim() - 1 else target
-        nll = -lprobs.gather(-1, tgt)
-        smooth = -lprobs.sum(-1, keepdim=True)
-        if ignore_index is not None:
-            pad = tgt.eq(ignore_index)
-            nll = nll.masked_fill(pad, 0.0)
-            smooth = smooth.masked_fill(pad, 0.0)
-        else:
-            nll, smooth = nll.squeeze(-1), smooth.squeeze(-1)
-        if reduce:
-            nll, smooth = nll.sum(), smooth.sum()
-        eps_i = epsilon / (lprobs.size(-1) - 1)
-        return (1.0 - epsilon - eps_i) * nll + eps_i * smooth, nll
+    # the real file's module imports drag omegaconf, but the function itself needs nothing: compile the reference's OWN
+    # label_smoothed_nll_loss (fairseq/criterions/label_smoothed_cross_entropy.py:34-51) from its source text, so the NLL term of
+    # the training fixtures is the reference's code, not a restatement
+    import ast
 
+    path = os.path.join(REF, "fairseq/criterions/label_smoothed_cross_entropy.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "label_smoothed_nll_loss")
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    label_smoothed_nll_loss = ns["label_smoothed_nll_loss"]
     ls.label_smoothed_nll_loss = label_smoothed_nll_loss
     sys.modules[ls.__name__] = ls
     _pkg("fairseq.models.text_to_speech")

@@ -180,6 +180,106 @@ def test_plugin_train_step_follows_the_reference_trajectory(golden):
     assert float(eng.grads.abs().max()) == 0.0
 
 
+class _FairseqStyleOptimizer:
+    """The slice of fairseq's FairseqOptimizer a train step touches, over a plain torch optimizer -- including its zero_grad, which
+    sets `p.grad = None` (fairseq/optim/fairseq_optimizer.py:129-133) -- as the reference trainer builds it: from
+    `model.parameters()`, after `model.to(device)`, before the first train_step (fairseq/trainer.py:292)."""
+
+    def __init__(self, model, **kw):
+        self._optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], **kw)
+
+    @property
+    def params(self):
+        for g in self._optimizer.param_groups:
+            yield from g["params"]
+
+    def backward(self, loss):
+        loss.backward()
+
+    def multiply_grads(self, c):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.mul_(c)
+
+    def step(self):
+        self._optimizer.step()
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+def test_level1_reference_trainer_order_with_an_external_optimizer(golden):
+    """The documented Level-1 path: plugin + the trainer's OWN optimizer.  A training namespace (--optimizer set) makes the model
+    switch to the HIP training engine when it is moved to the GPU, so an optimizer built afterwards from `model.parameters()`
+    -- and before any train_step -- holds `flat_params`; fairseq-style `zero_grad` (grad = None) clears the engine's gradient
+    buffer and the backward restores the alias; an update by that optimizer is picked up by the next forward (bf16 working copy /
+    transposed weights refreshed).  Three updates equal the HIP-backed FlatOptimizer's; a loss scale flows through
+    `optimizer.backward(loss * scale)`; a model built without a training namespace refuses an optimizer that predates the switch."""
+    import types
+
+    from diffnorm_amd import fairseq_plugin, optim  # noqa: F401
+    from diffnorm_amd.fairseq_plugin import registry
+
+    g = golden("vae_train")
+
+    def build(training_ns):
+        args = types.SimpleNamespace(arch="speech_vae_decoder", criterion="speech_vae_decoder_loss", latent_dim=CFG.latent_dim,
+                                     feature_dim=CFG.dim, hip_dtype="f32", target_code_size=1000, data="")
+        if training_ns:
+            args.optimizer, args.lr = "adam", [1e-3]
+        task = registry.TASK_REGISTRY["speech_decoder"].setup_task(args)
+        model = task.build_model(args)
+        model.load_state_dict({"encoder." + k: v for k, v in O.make_vae_state_dict(CFG, "train").items()}, strict=True)
+        model.to(DEV)
+        model.encoder.attn_dropout = 0.0
+        return task, model, task.build_criterion(args)
+
+    task, model, criterion = build(True)
+    assert [n for n, _ in model.named_parameters()] == ["encoder.flat_params"], "the switch happens with model.to(device)"
+    # (eps far below every gradient: torch's Adam adds it to sqrt(v_hat), the fairseq-contract kernel to sqrt(v) before the bias
+    # correction -- with 1e-8 the two differ visibly on near-zero gradients; the pads' 0 / (0 + eps) is 0 either way)
+    ext = _FairseqStyleOptimizer(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-15)  # BEFORE the first train_step
+    task2, model2, criterion2 = build(True)
+    ref = optim.FlatOptimizer(model2.encoder._train_engine, lr=1e-3, betas=(0.9, 0.98), eps=1e-15)
+    for it in range(3):
+        sample = _sample(g, torch.from_numpy(g[f"traj_noise{it}"]))
+        ext.zero_grad()
+        assert model.encoder.flat_params.grad is None
+        loss, n, _ = task.train_step(sample, model, criterion, ext, it)
+        assert model.encoder.flat_params.grad is model.encoder._train_engine.grads
+        ref.zero_grad()
+        loss2, _, _ = task2.train_step(sample, model2, criterion2, ref, it)
+        assert abs(float(loss.detach()) - float(loss2.detach())) <= 1e-5 * abs(float(loss2.detach())), (it, float(loss.detach()), float(loss2.detach()))
+        ga, gb = model.encoder._train_engine.grads, model2.encoder._train_engine.grads
+        assert float((ga - gb).norm() / gb.norm()) < 1e-4, (it, float((ga - gb).norm() / gb.norm()))
+        ext.multiply_grads(1.0 / n)
+        ref.multiply_grads(1.0 / n)
+        ext.step()
+        ref.step()
+        pa, pb = model.encoder._train_engine.master, model2.encoder._train_engine.master
+        assert float((pa - pb).norm() / pb.norm()) < 1e-5, (it, float((pa - pb).norm() / pb.norm()))  # torch's Adam vs the fairseq-contract kernel
+    # loss scaling: the bridge takes any scalar upstream gradient
+    sample = _sample(g, torch.from_numpy(g["post_noise"]))
+    ext.zero_grad()
+    loss, _, _ = criterion(model, sample)
+    ext.backward(loss)
+    plain = model.encoder._train_engine.grads.clone()
+    ext.zero_grad()
+    loss, _, _ = criterion(model, sample)
+    ext.backward(loss * 128.0)
+    assert torch.equal(model.encoder._train_engine.grads / 128.0, plain)
+    loss, _, _ = criterion(model, sample)  # a second micro-batch accumulates c * g on top (grad not None: no zeroing)
+    ext.backward(loss * 128.0)
+    assert float((model.encoder._train_engine.grads / 256.0 - plain).norm() / plain.norm()) < 1e-6
+    # without a training namespace the model keeps its per-tensor parameters until train_step: an optimizer built before is refused
+    task3, model3, criterion3 = build(False)
+    assert len(list(model3.parameters())) > 1
+    stale = _FairseqStyleOptimizer(model3, lr=1e-3)
+    with pytest.raises(RuntimeError, match="flat_params"):
+        task3.train_step(sample, model3, criterion3, stale, 0)
+
+
 def test_reference_style_criterion_differentiates_the_model_outputs(golden):
     """A caller that builds its loss from the model's (mse_loss, lm_logits, kl_loss) -- the reference criterion's own code
     path -- gets the same parameter gradients as the fused criterion: autograd hands d loss / d logits to the HIP backward."""
