@@ -11,6 +11,7 @@ import zlib
 import torch
 
 from ...data import ReprToReprUnitDataset, UnitDictionary
+from ...profiling import profile_range
 from ..registry import MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY, CRITERION_REGISTRY, FairseqTask, register_task
 
 
@@ -139,10 +140,12 @@ class _SpeechTaskBase(FairseqTask):
         if hasattr(enc, "enable_training"):
             enc.enable_training()  # (a training run's model did this when it was moved to the GPU: models/common_args.is_training_run)
             _check_optimizer_holds_flat_params(enc, optimizer)
-        loss, sample_size, logging_output = criterion(model, sample)
+        with profile_range("forward"):  # the reference's range names (speech_decoder_task.py:215-220)
+            loss, sample_size, logging_output = criterion(model, sample)
         if ignore_grad:
             loss = loss * 0
-        optimizer.backward(loss)
+        with profile_range("backward"):
+            optimizer.backward(loss)
         return loss, sample_size, logging_output
 
     def valid_step(self, sample, model, criterion):

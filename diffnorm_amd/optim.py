@@ -117,14 +117,20 @@ class FlatOptimizer:
 
     def clip_grad_norm(self, max_norm, aggregate_norm_fn=None):
         """Returns the norm of the (scaled) gradient as a device scalar; the clip itself happens inside `step`."""
+        from .profiling import profile_range
+
         self._max_norm = float(max_norm)
-        norm = self.adam.grad_sumsq(self.engine.grads).sqrt()[0] * self._scale
+        with profile_range("clip-grads"):  # fairseq/trainer.py:937 (here: the norm; the clip coefficient is applied by dn_adam_step)
+            norm = self.adam.grad_sumsq(self.engine.grads).sqrt()[0] * self._scale
         return norm * self._scale_dev[0] if self._scale_dev is not None else norm
 
     def step(self, closure=None):
+        from .profiling import profile_range
+
         self.adam.clip_norm = self._max_norm
-        self.adam.step(self.engine.grads, grad_scale=self._scale, grad_scale_dev=self._scale_dev)
-        self.engine.refresh()
+        with profile_range("optimizer"):  # fairseq/trainer.py:958
+            self.adam.step(self.engine.grads, grad_scale=self._scale, grad_scale_dev=self._scale_dev)
+            self.engine.refresh()
         self._scale, self._scale_dev = 1.0, None
 
     def zero_grad(self):

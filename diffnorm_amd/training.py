@@ -16,6 +16,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, optim, packing
+from .profiling import profile_range
 from .engine import _dtype_code, _require_cuda
 
 
@@ -467,26 +468,30 @@ class VaeTrainer:
         eng.zero_grad()
         totals = torch.zeros(10, dtype=torch.float32, device=eng.device)  # sum_i nsent_i * stats_i [0:8], nsentences, ntokens
         for k, sample in enumerate(samples):
-            stats = self._forward(sample, None if noises is None else noises[k])
+            with profile_range("forward"):
+                stats = self._forward(sample, None if noises is None else noises[k])
             nsent = float(sample["nsentences"])
             totals[:8] += stats * nsent
             totals[8] += nsent
             totals[9] += float(sample["ntokens"])
-            if k + 1 < len(samples):
-                eng.backward()
-                continue
-            for stage in range(eng.n_stages):  # last micro-batch: ranges enter the all-reduce as they complete
-                eng.backward(stage, stage)
-                b = red.bucket_after_stage(stage)
-                if b is not None:
-                    red.reduce_bucket(b)
-        if red.world > 1:
-            red.dist.all_reduce(totals, group=self.group)  # the one small statistics exchange (replaces all_gather_list of dicts)
-        red.finish()
+            with profile_range("backward"):
+                if k + 1 < len(samples):
+                    eng.backward()
+                    continue
+                for stage in range(eng.n_stages):  # last micro-batch: ranges enter the all-reduce as they complete
+                    eng.backward(stage, stage)
+                    b = red.bucket_after_stage(stage)
+                    if b is not None:
+                        red.reduce_bucket(b)
+        with profile_range("reduce-grads"):  # (the buckets were issued under the backward; this is the wait + the statistics exchange)
+            if red.world > 1:
+                red.dist.all_reduce(totals, group=self.group)  # the one small statistics exchange (replaces all_gather_list of dicts)
+            red.finish()
         inv_sample_size = 1.0 / totals[8:9]  # sample_size = sum of nsentences over ranks and micro-batches (criterion :84)
         self.adam.set_lr(self.schedule.step_update(self.num_updates))
-        grad_norm = self.adam.step(eng.grads, grad_scale=1.0, grad_scale_dev=inv_sample_size)
-        eng.refresh()
+        with profile_range("optimizer"):  # multiply-grads and clip-grads are not passes of their own: both happen inside dn_adam_step
+            grad_norm = self.adam.step(eng.grads, grad_scale=1.0, grad_scale_dev=inv_sample_size)
+            eng.refresh()
         self.num_updates += 1
         logged = totals[:8] / totals[8]  # sample-size-weighted means, as reduce_metrics (:97-112)
         return logged, grad_norm

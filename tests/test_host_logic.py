@@ -167,3 +167,19 @@ def test_split_rows_round_trip_on_host():
     w = packing.split_rows(x, weight=True)                                              # weights: lo half first
     assert torch.equal(w[:, 32:64], s[:, :32]) and torch.equal(w[:, :32], s[:, 32:64])
     assert torch.equal(packing.unsplit_rows(w), back)
+
+
+def test_profile_ranges_carry_the_reference_names():
+    """diffnorm_amd.profiling: the phases of an update are bracketed with the names the reference trainer uses (fairseq/trainer.py:
+    912-958, fairseq/tasks/speech_decoder_task.py:215-220) as torch profiler ranges (+ roctx where libroctx64 loads): a trace of this
+    build's update reads like the reference's."""
+    from diffnorm_amd import profiling
+
+    assert profiling.RANGES == ("forward", "backward", "reduce-grads", "multiply-grads", "clip-grads", "optimizer")
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        for name in profiling.RANGES:
+            with profiling.profile_range(name):
+                torch.ones(4).sum()
+    seen = {e.key for e in prof.key_averages()}
+    assert set(profiling.RANGES) <= seen
+
