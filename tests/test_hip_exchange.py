@@ -1,0 +1,66 @@
+"""The multi-rank exchange of data-parallel training on GPU buffers (training row): two FRESH processes (subprocess ->
+torch.distributed.run, as bench.py's launcher does; no process that touched the GPU is re-exec'ed) share cuda:0, each with the
+real training engine + trainer and its own batch, and exchange over gloo -- the GradientReducer's GPU branch (ready event -> side
+stream -> async all-reduce per bucket -> finish) plus the statistics all-reduce.  Checked against ONE process running the two
+batches as two micro-batches of one update (2 ranks x 1 micro-batch == 1 rank x 2 micro-batches: the same summed gradient, the
+same 1 / sample_size, the same clip and Adam): post-exchange gradient, gradient norm, logged statistics and the master buffer
+after 3 updates, f32; and the two ranks end bit-identical to each other.  Reference: fairseq/models/distributed_fairseq_model.py:
+59-84 (DDP), fairseq/trainer.py:912-939."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _launch(kind, out_dir):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "exchange_worker.py"), kind, str(out_dir)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    errs = "".join(open(os.path.join(out_dir, f)).read() for f in sorted(os.listdir(out_dir)) if f.startswith("error_rank"))
+    assert r.returncode == 0, errs or (r.stdout[-3000:] + r.stderr[-3000:])
+    return [np.load(os.path.join(out_dir, f"rank{k}.npz")) for k in range(2)]
+
+
+@pytest.mark.parametrize("kind", ["vae", "diffusion"])
+def test_two_ranks_on_gpu_buffers_equal_one_rank_with_two_micro_batches(kind, tmp_path):
+    sys.path.insert(0, HERE)
+    import exchange_worker as W
+
+    ranks = _launch(kind, tmp_path)
+    for k in ranks[0].files:  # replicas stay identical: same summed gradient, same update
+        assert np.array_equal(ranks[0][k], ranks[1][k]), f"ranks differ in {k}"
+    assert int(ranks[0]["buckets"]) >= 3
+    # the same two batches as two micro-batches of one update in THIS process (world 1: no exchange)
+    dev = torch.device("cuda", 0)
+    tr, cfg, z = W.build(kind, dev, 1)
+    assert tr.reducer.world == 1
+    batches = []
+    for r in range(2):
+        sample, draws = W.make_batch(r, cfg.dim, z)
+        batches.append((sample, draws, r))
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        one = W.run(kind, tr, batches, 3)
+        torch.cuda.synchronize()
+    two = ranks[0]
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    assert rel(two["grad0"], one["grad0"]) < 1e-5, rel(two["grad0"], one["grad0"])  # post-exchange gradient = gradient of the concatenated batches
+    for it in range(3):
+        assert abs(float(two[f"norm{it}"]) - one[f"norm{it}"]) <= 1e-5 * one[f"norm{it}"], (it, float(two[f"norm{it}"]), one[f"norm{it}"])
+        assert rel(two[f"logged{it}"][:5], one[f"logged{it}"][:5]) < 1e-5
+    assert rel(two["master"], one["master"]) < 1e-5, rel(two["master"], one["master"])
