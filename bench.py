@@ -426,6 +426,19 @@ def run_sampling(args, ctx):
         if sb is not None and (B, T, args.dtype) == (32, 512, "bf16"):
             result["hbm_bytes_per_step"] = sb
             result["hbm_gbps_per_gpu"] = sb * K / dt / 1e9
+        # BASELINE configs[2] read literally ("DDPM reverse sampling"): the same chain with the ancestral update of
+        # GaussianDiffusion.p_sample, noise drawn in the update kernel (dn_ddpm_loop) -- 20 steps after a 3-step set-up
+        if world == 1:
+            with torch.cuda.stream(stream):
+                gtab = sched.gaussian_table(dev)
+                xd = ops.randn((B, T, cfg.latent_dim), seed=4321, device=dev)
+                eng.ddpm_loop(xd, lengths, args.timesteps, gtab, seed=11, use_graph=not args.no_graph, max_evals=3, split=not args.no_split)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.ddpm_loop(xd, lengths, args.timesteps - 3, gtab, seed=11, use_graph=not args.no_graph, max_evals=20, split=not args.no_split, keep_table=True)
+                torch.cuda.synchronize()
+                result["ddpm_steps_per_s"] = 20 / (time.perf_counter() - t1)
+                assert torch.isfinite(xd).all().item()
         result["tolerance"] = TOLERANCE
         if world == 1 and not args.no_x3 and args.dtype == "bf16":
             result.update(x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths))

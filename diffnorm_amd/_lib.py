@@ -191,6 +191,7 @@ SYMBOLS = {
     "dn_vae_decode": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dn_ddim_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "dn_ddim_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "dn_ddpm_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, C.c_uint64, _vp, _i32, _vp, _sz, _vp]),
     "dn_last_error": (C.c_char_p, []),
     "dn_version": (C.c_int, []),
 }

@@ -107,6 +107,7 @@ struct DnEps {
   const int32_t* graph_len;
   const float* graph_coef;
   int graph_flags;
+  uint64_t graph_seed;  // dn_ddpm_loop: the Philox key baked into the captured step
   void *side_stream, *ev_fork, *ev_join;  // DN_LOOP_SPLIT2: second half-batch stream and its fork/join events
   // DN_LOOP_KEEP_TABLE: the conditioning table built by the previous dn_ddim_loop call on this workspace
   void* table_ws;

@@ -542,14 +542,28 @@ extern "C" size_t dn_ddim_workspace_bytes(const DnEps* m, int32_t B, int32_t T, 
   return (whole > halves ? whole : halves) + ddim_extra_bytes(m, B, T, start_step);
 }
 
-extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
-                            const float* coef, int32_t timesteps, int32_t flags, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+int dn_ddpm_step_launch(float* x, const float* eps, int M, int C, int T, const float* table, const int32_t* t, int clip, const float* noise,
+                        int64_t noise_row, int t_top, uint64_t seed, hipStream_t stream);  // pointwise.hip
+
+namespace {
+// the scheduler update applied after every evaluation of the device loop
+struct StepOp {
+  bool ddpm = false;        // false: DDIM eta = 0 with `coef` [timesteps, 4]; true: ancestral step with `coef` = table [timesteps, DN_GD_COLS]
+  int clip = 0;
+  uint64_t seed = 0;
+  const float* noise = nullptr;  // injected noise rows (ddpm) or NULL
+};
+}  // namespace
+
+static int sampler_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
+                        const float* coef, int32_t timesteps, int32_t flags, void* workspace, size_t workspace_bytes, void* stream,
+                        const StepOp& op) {
   DN_CHECK_ARG(m && m->cfg.dim_prompt == 0, "dn_ddim_loop: the device loop covers the unconditional model (prompted chains step through dn_eps_forward_cond)");
   int use_graph = flags & DN_LOOP_GRAPH;
   const bool split = (flags & DN_LOOP_SPLIT2) && B >= 2;
   DN_CHECK_ARG(m && x && lengths && coef && workspace, "dn_ddim_loop: null argument");
-  DN_CHECK_ARG(start_step >= 1 && start_step <= timesteps - 1, "dn_ddim_loop: start_step=%d must be in [1, %d]", start_step, timesteps - 1);
+  DN_CHECK_ARG(start_step >= 1 && start_step <= timesteps - (op.ddpm ? 0 : 1), "dn_ddim_loop: start_step=%d must be in [1, %d]", start_step,
+               timesteps - (op.ddpm ? 0 : 1));
   hipStream_t s = (hipStream_t)stream;
   DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_ddim_loop: workspace must be 256-byte aligned");
   const int z = m->cfg.latent, M = B * T, C = m->cfg.dim * m->cfg.cond_mult;
@@ -585,7 +599,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   float* cond_all = (float*)ar.take((size_t)start_step * C * 4);
   void* table_h = m->cfg.dtype == DN_F32 ? nullptr : ar.take((size_t)start_step * m->n_cond * esize(m->cfg.dtype));
   int32_t* tall = (int32_t*)ar.take((size_t)start_step * 4);
-  const int last = start_step == 1 ? 0 : 1;  // the loop breaks after the t == 1 update (:1444-1445)
+  const int last = (start_step == 1 || op.ddpm) ? 0 : 1;  // DDIM: the loop breaks after the t == 1 update (:1444-1445); p_sample_loop runs t = 0 too
   int n_eval = start_step - last;             // t = start_step-1 ... last
   if (max_evals > 0 && max_evals < n_eval) n_eval = max_evals;  // partial chain (benchmarks, chunked sampling)
   // The 56 conditioning vectors depend only on t: build them for the whole chain once (fp32), so the
@@ -597,6 +611,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
     DN_TRY(eps_cond_rows(m, tall, start_step, cond_all, table, table_h, s));
     m->table_ws = workspace; m->table_B = B; m->table_T = T; m->table_split = (int)split; m->table_rows = start_step;
   }
+  const int noise_top = start_step - 1;  // injected noise: row (noise_top - t) belongs to step t
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
     hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_row, counter, bufs.gb);
@@ -607,10 +622,17 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
         return DN_ELAUNCH;
       }
       DN_TRY(eps_core(m, x + off, bufs.gb, 0, lengths + B0, B1, T, eps + off, bufs1, s2));
-      DN_TRY(dn_ddim_step(x + off, eps + off, x + off, nullptr, DN_F32, z, B1 * T, z, z, T, coef, tvec + B0, s2));
+      if (op.ddpm)
+        DN_TRY(dn_ddpm_step_launch(x + off, eps + off, B1 * T, z, T, coef, tvec + B0, op.clip, op.noise ? op.noise + off : nullptr, (int64_t)M * z,
+                                   noise_top, op.seed ^ 0x9E3779B97F4A7C15ull, s2));  // (the second half draws from its own key)
+      else
+        DN_TRY(dn_ddim_step(x + off, eps + off, x + off, nullptr, DN_F32, z, B1 * T, z, z, T, coef, tvec + B0, s2));
     }
     DN_TRY(eps_core(m, x, bufs.gb, 0, lengths, B0, T, eps, bufs, s));
-    DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, B0 * T, z, z, T, coef, tvec, s));
+    if (op.ddpm)
+      DN_TRY(dn_ddpm_step_launch(x, eps, B0 * T, z, T, coef, tvec, op.clip, op.noise, (int64_t)M * z, noise_top, op.seed, s));
+    else
+      DN_TRY(dn_ddim_step(x, eps, x, nullptr, DN_F32, z, B0 * T, z, z, T, coef, tvec, s));
     if (split) {  // join
       if (hipEventRecord((hipEvent_t)m->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, (hipEvent_t)m->ev_join, 0) != hipSuccess) {
         dn_set_error("dn_ddim_loop: join failed");
@@ -625,8 +647,11 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
   int done = 0;
   if (!s) use_graph = 0;  // the null stream cannot be captured
   if (use_graph && n_eval > 2) {
+    const int gflags = (flags & ~DN_LOOP_KEEP_TABLE) | (op.ddpm ? 1 << 16 : 0) | (op.clip ? 1 << 17 : 0);
+    // (an injected-noise chain bakes noise_top into the captured step: never served from the cache)
     const bool cached = m->graph_exec && m->graph_B == B && m->graph_T == T && m->graph_ws == workspace && m->graph_x == x &&
-                        m->graph_len == lengths && m->graph_coef == coef && m->graph_flags == (flags & ~DN_LOOP_KEEP_TABLE);
+                        m->graph_len == lengths && m->graph_coef == coef && m->graph_flags == gflags && !op.noise &&
+                        m->graph_seed == op.seed;
     if (!cached) {
       DN_TRY(one_step());  // eager first step: also settles the per-kernel attributes outside capture
       done = 1;
@@ -654,7 +679,7 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
         return DN_ELAUNCH;
       }
       m->graph_exec = exec; m->graph_B = B; m->graph_T = T; m->graph_ws = workspace; m->graph_x = x;
-      m->graph_len = lengths; m->graph_coef = coef; m->graph_flags = flags & ~DN_LOOP_KEEP_TABLE;
+      m->graph_len = lengths; m->graph_coef = coef; m->graph_flags = op.noise ? -1 : gflags; m->graph_seed = op.seed;
     }
     for (; done < n_eval; ++done) {
       hipError_t e = hipGraphLaunch((hipGraphExec_t)m->graph_exec, s);
@@ -667,6 +692,20 @@ extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t 
     for (; done < n_eval; ++done) DN_TRY(one_step());
   }
   return n_eval;
+}
+
+extern "C" int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
+                            const float* coef, int32_t timesteps, int32_t flags, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  return sampler_loop(m, x, lengths, B, T, start_step, max_evals, coef, timesteps, flags, workspace, workspace_bytes, stream, StepOp());
+}
+
+extern "C" int dn_ddpm_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
+                            const float* table, int32_t timesteps, int32_t clip_denoised, uint64_t seed, const float* noise, int32_t flags,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  StepOp op;
+  op.ddpm = true; op.clip = clip_denoised; op.seed = seed; op.noise = noise;
+  return sampler_loop(m, x, lengths, B, T, start_step, max_evals, table, timesteps, flags, workspace, workspace_bytes, stream, op);
 }
 
 

@@ -250,6 +250,64 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int
   }
 }
 
+// ------------------------------------------------------------------------------------------ ancestral (DDPM) step of the device loop
+// p_sample (diffusion/gaussian_diffusion.py:376-417) with a fixed variance, the arithmetic of gaussian_step_kernel's sampler 0;
+// the noise is injected (`noise`, the row of this step) or drawn here: Philox4x32-10, key = seed, counter = (element quad, t) --
+// t comes from the per-sample step vector the loop fills from its device counter, so graph replays draw fresh noise.
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr_lo, uint32_t ctr_hi, float (&r)[4]);
+__global__ __launch_bounds__(256) void ddpm_step_kernel(float* x, const float* __restrict__ eps, int M, int C, int T,
+                                                        const float* __restrict__ table, const int32_t* __restrict__ t,
+                                                        int clip, const float* __restrict__ noise, int64_t noise_row, int t_top,
+                                                        uint64_t seed) {
+  const int64_t nquad = ((int64_t)M * C) >> 2;  // C is a multiple of 4: a quad stays inside one row
+  for (int64_t q = blockIdx.x * 256 + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = q << 2;
+    const int m = (int)(i / C);
+    const int tn = t[m / T];
+    const float* tb = table + (int64_t)tn * DN_GD_COLS;
+    const float4 xv = *reinterpret_cast<const float4*>(x + i), ev = *reinterpret_cast<const float4*>(eps + i);
+    float z[4];
+    if (noise) {
+      const float4 nv = *reinterpret_cast<const float4*>(noise + (int64_t)(t_top - tn) * noise_row + i);
+      z[0] = nv.x; z[1] = nv.y; z[2] = nv.z; z[3] = nv.w;
+    } else {
+      philox_normal4(seed, (uint64_t)q, (uint32_t)tn, z);
+    }
+    const float sd = tn != 0 ? expf(__fmul_rn(0.5f, tb[4])) : 0.0f;
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, es[4] = {ev.x, ev.y, ev.z, ev.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = __fsub_rn(__fmul_rn(tb[0], xs[j]), __fmul_rn(tb[1], es[j]));
+      if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      const float mean = __fadd_rn(__fmul_rn(tb[2], x0), __fmul_rn(tb[3], xs[j]));
+      o[j] = __fadd_rn(mean, __fmul_rn(sd, z[j]));
+    }
+    *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr_lo, uint32_t ctr_hi, float (&r)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), ctr_hi, 0x44504d50u};  // ("DPMP": a stream apart from dn_randn's)
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // Box-Muller on (0,1) uniforms, as randn_kernel
+    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    r[2 * h] = rad * cs;
+    r[2 * h + 1] = rad * sn;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ convert rows
 __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restrict__ src, int sdt, int lds, void* __restrict__ dst, int ddt,
                                                            int ldd, int M, int C) {
@@ -469,6 +527,16 @@ extern "C" int dn_ddim_step(const float* x, const float* eps, float* x_out, void
   hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_grid((int64_t)M * C)), dim3(256), 0, (hipStream_t)stream, x, eps, x_out, x_act, act_dtype,
                      ld_act, M, C, ld, T, coef, t);
   DN_CHECK_LAUNCH("dn_ddim_step");
+  return DN_OK;
+}
+
+// (engine.hip: the ancestral update of dn_ddpm_loop)
+int dn_ddpm_step_launch(float* x, const float* eps, int M, int C, int T, const float* table, const int32_t* t, int clip, const float* noise,
+                        int64_t noise_row, int t_top, uint64_t seed, hipStream_t stream) {
+  DN_CHECK_ARG(C % 4 == 0, "dn_ddpm_loop: the latent width must be a multiple of 4");
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(ew_grid(((int64_t)M * C) >> 2)), dim3(256), 0, stream, x, eps, M, C, T, table, t, clip, noise,
+                     noise_row, t_top, seed);
+  DN_CHECK_LAUNCH("dn_ddpm_loop step");
   return DN_OK;
 }
 

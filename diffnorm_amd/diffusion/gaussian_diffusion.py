@@ -61,13 +61,7 @@ class GaussianDiffusion(ScheduleTables):
     def _table(self, device):
         key = str(device)
         if key not in self._dev_tables:
-            fixed_var = (np.append(self.posterior_variance[1], self.betas[1:]) if self.model_var_type == ModelVarType.FIXED_LARGE
-                         else self.posterior_variance)  # (:300-310)
-            cols = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
-                    self.posterior_mean_coef2, self._fixed_log_variance(), self.posterior_log_variance_clipped,
-                    np.log(self.betas), self.alphas_cumprod, self.alphas_cumprod_prev,
-                    np.append(self.alphas_cumprod[1:], 0.0), self.posterior_variance, fixed_var]
-            tab = torch.from_numpy(np.stack(cols, axis=1).astype(np.float32)).contiguous().to(device)
+            tab = self.gaussian_table(device, fixed_large=self.model_var_type == ModelVarType.FIXED_LARGE)  # (:300-310)
             sa, s1 = self.f32("sqrt_alphas_cumprod", device), self.f32("sqrt_one_minus_alphas_cumprod", device)
             self._dev_tables[key] = (tab, sa, s1)
         return self._dev_tables[key]

@@ -152,6 +152,32 @@ class EpsEngine(_Engine):
                                                     _lib.current_stream()), "dn_ddim_loop")
 
 
+    def ddpm_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, table: torch.Tensor, seed: int = 0,
+                  noise: Optional[torch.Tensor] = None, clip_denoised: bool = False, use_graph: bool = True, max_evals: int = 0,
+                  split: bool = True, keep_table: bool = False) -> int:
+        """In-place ancestral (DDPM) chain on x [B,T,z] fp32: GaussianDiffusion.p_sample (reference diffusion/gaussian_diffusion.py:
+        376-417) for t = start_step-1 .. 0, x given at index start_step-1 (x_T ~ N(0, I) with start_step = timesteps: BASELINE
+        configs[2] read literally).  table: fp32 [timesteps, 12] from `scheduler.gaussian_table`.  The noise of a step is drawn
+        in the update kernel (Philox keyed by `seed` and the step) or injected: noise [start_step, B, T, z], row k for
+        t = start_step-1-k.  Returns the number of model evaluations."""
+        B, T, z = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.device == self.device
+        assert table.dtype == torch.float32 and table.is_contiguous() and table.device == self.device and table.shape[1] == 12
+        l32 = lengths if (lengths.dtype == torch.int32 and lengths.device == self.device) else _i32(lengths, self.device)
+        nz = None
+        if noise is not None:
+            nz = _f32(noise, self.device)
+            assert nz.shape == (start_step, B, T, z), (nz.shape, (start_step, B, T, z))
+        self._keep = (l32, table, nz)
+        ws = self._workspace(int(self.lib.dn_ddim_workspace_bytes(self.handle, B, T, start_step)))
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            return _lib.check(self.lib.dn_ddpm_loop(self.handle, x.data_ptr(), l32.data_ptr(), B, T, start_step, max_evals, table.data_ptr(),
+                                                    table.shape[0], int(clip_denoised), int(seed) & (2 ** 64 - 1), _lib.ptr(nz),
+                                                    (1 if use_graph else 0) | (2 if split else 0) | (4 if keep_table else 0), wp, wn,
+                                                    _lib.current_stream()), "dn_ddpm_loop")
+
+
 class VaeEngine(_Engine):
     """SpeechVAEEncoderDecoder (reference latent_module.py:1035-1142) on the GPU."""
 

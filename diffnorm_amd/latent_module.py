@@ -527,6 +527,37 @@ class LatentDiscreteModel(nn.Module):
         out_tokens = [pred_units[i, : lens[i]] for i in range(B)]
         return out_tokens, match, total, recon
 
+    @torch.no_grad()
+    def ddpm_sample(self, tgt_feature, input_mask=None, ref_units=None, start_step=50, post_noise=None, start_noise=None, seed=0,
+                    step_noise=None, fixed_large=False, clip_denoised=False, use_graph=True):
+        """The chain of `ddim_sample` with the ancestral (DDPM) update -- GaussianDiffusion.p_sample (reference diffusion/
+        gaussian_diffusion.py:376-417) on this model's cosine schedule: encode, noise to index start_step-1 (q_sample), then
+        t = start_step-1 .. 0 on the device (dn_ddpm_loop; the per-step noise drawn in the kernel from `seed`, or `step_noise`
+        [start_step, B, T, z] injected), decode, units.  BASELINE configs[2] read literally; the reference's LatentDiscreteModel
+        itself only has the DDIM sampler.  -> (list of unit tensors, match, total, recon_feature)."""
+        dev = self.device
+        _, sa, s1 = self._tables()
+        B, T, _ = tgt_feature.shape
+        if input_mask is None:
+            input_mask = torch.ones(B, T, dtype=torch.bool, device=dev)
+        input_mask = input_mask.to(dev)
+        lengths = _mask_to_lengths(input_mask).to(torch.int32)
+        z = self.speech_decoder.encode_feature(tgt_feature, noise=post_noise).transpose(1, 2).contiguous()
+        if start_noise is None:
+            start_noise = torch.randn(z.shape, device=dev)
+        t_start = torch.full((B,), start_step - 1, dtype=torch.int32, device=dev)
+        x = ops.q_sample(z, start_noise.to(dev, torch.float32).contiguous(), sa, s1, t_start, T)
+        key = ("gd", bool(fixed_large))
+        if getattr(self, "_gd_table", (None,))[0] != key or self._gd_table[1].device != dev:
+            self._gd_table = (key, self.scheduler.gaussian_table(dev, fixed_large=fixed_large))
+        self.model.engine().ddpm_loop(x, lengths, start_step, self._gd_table[1], seed=seed, noise=step_noise, clip_denoised=clip_denoised,
+                                      use_graph=use_graph)
+        recon, _, units = self.speech_decoder.engine().decode(x, lengths, want_logits=False)
+        pred_units = units.long()
+        match = (pred_units[input_mask] == ref_units.to(dev)[input_mask]).sum().item() if ref_units is not None else 0
+        lens = lengths.tolist()
+        return [pred_units[i, : lens[i]] for i in range(B)], match, int(input_mask.sum().item()), recon
+
     def forward(self, audio, audio_units, src_feature=None, src_mask=None, tgt_mask=None, prompt=None, pitch=None,
                 times=None, post_noise=None, jitter_noise=None, true_noise=None, *args, **kwargs):
         """Training loss dict (:1514-1613), forward only.  t, the posterior noise, the beta_0 jitter and the target

@@ -56,6 +56,19 @@ class ScheduleTables:
         t = torch.from_numpy(np.ascontiguousarray(arr.astype(np.float32)))
         return t.to(device) if device is not None else t
 
+    def gaussian_table(self, device=None, fixed_large: bool = False) -> torch.Tensor:
+        """fp32 [timesteps, DN_GD_COLS = 12] table of dn_gaussian_step / dn_gaussian_moments / dn_ddpm_loop: {sqrt_recip_abar,
+        sqrt_recipm1_abar, posterior_mean_coef1, posterior_mean_coef2, fixed log-variance (FIXED_SMALL: the clipped posterior
+        log-variance; FIXED_LARGE: log [posterior_variance[1], betas[1:]], diffusion/gaussian_diffusion.py:300-310),
+        posterior_log_variance_clipped, log betas, abar, abar_prev, abar_next, posterior_variance, the fixed variance}."""
+        fixed_var = np.append(self.posterior_variance[1], self.betas[1:]) if fixed_large else self.posterior_variance
+        fixed_log = np.log(np.append(self.posterior_variance[1], self.betas[1:])) if fixed_large else self.posterior_log_variance_clipped
+        cols = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1, self.posterior_mean_coef2,
+                fixed_log, self.posterior_log_variance_clipped, np.log(self.betas), self.alphas_cumprod, self.alphas_cumprod_prev,
+                np.append(self.alphas_cumprod[1:], 0.0), self.posterior_variance, fixed_var]
+        t = torch.from_numpy(np.stack(cols, axis=1).astype(np.float32)).contiguous()
+        return t.to(device) if device is not None else t
+
     def ddim_coef_table(self, device=None) -> torch.Tensor:
         """[timesteps, 4] fp32 rows {sqrt_abar, sqrt(1-abar), sqrt(abar_prev), sqrt(1-abar_prev)} with the
         last two formed in fp32 from the fp32-cast abar_prev, as the eta=0 update does (:1426-1437)."""

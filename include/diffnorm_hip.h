@@ -487,6 +487,20 @@ int dn_ddim_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t 
                  int32_t max_evals, const float* coef, int32_t timesteps, int32_t flags, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* The same device loop with the ancestral (DDPM) update of GaussianDiffusion.p_sample / p_sample_loop
+ * (diffusion/gaussian_diffusion.py:376-417, 459-511) instead of DDIM eta = 0 -- BASELINE configs[2] read literally: for
+ * t = start_step-1 .. 0 (t = 0 IS evaluated, its noise masked): eps = Model(x, t); x0 = sqrt_recip_abar x - sqrt_recipm1_abar eps
+ * [clamped to +-1 when clip_denoised]; mean = coef1 x0 + coef2 x; x <- mean + 1[t != 0] exp(0.5 log_var_t) z.
+ * table: fp32 [timesteps, DN_GD_COLS] as dn_gaussian_step takes it (column 4 = the fixed log-variance: FIXED_SMALL or
+ * FIXED_LARGE).  z: injected -- noise fp32 [start_step, B*T*latent], row (start_step-1-t) used at step t (parity runs) -- or,
+ * noise == NULL, drawn in the update kernel from Philox4x32-10 keyed by `seed` with the counter (t, element quad): the step
+ * index is read from the loop's device counter, so a captured graph draws fresh noise at every replay.  Everything else
+ * (conditioning table once per chain, hipGraph replay, two half-batch streams, max_evals / KEEP_TABLE) as dn_ddim_loop;
+ * workspace: dn_ddim_workspace_bytes.  Returns the number of model evaluations or a negative error.                     */
+int dn_ddpm_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, int32_t T, int32_t start_step, int32_t max_evals,
+                 const float* table, int32_t timesteps, int32_t clip_denoised, uint64_t seed, const float* noise, int32_t flags,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ VAE training step (BASELINE config 4) */
 /* speech_vae_decoder_loss training (reference SpeechVAEEncoderDecoder.forward latent_module.py:1118-1142 + the criterion
  * fairseq/criterions/speech_vae_decoder_loss.py:45-95) on flat buffers in the PACKED parameter layout (csrc/engine.h: rows

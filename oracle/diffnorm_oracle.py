@@ -550,6 +550,18 @@ def diffusion_train_forward(eps_sd: SD, eps_cfg: EpsConfig, vae_sd: SD, vae_cfg:
 
 
 # --------------------------------------------------------------------------- generic Gaussian scheduler
+def ddpm_chain(eps_sd: SD, eps_cfg: EpsConfig, timesteps: int, x: Tensor, mask: Tensor, start_step: int, noises: Tensor,
+               var_type: str = "fixed_small", clip_denoised: bool = False) -> Tensor:
+    """Ancestral (DDPM) chain over the eps-predictor on the cosine schedule: GaussianDiffusion.p_sample
+    (diffusion/gaussian_diffusion.py:376-417) for t = start_step-1 .. 0 from x at index start_step-1, noises[k] used at
+    t = start_step-1-k (what dn_ddpm_loop runs on the device; pinned by tests/golden/ddpm_chain.npz, the real reference's steps)."""
+    diff = GaussianDiffusionOracle(cosine_betas(timesteps), var_type)
+    model = lambda xx, tt: eps_forward(eps_sd, eps_cfg, xx, tt, mask)  # noqa: E731
+    for k, t in enumerate(range(start_step - 1, -1, -1)):
+        x = diff.p_sample(model, x, torch.full((x.shape[0],), t, dtype=torch.long), noises[k], clip_denoised)["sample"]
+    return x
+
+
 def space_timesteps(num_timesteps: int, section_counts) -> set:
     """diffusion/respace.py:12-62."""
     if isinstance(section_counts, str):

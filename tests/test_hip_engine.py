@@ -293,3 +293,55 @@ def test_eps_conditional_variant_vs_reference_golden(eng, golden, dtype, tol):
     assert torch.equal(again, cond)
     with pytest.raises(Exception):
         e.forward(x.to(DEV), t, lens)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)])
+def test_ddpm_loop_matches_reference_p_sample_steps(eng, golden, dtype, tol):
+    """dn_ddpm_loop (BASELINE configs[2] read literally: ancestral sampling, GaussianDiffusion.p_sample, diffusion/
+    gaussian_diffusion.py:376-417) against five real-reference steps t = 4 .. 0 with the reference's recorded noise injected:
+    FIXED_SMALL / FIXED_LARGE variance, clip_denoised, eager == hipGraph == two half-batch streams.  With the in-kernel Philox
+    noise: reproducible per seed, different per seed and per step, and the noise it adds has the schedule's variance."""
+    engine, scheduler = eng
+    g = golden("ddpm_chain")
+    e = engine.EpsEngine(O.make_eps_state_dict(CHAIN_EPS, "chain"), CHAIN_EPS, dtype=dtype, device=DEV)
+    sched = scheduler.DDPMScheduler(200)
+    lens = T_(g["lens"]).to(DEV).int()
+    mask = O.lengths_to_mask(T_(g["lens"]), 48)
+    for name, large, clip in (("small", False, False), ("large", True, False), ("small_clip", False, True)):
+        table = sched.gaussian_table(DEV, fixed_large=large)
+        outs = []
+        for graph, split in ((False, False), (True, False), (True, True)):
+            x = T_(g[f"{name}_x_start"]).to(DEV).clone()
+            with torch.cuda.stream(torch.cuda.Stream()):
+                assert e.ddpm_loop(x, lens, 5, table, noise=T_(g[f"{name}_noise"]), clip_denoised=clip, use_graph=graph, split=split) == 5
+            torch.cuda.synchronize()
+            outs.append(x.cpu())
+        err = maxerr(outs[0][mask], T_(g[f"{name}_x_end"])[mask])
+        print(f"ddpm chain {name} {dtype}: max abs err {err:.3e}")
+        assert err < tol
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    # in-kernel noise (Philox keyed by seed and step)
+    table = sched.gaussian_table(DEV)
+    x0 = T_(g["small_x_start"]).to(DEV)
+
+    def run(seed, steps, graph):
+        x = x0.clone()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            assert e.ddpm_loop(x, lens, 5, table, seed=seed, use_graph=graph, split=False, max_evals=steps) == steps
+        torch.cuda.synchronize()
+        return x.cpu()
+
+    a, b, c = run(7, 5, False), run(7, 5, True), run(8, 5, False)
+    assert torch.equal(a, b) and not torch.equal(a, c)  # a seed reproduces, eager == graph replay (the step index is read on the device)
+    # one step from the same x: (x_out - mean) / sigma_t is standard normal; mean from a zero-noise injected step
+    one = run(7, 1, False)
+    xz = x0.clone()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        e.ddpm_loop(xz, lens, 5, table, noise=torch.zeros(5, *x0.shape), use_graph=False, split=False, max_evals=1)
+    torch.cuda.synchronize()
+    sigma = float(np.exp(0.5 * sched.posterior_log_variance_clipped[4]))
+    zed = ((one - xz.cpu()) / sigma).flatten()
+    assert abs(zed.mean().item()) < 0.15 and abs(zed.std().item() - 1.0) < 0.1, (zed.mean().item(), zed.std().item())
+    two = run(7, 2, False)  # the second step's draw differs from the first's (counter = step)
+    assert not torch.allclose((two - one).flatten()[:64], torch.zeros(64))
+

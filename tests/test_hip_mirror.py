@@ -64,6 +64,38 @@ def test_ddim_sample_matches_reference(ldm, golden):
         assert [t.shape[0] for t in toks] == lens.tolist()
 
 
+def test_ddpm_sample_through_the_mirror(ldm, golden):
+    """LatentDiscreteModel.ddpm_sample (encode -> q_sample to index start_step-1 -> device ancestral loop -> decode): with the
+    step noise injected it equals the CPU oracle's chain (encode / p_sample steps / decode, every piece pinned to the reference
+    separately); with in-kernel noise it is reproducible per seed."""
+    g = golden("chain_small")
+    feat = seeded((3, 48, CHAIN_VAE.dim), 31)
+    lens = T_(g["lens"])
+    mask = O.lengths_to_mask(lens, 48)
+    start = 5
+    post, sn = T_(g["s5_post_noise"]), T_(g["s5_start_noise"])
+    steps = seeded((start, 3, 48, CHAIN_VAE.z), 91)
+    toks, _, total, recon = ldm.ddpm_sample(feat.to(DEV), input_mask=mask.to(DEV), start_step=start, post_noise=post, start_noise=sn, step_noise=steps)
+    vsd, esd = O.make_vae_state_dict(CHAIN_VAE, "chain"), O.make_eps_state_dict(CHAIN_EPS, "chain")
+    with torch.no_grad():
+        z = O.vae_encode(vsd, CHAIN_VAE, feat, post)
+        tab = O.ddpm_tables(200)
+        t = torch.full((3,), start - 1, dtype=torch.long)
+        x = tab.at("sqrt_alphas_cumprod", t, 3) * z + tab.at("sqrt_one_minus_alphas_cumprod", t, 3) * sn
+        x = O.ddpm_chain(esd, CHAIN_EPS, 200, x, mask, start, steps)
+        want_recon, want_logits = O.vae_decode(vsd, CHAIN_VAE, x, mask)
+    tol = 1e-3 if ldm.test_dtype != "bf16" else 2e-2
+    close(recon.cpu()[mask], want_recon[mask], tol)
+    assert total == int(mask.sum()) and [t_.shape[0] for t_ in toks] == lens.tolist()
+    if ldm.test_dtype != "bf16":
+        want_units = torch.cat([(want_logits[i, : int(lens[i])].argmax(-1) - 4) for i in range(3)])
+        assert (torch.cat(toks).cpu() == want_units).float().mean().item() > 0.99
+    a = ldm.ddpm_sample(feat.to(DEV), input_mask=mask.to(DEV), start_step=start, post_noise=post, start_noise=sn, seed=3)[3]
+    b = ldm.ddpm_sample(feat.to(DEV), input_mask=mask.to(DEV), start_step=start, post_noise=post, start_noise=sn, seed=3)[3]
+    c = ldm.ddpm_sample(feat.to(DEV), input_mask=mask.to(DEV), start_step=start, post_noise=post, start_noise=sn, seed=4)[3]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
 def test_reference_rng_draw_order(ldm, golden):
     """Without injected noise the mirror draws the posterior noise from the CPU generator as [B,z,T], like upstream."""
     g = golden("chain_small")

@@ -207,3 +207,18 @@ def test_vae_full_cfg1(golden):
     units = (logits.argmax(-1) - 4).numpy()
     safe = g["margin"][:n] > 1e-3  # argmax is only pinned where the reference's top-2 margin is clear
     assert (units[safe] == g["units"][:n][safe]).all()
+
+
+def test_oracle_ddpm_chain_matches_the_reference_steps(golden):
+    """O.ddpm_chain (the CPU restatement of what dn_ddpm_loop runs) against five real-reference p_sample steps over the real
+    reference eps-predictor (tests/golden/ddpm_chain.npz, oracle/gen_golden_ddpm.py): both fixed variances, clip on / off."""
+    g = golden("ddpm_chain")
+    sd = O.make_eps_state_dict(CHAIN_EPS, "chain")
+    lens = torch.from_numpy(g["lens"])
+    mask = O.lengths_to_mask(lens, 48)
+    for name, var, clip in (("small", "fixed_small", False), ("large", "fixed_large", False), ("small_clip", "fixed_small", True)):
+        with torch.no_grad():
+            got = O.ddpm_chain(sd, CHAIN_EPS, 200, torch.from_numpy(g[f"{name}_x_start"]), mask, 5, torch.from_numpy(g[f"{name}_noise"]), var, clip)
+        err = (got - torch.from_numpy(g[f"{name}_x_end"]))[mask].abs().max().item()
+        assert err < 5e-5, (name, err)
+
