@@ -74,7 +74,7 @@ class GaussianStep(C.Structure):
     _fields_ = [("x", C.c_void_p), ("model_out", C.c_void_p), ("noise", C.c_void_p), ("sample", C.c_void_p),
                 ("pred_xstart", C.c_void_p), ("t", C.c_void_p), ("table", C.c_void_p), ("N", C.c_int32),
                 ("inner", C.c_int32), ("learned_range", C.c_int32), ("clip_denoised", C.c_int32), ("sampler", C.c_int32),
-                ("eta", C.c_float)]
+                ("eta", C.c_float), ("predict_xstart", C.c_int32), ("cond_grad", C.c_void_p)]
 
 
 GD_COLS = 12
@@ -82,7 +82,7 @@ GD_COLS = 12
 
 class GaussianMoments(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "model_out", "x_start", "t", "table", "mean", "variance", "log_variance", "pred_xstart",
-                                          "vb", "reverse_sample")] + [(n, C.c_int32) for n in ("N", "inner", "learned_range", "clip_denoised")]
+                                          "vb", "reverse_sample")] + [(n, C.c_int32) for n in ("N", "inner", "learned_range", "clip_denoised", "predict_xstart")]
 
 
 class EpsConfig(C.Structure):

@@ -339,21 +339,28 @@ __global__ __launch_bounds__(256) void gaussian_step_kernel(const DnGaussianStep
     const float* tb = p.table + (int64_t)tn * DN_GD_COLS;
     const float xv = p.x[i];
     const float eps = p.model_out[(int64_t)n * p.inner * cmul + rem];
-    float x0 = __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));
+    float x0 = p.predict_xstart ? eps : __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));  // START_X: the output is x_0 (:317-318)
     if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-    float logvar = tb[4];
+    float logvar = tb[4], var = tb[11];
     if (p.learned_range) {
       const float v = p.model_out[(int64_t)n * p.inner * 2 + p.inner + rem];
       const float frac = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);
       logvar = __fadd_rn(__fmul_rn(frac, tb[6]), __fmul_rn(__fsub_rn(1.0f, frac), tb[5]));
+      var = expf(logvar);
     }
     const float nz = tn != 0 ? 1.0f : 0.0f;
     const float nv = p.noise ? p.noise[i] : 0.0f;
     float out;
     if (p.sampler == 0) {  // p_sample: mean + 1[t != 0] * exp(0.5 * log_variance) * noise
-      const float mean = __fadd_rn(__fmul_rn(tb[2], x0), __fmul_rn(tb[3], xv));
+      float mean = __fadd_rn(__fmul_rn(tb[2], x0), __fmul_rn(tb[3], xv));
+      if (p.cond_grad) mean = __fadd_rn(mean, __fmul_rn(var, p.cond_grad[i]));  // condition_mean (:346-358)
       out = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, expf(__fmul_rn(0.5f, logvar))), nv));
     } else {  // ddim_sample
+      if (p.cond_grad) {  // condition_score (:360-374): shift eps by the conditional score, re-derive the x_0 prediction (not re-clipped)
+        float ec = __fdiv_rn(__fsub_rn(__fmul_rn(tb[0], xv), x0), tb[1]);
+        ec = __fsub_rn(ec, __fmul_rn(sqrtf(__fsub_rn(1.0f, tb[7])), p.cond_grad[i]));
+        x0 = __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], ec));
+      }
       const float e2 = __fdiv_rn(__fsub_rn(__fmul_rn(tb[0], xv), x0), tb[1]);
       const float ab = tb[7], abp = tb[8];
       const float sigma = __fmul_rn(__fmul_rn(p.eta, sqrtf(__fdiv_rn(__fsub_rn(1.0f, abp), __fsub_rn(1.0f, ab)))),
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256) void gaussian_moments_kernel(const DnGaussianM
       continue;
     }
     const float eps = p.model_out[(int64_t)n * p.inner * cmul + rem];
-    float x0 = __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));
+    float x0 = p.predict_xstart ? eps : __fsub_rn(__fmul_rn(tb[0], xv), __fmul_rn(tb[1], eps));
     if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
     float logvar = tb[4], var = tb[11];
     if (p.learned_range) {

@@ -60,8 +60,14 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         return model if isinstance(model, _WrappedModel) else _WrappedModel(model, self.timestep_map, self.original_num_steps)
 
-    def _step(self, model, *args, **kwargs):
-        return super()._step(self._wrap_model(model), *args, **kwargs)
+    def _step(self, model, *args, cond_fn=None, **kwargs):  # the samplers: model and cond_fn both see the ORIGINAL step indices (:102-106)
+        return super()._step(self._wrap_model(model), *args, cond_fn=None if cond_fn is None else self._wrap_model(cond_fn), **kwargs)
+
+    def condition_mean(self, cond_fn, *args, **kwargs):
+        return super().condition_mean(self._wrap_model(cond_fn), *args, **kwargs)
+
+    def condition_score(self, cond_fn, *args, **kwargs):
+        return super().condition_score(self._wrap_model(cond_fn), *args, **kwargs)
 
     def _model_out(self, model, *args, **kwargs):  # p_mean_variance / ddim_reverse_sample / _vb_terms_bpd (reference :90-93)
         return super()._model_out(self._wrap_model(model), *args, **kwargs)

@@ -232,6 +232,10 @@ typedef struct {
   const float* table;
   int32_t N, inner, learned_range, clip_denoised, sampler;
   float eta;
+  int32_t predict_xstart;   /* ModelMeanType.START_X (:317-318): model_out IS the x_0 prediction (clamped when clip_denoised) */
+  const float* cond_grad;   /* optional fp32 [N, inner]: cond_fn(x, t), the gradient of a conditional log-probability -- sampler 0:
+                               condition_mean (:346-358) mean += variance * grad; sampler 1: condition_score (:360-374)
+                               eps -= sqrt(1 - abar) * grad, pred_xstart and the mean re-derived from it                        */
 } DnGaussianStep;
 int dn_gaussian_step(const DnGaussianStep* p, void* stream);
 
@@ -250,6 +254,7 @@ typedef struct {
   const int32_t* t; const float* table;
   float *mean, *variance, *log_variance, *pred_xstart, *vb, *reverse_sample;
   int32_t N, inner, learned_range, clip_denoised;
+  int32_t predict_xstart;   /* ModelMeanType.START_X: model_out is the x_0 prediction */
 } DnGaussianMoments;
 int dn_gaussian_moments(const DnGaussianMoments* p, void* stream);
 

@@ -194,6 +194,69 @@ def test_gaussian_diffusion_matches_reference_golden(golden):
     assert out.shape == (2, 4, 6) and torch.isfinite(out).all()
 
 
+def test_gaussian_diffusion_tail_matches_reference_golden(golden):
+    """What is left of GaussianDiffusion behind create_diffusion, against the REAL reference's outputs (tests/golden/
+    gaussian_tail.npz, oracle/gen_golden_gd_tail.py): the START_X mean type (predict_xstart=True) through p_sample / p_mean_variance /
+    training_losses, cond_fn guidance -- condition_mean in p_sample, condition_score in ddim_sample --, ddim_sample_loop with
+    eta > 0, _prior_bpd and calc_bpd_loop (100 steps), and a respaced chain whose model AND cond_fn must see the original step
+    indices.  The reference's recorded draws are injected."""
+    from diffnorm_amd.diffusion import create_diffusion
+
+    g = golden("gaussian_tail")
+    x = T_(g["x"]).to(DEV)
+    N, C, L = x.shape
+
+    def toy_model(learned):
+        def f(xx, t, **kw):
+            tt = t.float().view(-1, 1, 1)
+            base = torch.tanh(0.7 * xx + 0.01 * tt) - 0.1 * xx
+            return torch.cat([base, torch.sin(1.3 * xx + 0.02 * tt)], dim=1) if learned else base
+        return f
+
+    cond_fn = lambda xx, t, **kw: 0.3 * torch.cos(xx) - 0.001 * t.float().view(-1, 1, 1)
+    rel = lambda a, b, tol: close(torch.as_tensor(a).cpu().double() / max(np.abs(b).max(), 1e-6), b / max(np.abs(b).max(), 1e-6), tol)
+    t = torch.tensor([0, 37, 99], device=DEV)
+    for name, kw, learned in (("sx", dict(predict_xstart=True, learn_sigma=False), False),
+                              ("sx_lr", dict(predict_xstart=True, learn_sigma=True), True),
+                              ("eps", dict(learn_sigma=False, sigma_small=True), False)):
+        d = create_diffusion("", diffusion_steps=100, **kw)
+        model = toy_model(learned)
+        for clip in (False, True):
+            tag = f"{name}_clip{int(clip)}"
+            o = d.p_sample(model, x, t, clip_denoised=clip, noise=T_(g[f"{tag}_p_noise"]).to(DEV))
+            rel(o["sample"], g[f"{tag}_p_sample"], 1e-5)
+            rel(o["pred_xstart"], g[f"{tag}_p_x0"], 1e-5)
+            o = d.p_sample(model, x, t, clip_denoised=clip, cond_fn=cond_fn, model_kwargs={}, noise=T_(g[f"{tag}_pc_noise"]).to(DEV))
+            rel(o["sample"], g[f"{tag}_pc_sample"], 1e-5)
+            o = d.ddim_sample(model, x, t, clip_denoised=clip, cond_fn=cond_fn, model_kwargs={}, eta=0.5, noise=T_(g[f"{tag}_dc_noise"]).to(DEV))
+            rel(o["sample"], g[f"{tag}_dc_sample"], 2e-5)
+            rel(o["pred_xstart"], g[f"{tag}_dc_x0"], 2e-5)
+        pm = d.p_mean_variance(model, x, t, clip_denoised=True)
+        rel(pm["mean"], g[f"{name}_pmv_mean"], 1e-5)
+        rel(pm["log_variance"], g[f"{name}_pmv_logvar"], 1e-5)
+        tl = d.training_losses(lambda *a, **k: (model(*a, **k), None), x, t, noise=T_(g[f"{name}_tl_noise"]).to(DEV))
+        for k in ("loss", "mse", "vb"):
+            if f"{name}_tl_{k}" in g:
+                rel(tl[k], g[f"{name}_tl_{k}"], 3e-5)
+        rel(d._prior_bpd(x), g[f"{name}_prior_bpd"], 1e-5)
+        noises = T_(g[f"{name}_bpd_noises"])  # drawn for t = 99 .. 0
+        bp = d.calc_bpd_loop(model, x, clip_denoised=True, noises=[noises[99 - i] for i in range(100)])
+        for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
+            rel(bp[k], g[f"{name}_bpd_{k}"], 5e-4 if k == "mse" else 5e-5)  # (eps re-derived from x_0 divides by sqrt(1/abar - 1) -> tiny at t = 0)
+        # ddim_sample_loop with injected per-step noise: the loop is this class's own, the draws come from the fixture
+        dn = T_(g[f"{name}_dloop_noises"]).to(DEV)  # the recorder also caught the initial noise (draw 0); draws 1 .. 100 are the steps'
+        assert dn.shape[0] == 101 and torch.equal(dn[0].cpu(), seeded((N, C, L), 502))
+        img = dn[0]
+        for k, i in enumerate(range(99, -1, -1)):
+            img = d.ddim_sample(model, img, torch.tensor([i] * N, device=DEV), clip_denoised=True, eta=0.3, noise=dn[k + 1])["sample"]
+        rel(img, g[f"{name}_dloop_out"], 1e-4)
+    # the loop method itself (eta = 0: no draw matters) on the respaced diffusion with cond_fn
+    d = create_diffusion("5", diffusion_steps=100, learn_sigma=False)
+    y = d.ddim_sample_loop(toy_model(False), (N, C, L), noise=seeded((N, C, L), 503).to(DEV), clip_denoised=False, cond_fn=cond_fn, model_kwargs={},
+                           eta=0.0)
+    rel(y, g["resp_dloop_out"], 1e-4)
+
+
 def test_gaussian_moments_match_reference_golden(golden):
     """The rest of GaussianDiffusion on the GPU kernel dn_gaussian_moments against the reference's outputs
     (tests/golden/gaussian_moments.npz): q_posterior_mean_variance, p_mean_variance x 3 variance types x clip on/off,
