@@ -5,7 +5,8 @@ A file written here is a `torch.save`d dict with the trainer's keys -- "args", "
 "task_state", "extra_state", "last_optimizer_state" -- whose "model" entry holds the tensors under the reference's names and
 shapes (`encoder.*` for the VAE, 138 tensors; `encoder.model.*` + `encoder.speech_decoder.*` for the diffusion
 model, 516 tensors), whatever layout the HIP engines keep them in: the reference can `load_state_dict(strict=True)` it, and a
-checkpoint written by the reference loads here.
+checkpoint written by the reference loads here.  "args" is None and "cfg" the nested {model, task, criterion, common, ...}
+container, as the reference trainer writes them; the optimizer state is native-only (see save_checkpoint).
 """
 import os
 from typing import Any, Dict, Optional
@@ -17,11 +18,45 @@ def model_state(model) -> Dict[str, torch.Tensor]:
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
 
+_CFG_GROUPS = {  # which namespace attributes the reference's nested config keeps where (fairseq/dataclass/configs.py): enough for
+    # load_model_ensemble_and_task's `cfg.model` / `cfg.task` / `cfg.criterion` / `cfg.common` lookups (checkpoint_utils.py:423-470)
+    "task": ("task", "data", "config_yaml", "max_source_positions", "max_target_positions", "target_is_code", "target_code_size",
+             "n_frames_per_step", "src_feat_dir", "tgt_feat_dir"),
+    "criterion": ("criterion",),
+    "common": ("seed", "cpu", "fp16", "bf16", "amp", "user_dir"),
+    "optimizer": ("optimizer", "adam_betas", "adam_eps", "weight_decay"),
+    "lr_scheduler": ("lr_scheduler", "warmup_updates", "warmup_init_lr"),
+    "optimization": ("lr", "clip_norm", "max_update", "update_freq"),
+    "dataset": ("max_tokens", "batch_size", "train_subset", "valid_subset"),
+}
+
+
+def nested_cfg(args) -> Optional[Dict[str, Dict[str, Any]]]:
+    """The flat namespace as the nested container the reference trainer writes under "cfg" (trainer.state_dict, fairseq/trainer.py:
+    392-436: {model, task, criterion, common, ...}, a plain-dict rendering of its OmegaConf object); `model` carries every attribute
+    (the reference's `cfg.model` is the whole argparse namespace for registry-built models, `_name` = the arch)."""
+    if args is None:
+        return None
+    flat = dict(args) if isinstance(args, dict) else dict(vars(args))
+    cfg = {"model": dict(flat, _name=flat.get("arch"))}
+    for group, keys in _CFG_GROUPS.items():
+        cfg[group] = {k: flat[k] for k in keys if k in flat}
+        name = flat.get(group if group not in ("optimization", "dataset", "common") else "")
+        if name is not None:
+            cfg[group]["_name"] = name
+    return cfg
+
+
 def save_checkpoint(path: str, model, args=None, criterion=None, optimizer=None, lr_scheduler_state: Optional[dict] = None,
                     num_updates: int = 0, extra_state: Optional[dict] = None) -> Dict[str, Any]:
+    """The optimizer entry: the HIP-backed FlatOptimizer's moments are flat buffers in the PACKED layout -- resumable here, not by the
+    reference (whose Adam keeps per-parameter exp_avg / exp_avg_sq).  They are stored under "last_optimizer_state" with
+    "optimizer_name" = "FlatOptimizer" so that a reference-side `load_checkpoint(..., reset_optimizer=True)` -- or its own check
+    that the optimizer class matches (trainer.py:520-533) -- skips them instead of mis-reading them; the MODEL entry is what is
+    interchangeable both ways."""
     state = {
-        "args": args,  # legacy slot; fairseq >= 0.10 stores the config under "cfg"
-        "cfg": vars(args) if (args is not None and not isinstance(args, dict)) else args,
+        "args": None,  # as the reference trainer writes it (legacy slot; load_model_ensemble_and_task takes the "cfg" branch then)
+        "cfg": nested_cfg(args),
         "model": model_state(model),
         "criterion": None,
         "optimizer_history": [{

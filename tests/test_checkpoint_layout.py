@@ -31,7 +31,9 @@ def test_vae_checkpoint_round_trip_and_reference_keys(tmp_path):
     other = FairseqEncoderModel(_vae(seed=4))
     assert not torch.equal(other.state_dict()["encoder.decoder_lm.weight"], model.state_dict()["encoder.decoder_lm.weight"])
     loaded = checkpoint.load_checkpoint(path, other)
-    assert loaded["cfg"]["arch"] == "speech_vae_decoder"
+    # top-level entries as the reference trainer writes them: "args" None, "cfg" nested (checkpoint_utils.py:423-426 takes the cfg branch)
+    assert loaded["args"] is None and loaded["cfg"]["model"]["arch"] == "speech_vae_decoder" and loaded["cfg"]["model"]["_name"] == "speech_vae_decoder"
+    assert {"model", "task", "criterion", "common"} <= set(loaded["cfg"])
     for k, v in model.state_dict().items():
         assert torch.equal(other.state_dict()[k], v), k
     # shapes are the reference's: conv [Cout, Cin, k], linear [out, in]
