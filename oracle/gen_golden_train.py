@@ -13,7 +13,11 @@ The reference's attention dropout (p = 0.1, latent_module.py:338,668; the only t
 re-drawable from outside, so the fixtures are taken with the modules in eval() -- gradients flow identically, dropout is the
 identity.  Random tensors the reference draws (posterior noise, t, jitter, target noise) are recorded and stored.
 
-Usage:  python oracle/gen_golden_train.py   ->  tests/golden/{vae_train,eps_train}.npz
+  vae_train_full.npz / eps_train_full.npz (--full): the same losses and gradients on the RECIPE-sized models (dim 768 / d_h 96 /
+                  inner 2048; dim 512 / depth 12 / inner 1365 padded to 1408 / the 57 k-wide conditioning projection) at B = 2, T = 64:
+                  checksums + strided samples only.
+
+Usage:  python oracle/gen_golden_train.py [--full]   ->  tests/golden/{vae_train,eps_train}[_full].npz
 """
 import os
 import sys
@@ -40,18 +44,20 @@ def probe_vector(n: int) -> torch.Tensor:
     return (((i * 2654435761 + 12345) >> 7) & 1).to(torch.float64) * 2 - 1
 
 
-def grad_record(prefix, named_grads, out):
+def grad_record(prefix, named_grads, out, small=SMALL, samples=SAMPLES):
     """Per tensor: [sum, l2 norm, dot with probe_vector] in float64, plus the tensor itself (small) or a strided sample."""
     names = []
     for name, g in named_grads:
         g64 = g.detach().double().flatten()
         n = g64.numel()
         out[f"{prefix}chk/{name}"] = np.array([g64.sum().item(), g64.norm().item(), (g64 * probe_vector(n)).sum().item()])
-        if n <= SMALL:
+        if n <= small:
             out[f"{prefix}full/{name}"] = g.detach().float().numpy()
         else:
-            stride = (n + SAMPLES - 1) // SAMPLES
-            out[f"{prefix}samp/{name}"] = g.detach().float().flatten()[::stride].numpy()
+            stride = (n + samples - 1) // samples
+            samp = g.detach().float().flatten()[::stride]
+            assert (n + samp.numel() - 1) // samp.numel() == stride, (name, n, stride)  # train_oracle.compare_grads re-derives the stride
+            out[f"{prefix}samp/{name}"] = samp.numpy()
         names.append(name)
     out[prefix + "names"] = np.array(names)
     total = torch.sqrt(sum(g.detach().double().pow(2).sum() for _, g in named_grads))
@@ -156,9 +162,71 @@ def gen_eps_train(lm):
     save("eps_train", **out)
 
 
+def full_batch(dim):
+    """B = 2, T = 64 at the recipe's sizes: one full-length and one ragged utterance."""
+    B, T = 2, 64
+    feat = seeded((B, T, dim), 41)
+    lens = torch.tensor([64, 41])
+    mask = O.lengths_to_mask(lens, T)
+    g = torch.Generator().manual_seed(42)
+    units = torch.randint(4, 1004, (B, T), generator=g).masked_fill(~mask, 0)
+    return feat, lens, mask, units
+
+
+def gen_vae_train_full(lm):
+    """The recipe-sized VAE (dim 768, d_h 96, inner 2048, 138.6 M parameters): loss terms and the gradient of every parameter
+    (checksums + 256 strided samples each; whole tensors up to 2048 elements)."""
+    from gen_golden_configs import FULL_VAE
+
+    vsd = O.make_vae_state_dict(FULL_VAE, "full")
+    vae = ref_vae(lm, FULL_VAE, vsd)
+    feat, lens, mask, units = full_batch(FULL_VAE.dim)
+    out = dict(lens=lens, units=units)
+    torch.manual_seed(502)
+    with record_draws() as rec:
+        loss, parts, logits = vae_criterion_loss(lm, vae, feat, units, mask, lens)
+    out["post_noise"] = rec.draws[0].transpose(1, 2).contiguous()
+    loss.backward()
+    out["loss"] = loss.detach()
+    out.update({k: v.detach() for k, v in parts.items()})
+    out["logits_head"] = logits.detach()[:, :4, :64]
+    grad_record("g/", [(n, p.grad) for n, p in vae.named_parameters()], out, small=2048, samples=256)
+    save("vae_train_full", **out)
+
+
+def gen_eps_train_full(lm):
+    """The recipe-sized eps-predictor (dim 512, depth 12, inner 1365 -> 1408, 57 k-wide conditioning projection, 260.6 M parameters)
+    through the frozen recipe-sized VAE: the loss dict and the gradient of every eps-predictor parameter, same storage."""
+    from gen_golden_configs import FULL_EPS, FULL_VAE
+
+    esd, vsd = O.make_eps_state_dict(FULL_EPS, "full"), O.make_vae_state_dict(FULL_VAE, "full")
+    vae = ref_vae(lm, FULL_VAE, vsd)
+    for p in vae.parameters():
+        p.requires_grad = False
+    ldm = lm.LatentDiscreteModel(types.SimpleNamespace(encoder=vae), FULL_EPS.dim, FULL_VAE.z, timesteps=200, multitask=True)
+    ldm.model.load_state_dict(dict(esd, **{"pos_embed._float_tensor": torch.zeros(1)}), strict=True)
+    ldm.eval()
+    feat, lens, mask, units = full_batch(FULL_VAE.dim)
+    out = dict(lens=lens, units=units)
+    torch.manual_seed(778)
+    with record_draws() as rec:
+        ld = ldm(feat, units, tgt_mask=mask)
+    assert len(rec.draws) == 4, len(rec.draws)
+    out.update(times=rec.draws[0], post_noise=rec.draws[1].transpose(1, 2).contiguous(), jitter=rec.draws[2].contiguous(),
+               true_noise=rec.draws[3].contiguous(), **{"loss_" + k: v.detach() for k, v in ld.items()})
+    ld["total_loss"].backward()
+    grad_record("g/", [(n, p.grad) for n, p in ldm.model.named_parameters() if p.grad is not None], out, small=2048, samples=256)
+    out["no_grad_names"] = np.array([n for n, p in ldm.model.named_parameters() if p.grad is None])
+    save("eps_train_full", **out)
+
+
 def main():
     torch.set_grad_enabled(True)
     lm, _ = ref_loader.load_reference()
+    if "--full" in sys.argv:  # recipe-sized models: a few minutes of CPU
+        gen_vae_train_full(lm)
+        gen_eps_train_full(lm)
+        return
     gen_vae_train(lm)
     gen_eps_train(lm)
 

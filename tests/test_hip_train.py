@@ -535,3 +535,94 @@ def test_plugin_diffusion_train_step_matches_reference(golden):
     mask = O.lengths_to_mask(lens, 48).to(DEV)
     toks, _, total, _ = model.encoder.ddim_sample(feat.to(DEV), input_mask=mask, ref_units=(units - 4).to(DEV), start_step=3)
     assert total == int(lens.sum()) and [t.shape[0] for t in toks] == lens.tolist()
+
+
+def _cosine(got, want_samples, golden, prefix="g/"):
+    """Cosine / norm ratio of a gradient against the fixture's strided samples (the fixture keeps samples, not whole tensors)."""
+    dot = n1 = n2 = 0.0
+    for name in [str(n) for n in golden[prefix + "names"]]:
+        g = got[name].detach().double().cpu().flatten()
+        key = f"{prefix}full/{name}" if f"{prefix}full/{name}" in golden else f"{prefix}samp/{name}"
+        ref = torch.from_numpy(golden[key]).double().flatten()
+        if key.startswith(prefix + "samp/"):
+            g = g[:: (g.numel() + ref.numel() - 1) // ref.numel()]
+        dot += float((g * ref).sum())
+        n1 += float(g.pow(2).sum())
+        n2 += float(ref.pow(2).sum())
+    return dot / (n1 * n2) ** 0.5, (n1 / n2) ** 0.5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fullsize_vae_training_step_matches_reference(golden, dtype):
+    """The RECIPE-sized VAE (dim 768, 8 x 96 heads, FFN inner 2048, 138.6 M parameters) at B = 2, T = 64: loss terms and the
+    gradient of every parameter against the real reference's autograd (tests/golden/vae_train_full.npz: checksums + strided
+    samples) -- the d_h = 96 attention backward, the 2048-wide GEGLU / causal-conv gradients and the 1004-way head at the sizes
+    the recipe trains.  f32: every tensor within 1e-3; bf16: cosine / norm of the whole gradient."""
+    from diffnorm_amd import training
+    from gen_golden_configs import FULL_VAE
+
+    g = golden("vae_train_full")
+    sd = O.make_vae_state_dict(FULL_VAE, "full")
+    eng = training.VaeTrainEngine(sd, dtype=dtype, device=DEV)
+    del sd
+    feat = seeded((2, 64, FULL_VAE.dim), 41)
+    units, lens = torch.from_numpy(g["units"]), torch.from_numpy(g["lens"])
+    stats, logits, _ = eng.forward(feat, units, lens, noise=torch.from_numpy(g["post_noise"]), ntokens=int(lens.sum()), want_logits=True)
+    eng.zero_grad()
+    eng.backward()
+    s = stats.cpu().double().numpy()
+    tol = 2e-4 if dtype == "f32" else 3e-2
+    for i, k in enumerate(("loss", "nll_loss", "mse_loss", "kl_loss")):
+        assert abs(s[i] - float(g[k])) <= tol * max(1.0, abs(float(g[k]))), (k, s[i], float(g[k]))
+    grads = eng.grad_dict()
+    if dtype == "f32":
+        assert np.abs(logits.cpu().numpy()[:, :4, :64] - g["logits_head"]).max() < 1e-3
+        worst = TO.compare_grads(grads, g, "g/", rtol=1e-3)
+        print("full-size VAE: worst relative gradient error vs the reference:", worst)
+    else:
+        cos, ratio = _cosine(grads, None, g)
+        print(f"full-size VAE bf16 gradient: cosine {cos:.5f}, norm ratio {ratio:.4f}")
+        assert cos > 0.995 and abs(ratio - 1) < 5e-2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fullsize_diffusion_training_step_matches_reference(golden, dtype):
+    """The RECIPE-sized eps-predictor (dim 512, depth 12, FFN inner 1365 padded to 1408, the 57 k-wide conditioning projection,
+    260.6 M trained parameters) through the frozen recipe-sized VAE at B = 2, T = 64: LatentDiscreteModel.forward's loss dict and
+    the gradient of every eps-predictor parameter against the real reference (tests/golden/eps_train_full.npz)."""
+    from diffnorm_amd import training
+    from gen_golden_configs import FULL_EPS, FULL_VAE
+
+    g = golden("eps_train_full")
+    vsd, esd = O.make_vae_state_dict(FULL_VAE, "full"), O.make_eps_state_dict(FULL_EPS, "full")
+    vae = training.VaeTrainEngine(vsd, dtype=dtype, device=DEV)
+    eps = training.EpsTrainEngine(esd, FULL_EPS, vae, timesteps=200, dtype=dtype, device=DEV)
+    feat = seeded((2, 64, FULL_VAE.dim), 41)
+    units, lens = torch.from_numpy(g["units"]), torch.from_numpy(g["lens"])
+    T = lambda k: torch.from_numpy(g[k])
+    # the frozen encoder's posterior sample: exact-fp32 inference engine in both modes (its parity: tests/test_hip_engine.py), so the
+    # training engine under test sees the reference's z
+    from diffnorm_amd import engine
+
+    ve = engine.VaeEngine(vsd, dtype="f32", device=DEV)
+    z = ve.sample_posterior(ve.encode_params(feat.to(DEV)), T("post_noise"))
+    del ve, vsd, esd
+    stats = eps.forward(feat, units, lens, z, T("times"), T("jitter"), T("true_noise"))
+    vae.zero_grad()
+    eps.zero_grad()
+    eps.backward()
+    s = stats.cpu().double().numpy()
+    tol = 2e-4 if dtype == "f32" else 3e-2
+    for i, k in enumerate(("total_loss", "nll_loss", "recon_mse_loss", "noise_loss")):
+        ref = float(g["loss_" + k])
+        assert abs(s[i] - ref) <= tol * max(1.0, abs(ref)), (k, s[i], ref)
+    assert float(vae.grads.abs().max()) == 0.0  # frozen
+    grads = eps.grad_dict()
+    if dtype == "f32":
+        worst = TO.compare_grads(grads, g, "g/", rtol=1e-3)
+        print("full-size diffusion training: worst relative gradient error vs the reference:", worst)
+    else:
+        cos, ratio = _cosine(grads, None, g)
+        print(f"full-size diffusion bf16 gradient: cosine {cos:.5f}, norm ratio {ratio:.4f}")
+        assert cos > 0.99 and abs(ratio - 1) < 8e-2
+
