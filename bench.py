@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-full-chain", action="store_true", help="skip the end-to-end 998-evaluation chain leg")
     ap.add_argument("--no-x3", action="store_true", help="skip the split-operand (bf16x3) leg")
     ap.add_argument("--no-train", action="store_true", help="skip the two training legs of the default line")
+    ap.add_argument("--no-refine", action="store_true", help="skip the mask-predict refinement leg (SURVEY 8 f4)")
     ap.add_argument("--train-loss", default="vae", choices=["vae", "diffusion"], help="--mode train: which loss's update is the step")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 legs (20 steps + the full chain for the unit agreement)")
     return ap.parse_args()
@@ -318,6 +319,48 @@ def x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths):
                                     "avg_launch_ms": avg_ms.value, "launches_timed": n_l.value, "traffic": None}}}
 
 
+def refine_leg(args, dev, stream):
+    """The loop downstream of the normalised units: mask-predict iterative refinement of the NAR S2UT decoder
+    (research/TranSpeech/nar_transformer.py: embed 512, FFN 2048, 6 layers, 8 heads, 1004 units) on the HIP engine -- B = 32
+    hypotheses of T = 256 target frames against S = 128 encoder frames, 10 refinement iterations (one decoder pass + the CMLM update
+    each; the encoder-attention keys / values of all layers computed once per batch), random-init weights, the encoder output a
+    given tensor."""
+    import torch
+
+    from diffnorm_amd import nar_decoder, synthetic
+    from diffnorm_amd.iterative_refinement import DecoderOut
+
+    B, T, S, iters = 32, 256, 128, 10
+    sd = synthetic.random_nar_decoder_state_dict(seed=3)
+    model = nar_decoder.NARS2UTDecoderModel(sd, dtype=args.dtype if args.dtype != "bf16x3" else "bf16x3", device=dev)
+    g = torch.Generator().manual_seed(5)
+    enc = {"encoder_out": [torch.randn(S, B, 512, generator=g).to(dev)], "encoder_padding_mask": [], "encoder_embedding": [], "encoder_states": [],
+           "src_tokens": [], "src_lengths": []}
+    lengths = torch.full((B,), T, dtype=torch.long, device=dev)
+
+    def chain():
+        state = model.initialize_output_tokens(enc, None, true_length=lengths)
+        for step in range(iters):
+            state = model.forward_decoder(state._replace(step=step, max_step=iters), enc)
+        return state
+
+    with torch.cuda.stream(stream):
+        chain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            st = chain()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    assert int(st.output_tokens.ne(3).sum()) == B * T  # every position decided after the last iteration
+    flops = B * T * 2.0 * 6 * (4 * 512 * 512 + 2 * 512 * 512 + 2 * 512 * 2048 + 2 * 512 * (T + S)) + B * T * 2.0 * 512 * 1004
+    return {"refine": {"iterations_per_s": iters / dt, "ms_per_iteration": dt / iters * 1e3, "hypothesis_frames_per_s": B * T * iters / dt,
+                       "dtype": args.dtype, "tflops": flops * iters / dt / 1e12,
+                       "what": f"NAR S2UT decoder (512 / 2048 / 6 layers / 8 heads / 1004 units) inside mask-predict refinement: B = {B}, T = {T}, "
+                               f"S = {S} encoder frames, {iters} iterations (decoder pass + dn_cmlm_step each), host-stepped like the reference's generator"}}
+
+
 # Which arithmetic mode meets which of north_star's budgets ("1e-3 fp32 / 1e-2 bf16", max-abs vs the reference's fp32 outputs),
 # as measured by the -m gpu tests on the reference-generated goldens (tests/test_hip_engine.py; BASELINE config 2 = eps_full_cfg2).
 TOLERANCE = {
@@ -444,6 +487,8 @@ def run_sampling(args, ctx):
             result.update(x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths))
         if world == 1 and not args.no_full_chain:
             result.update(full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched))
+        if world == 1 and not args.no_refine:
+            result.update(refine_leg(args, dev, stream))
         if world == 1 and not args.no_train:
             del eng
             import gc

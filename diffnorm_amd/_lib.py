@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffnorm_hip.so")
 
 DN_F32, DN_BF16, DN_BF16X3 = 0, 1, 2
-EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB = range(6)
+EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB, EPI_RELU = range(7)
 DN_MAX_TERMS = 8
 TAG_FFN_CONV, TAG_WN_DILATED, TAG_FFN_CONV_WGRAD = 1, 2, 3
 
@@ -93,6 +93,10 @@ class EpsConfig(C.Structure):
 class VaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "z", "depth", "heads", "dim_head", "stacks", "layers",
                                          "vocab", "n_mults")] + [("mults", C.c_int32 * 4), ("dtype", C.c_int32)]
+
+
+class NarConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "ffn", "layers", "heads", "vocab", "max_pos", "pad", "dtype")]
 
 
 class VaeTrainBatch(C.Structure):
@@ -192,6 +196,13 @@ SYMBOLS = {
     "dn_ddim_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "dn_ddim_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
     "dn_ddpm_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, C.c_uint64, _vp, _i32, _vp, _sz, _vp]),
+    "dn_nar_create": (C.c_int, [C.POINTER(NarConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
+    "dn_nar_destroy": (None, [_vp]),
+    "dn_nar_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "dn_nar_cross_kv_bytes": (_sz, [_vp, _i32, _i32]),
+    "dn_nar_cross_kv": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_nar_predict_lengths": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_nar_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_last_error": (C.c_char_p, []),
     "dn_version": (C.c_int, []),
 }

@@ -411,29 +411,26 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
   const float* kp_t = kp + (int64_t)ld_r0 * p.ldk + ld_ch * 4;  // per-thread bases; the tile / chunk row offsets are uniform
   const float* vp_t = vp + (int64_t)ld_r0 * p.ldv + ld_ch * 4;
   const int wr_h = lds_off<L>(ld_r0, ld_ch * 8), wr_l = lds_off<L>(ld_r0, LO + ld_ch * 8);
-  float4 kreg[NPT], vreg[NPT];
-  auto issue_loads = [&](int kv0) {
+  // ONE staging register set serves both tensors of the next tile: its K rows are requested at the top of a tile and written
+  // to the other LDS buffer (free for the whole tile) behind the S^T products, its V rows are requested then and written at the
+  // end -- half the staging registers, which is what lets two workgroups share a CU without spills.
+  float4 sreg[NPT];
+  auto issue_loads = [&](const float* base, int ld, int kv0) {
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int key = kv0 + i * RSTEP;  // + ld_r0
-      kreg[i] = vreg[i] = make_float4(0, 0, 0, 0);
-      if (ld_col && key + ld_r0 < Tk) {
-        kreg[i] = *reinterpret_cast<const float4*>(kp_t + (int64_t)key * p.ldk);
-        vreg[i] = *reinterpret_cast<const float4*>(vp_t + (int64_t)key * p.ldv);
-      }
+      sreg[i] = make_float4(0, 0, 0, 0);
+      if (ld_col && key + ld_r0 < Tk) sreg[i] = *reinterpret_cast<const float4*>(base + (int64_t)key * ld);
     }
   };
-  auto write_tile = [&](int buf) {
+  auto write_tile = [&](char* lds, int buf) {
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int o = buf * TILE_LDS + i * RSTEP * ROWB;
       uint2 hi, lo;
-      split4(kreg[i], hi, lo);
-      *reinterpret_cast<uint2*>(k_lds + wr_h + o) = hi;
-      *reinterpret_cast<uint2*>(k_lds + wr_l + o) = lo;
-      split4(vreg[i], hi, lo);
-      *reinterpret_cast<uint2*>(v_lds + wr_h + o) = hi;
-      *reinterpret_cast<uint2*>(v_lds + wr_l + o) = lo;
+      split4(sreg[i], hi, lo);
+      *reinterpret_cast<uint2*>(lds + wr_h + o) = hi;
+      *reinterpret_cast<uint2*>(lds + wr_l + o) = lo;
     }
   };
   int k_base_h[KS_D], k_base_l[KS_D], v_base_h[DT], v_base_l[DT];
@@ -449,8 +446,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
   }
   using SET0 = std::integral_constant<int, 0>;
   using SET1 = std::integral_constant<int, 1>;
-  issue_loads(0);
-  write_tile(0);
+  issue_loads(kp_t, p.ldk, 0);
+  write_tile(k_lds, 0);
+  issue_loads(vp_t, p.ldv, 0);
+  write_tile(v_lds, 0);
   __syncthreads();
   auto tr_read = [&](const char* base) -> uint2 {
     const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
   auto key_tile = [&](auto cur_c, int kv0) {
     constexpr int buf = decltype(cur_c)::value;
     const bool more = kv0 + KV_TILE < len;
-    if (more) issue_loads(kv0 + KV_TILE);  // lands under this tile's products; written to the other buffer at the end
+    if (more) issue_loads(kp_t, p.ldk, kv0 + KV_TILE);  // the next tile's K rows land under this tile's S^T products
     const char* kt_lds = k_lds + buf * TILE_LDS;
     const char* vt_lds = v_lds + buf * TILE_LDS;
 
@@ -480,6 +479,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
         mma_kstep<BF16>(acc_s[kt][0], kh, qh[0][ks]);
         mma_kstep<BF16>(acc_s[kt][1], kh, qh[1][ks]);
       }
+    }
+    if (more) {  // K rows to the other buffer (last read one barrier ago); the same registers then fetch the V rows
+      write_tile(k_lds, 1 - buf);
+      issue_loads(vp_t, p.ldv, kv0 + KV_TILE);
     }
     // ---- online softmax in fp32 (log2 domain), as the other kernels
     auto softmax_tile = [&](auto masked_tag) {
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
         mma_kstep<BF16>(acc_o[dt][1], vh, ph[1]);
       }
     }
-    if (more) write_tile(1 - buf);
+    if (more) write_tile(v_lds, 1 - buf);
     __syncthreads();
   };
   for (int kv0 = 0; kv0 < len; kv0 += 2 * KV_TILE) {

@@ -70,10 +70,10 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
                  "dn_conv_gemm: term %d layout=%d (K-blocked operands are bf16 only)", i, p.terms[i].layout);
   if (p.out_layout)
     DN_CHECK_ARG(p.out_layout == DN_LAYOUT_OUT_KBLOCKED && p.out_dtype == DN_BF16 && p.N % 32 == 0 && !p.norm_out &&
-                     (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU || p.epilogue == DN_EPI_FILM_GATE),
+                     (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_RELU || p.epilogue == DN_EPI_GEGLU || p.epilogue == DN_EPI_FILM_GATE),
                  "dn_conv_gemm: K-blocked output needs a BIAS, SILU, GEGLU or FILM_GATE epilogue, a bf16 destination and N a multiple of 32");
   if (p.row_ssq) {
-    DN_CHECK_ARG(p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_GEGLU,
+    DN_CHECK_ARG(p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_SILU || p.epilogue == DN_EPI_RELU || p.epilogue == DN_EPI_GEGLU,
                  "dn_conv_gemm: row_ssq (split norm) needs a BIAS, SILU or GEGLU epilogue");
     DN_CHECK_ARG(p.row_ssq_parts >= 1 && p.row_ssq_ld >= p.row_ssq_parts && p.row_D > 0.f, "dn_conv_gemm: bad row_ssq_parts / row_ssq_ld / row_D");
     DN_CHECK_ARG(p.row_bias_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p.row_bias) & 15) == 0, "dn_conv_gemm: row_bias must be 16-byte aligned, stride a multiple of 4");

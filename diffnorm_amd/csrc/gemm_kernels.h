@@ -327,7 +327,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         v[i] += bv[i];
-        if constexpr (EPI == DN_EPI_SILU) v[i] = silu(v[i]);
+        if constexpr (EPI == DN_EPI_SILU) v[i] = (p.pad_ & 64) ? fmaxf(v[i], 0.f) : silu(v[i]);  // pad_ bit 6: DN_EPI_RELU rides on this epilogue
       }
       store8_bf16(out, out_off(p, m, n), v);
     }
@@ -483,7 +483,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         }
         float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
         if constexpr (EPI == DN_EPI_SILU) {
-          v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+          if (p.pad_ & 64) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }  // DN_EPI_RELU
+          else { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
         } else if constexpr (EPI == DN_EPI_FILM_GATE) {
           if (gbb) {
             v0 = v0 * ga[i].x + be[i].x; v1 = v1 * ga[i].y + be[i].y; v2 = v2 * ga[i].z + be[i].z; v3 = v3 * ga[i].w + be[i].w;
@@ -1787,7 +1788,7 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
 // with it the last bits, relative to the 128-byte-K-tile variants (term-outer): a batch large enough to route to these tiles and
 // a smaller one do not agree to the last bit; equal-size shards do.  DN_TAPS_INNER=0 (or DN_FAT_TAPS_INNER=0, the older name)
 // or bit 23 of pad_ restores term-outer everywhere (bit 22 forces tap-inner).
-static bool terms_are_taps(const DnGemmParams& p) {
+static inline bool terms_are_taps(const DnGemmParams& p) {
   const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
   if (!e) e = getenv("DN_FAT_TAPS_INNER");
   const bool env_taps = !(e && atoi(e) == 0);
@@ -1881,7 +1882,7 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
 }
 
 // Tile variant forced for this call: DN_GEMM_TILE (process-wide) or bits 16..19 of pad_ (per call; tests); 0 = choose by shape.
-static int forced_tile(const DnGemmParams& p) {
+static inline int forced_tile(const DnGemmParams& p) {
   static const int env_tile = getenv("DN_GEMM_TILE") ? atoi(getenv("DN_GEMM_TILE")) : 0;
   return ((p.pad_ >> 16) & 15) ? ((p.pad_ >> 16) & 15) : env_tile;
 }
@@ -1891,7 +1892,7 @@ static int forced_tile(const DnGemmParams& p) {
 // batches, +5 % on whole ones, against the 256 x 256 tile on the FFN conv).  Chosen by itself only for the long-K BIAS
 // contractions; on the GEGLU projection (K = 512: 16 K-tiles) it measured level with the 256 x 256 tile (67.6 vs 66.1
 // us), so there it runs only when forced.
-static bool routes_to_352(const DnGemmParams& p) {
+static inline bool routes_to_352(const DnGemmParams& p) {
   if (p.dtype != DN_BF16 || (p.epilogue != DN_EPI_BIAS && p.epilogue != DN_EPI_GEGLU)) return false;
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split) return false;
   const int force = forced_tile(p);
@@ -1902,7 +1903,7 @@ static bool routes_to_352(const DnGemmParams& p) {
 
 // The tile variant a contraction runs on: 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256, 4 = 256 x 352, 5 = whole-row (fused norm),
 // 6 / 7 = the forced-only hand-scheduled 256 x 256 forms; -1 = K-blocked operands with a tile forced that does not take them.
-static int choose_tile(const DnGemmParams& p) {
+static inline int choose_tile(const DnGemmParams& p) {
   const bool bf = p.dtype == DN_BF16;
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split && p.dtype != DN_BF16X3) return 5;
   const int force = forced_tile(p);
@@ -1968,7 +1969,7 @@ static int choose_tile(const DnGemmParams& p) {
 // block that balances activation-panel bytes against weight-panel bytes, band = sqrt(concurrency x weight panel / row panel).
 // (The VAE's FFN conv -- 25 MB of weights on 128 x 128 tiles -- re-streamed its weights once per four row tiles: 1.1 GB of fabric
 // traffic per launch at 5.3 TB/s.)  DN_GEMM_BAND forces a value for every launch (0 / 1 = column tiles fastest).
-static int choose_band(const DnGemmParams& p, int tile) {
+static inline int choose_band(const DnGemmParams& p, int tile) {
   static const int env_band = getenv("DN_GEMM_BAND") ? atoi(getenv("DN_GEMM_BAND")) : -1;
   if (env_band >= 0) return env_band < 255 ? env_band : 255;
   const int es = p.dtype == DN_BF16 ? 2 : 4;
@@ -2024,6 +2025,12 @@ static int dispatch_epi(const DnGemmParams& p, hipStream_t s) {
   switch (p.epilogue) {
     case DN_EPI_BIAS: return launch<E, DN_EPI_BIAS>(p, s);
     case DN_EPI_SILU: return launch<E, DN_EPI_SILU>(p, s);
+    case DN_EPI_RELU: {  // the SILU kernels with the activation switched by pad_ bit 6 (no further instantiations)
+      DnGemmParams q = p;
+      q.epilogue = DN_EPI_SILU;
+      q.pad_ |= 64;
+      return launch<E, DN_EPI_SILU>(q, s);
+    }
     case DN_EPI_GEGLU: return launch<E, DN_EPI_GEGLU>(p, s);
     case DN_EPI_FILM_GATE: return launch<E, DN_EPI_FILM_GATE>(p, s);
     case DN_EPI_RESADD: return launch<E, DN_EPI_RESADD>(p, s);

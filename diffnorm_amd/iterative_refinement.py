@@ -2,11 +2,12 @@
 of the reference's `IterativeRefinementGenerator` (fairseq/iterative_refinement_generator.py:18-330) and the per-iteration CMLM
 update of its non-autoregressive model (fairseq/models/nat/cmlm_transformer.py:19-134) as one HIP kernel (`dn_cmlm_step`).
 
-Scope: the generator (same constructor arguments, `generate(models, sample)` contract, hypothesis dicts) and the mask-predict
-update.  The NAT translation model itself (conformer encoder + CMLM decoder, fairseq/tasks/nat_s2s_task.py) is NOT part of this
-repo: any model exposing `forward_encoder / initialize_output_tokens / forward_decoder / encoder.reorder_encoder_out`
-(+ `regenerate_length_beam`, `allow_length_beam` for a length beam) plugs in; `cmlm_update` is what such a model's
-`forward_decoder` calls after its decoder has produced logits.
+Scope: the generator (same constructor arguments, `generate(models, sample)` contract, hypothesis dicts; `speech_source=True` =
+the research/TranSpeech variant the S2UT task builds) and the mask-predict update.  The model inside the loop is
+`diffnorm_amd.nar_decoder.NARS2UTDecoderModel` (the decoder side of the reference's NARS2UTTransformerModel on the HIP engine; the
+speech encoder's output is a given tensor); any other model exposing `forward_encoder / initialize_output_tokens / forward_decoder /
+encoder.reorder_encoder_out` (+ `regenerate_length_beam`, `allow_length_beam` for a length beam) plugs in; `cmlm_update` is what
+such a model's `forward_decoder` calls after its decoder has produced logits.
 """
 from collections import namedtuple
 from typing import List, Optional
@@ -33,7 +34,11 @@ class IterativeRefinementGenerator:
     re-ordered to the survivors); with `beam_size` > 1 the length beam's best-scoring candidate is kept (optionally re-ranked)."""
 
     def __init__(self, tgt_dict, models=None, eos_penalty=0.0, max_iter=10, max_ratio=2, beam_size=1, decoding_format=None,
-                 retain_dropout=False, adaptive=True, retain_history=False, reranking=False, use_true_length=False):
+                 retain_dropout=False, adaptive=True, retain_history=False, reranking=False, use_true_length=False, speech_source=False):
+        """speech_source=True: the variant DiffNorm's S2UT task builds (research/TranSpeech/iterative_refinement_generator.py:131-160, task
+        speech_to_speech_fasttranslate, fairseq/tasks/nat_s2s_task.py:170-190): the source is a [B, T, 80] feature tensor and the
+        model's `initialize_output_tokens(encoder_out, src_lengths)` takes the source LENGTHS (no true-length option)."""
+        self.speech_source = speech_source
         self.bos, self.pad, self.unk, self.eos = tgt_dict.bos(), tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
         self.vocab_size = len(tgt_dict)
         self.eos_penalty, self.max_iter, self.max_ratio, self.beam_size = eos_penalty, max_iter, max_ratio, beam_size
@@ -101,7 +106,11 @@ class IterativeRefinementGenerator:
             target_length = sample["target"].ne(self.pad).sum(dim=1)
 
         encoder_out = model.forward_encoder([src_tokens, src_lengths])
-        state = model.initialize_output_tokens(encoder_out, src_tokens, target_length)
+        if self.speech_source:
+            assert not self.use_true_length, "the speech-source generator has no true-length option"
+            state = model.initialize_output_tokens(encoder_out, src_lengths)
+        else:
+            state = model.initialize_output_tokens(encoder_out, src_tokens, target_length)
         if self.beam_size > 1:
             assert model.allow_length_beam, "{} does not support decoding with length beam.".format(model.__class__.__name__)
             order = torch.arange(bsz, device=src_tokens.device).repeat_interleave(self.beam_size)

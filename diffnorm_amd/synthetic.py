@@ -133,3 +133,24 @@ def random_vae_state_dict(dim=768, latent_dim=128, depth=6, heads=8, dim_head=96
 def eps_step_flops(B: int, T: int) -> float:
     """Algorithmic FLOPs of one denoising step of the recipe-size eps-predictor (MAC = 2 FLOP)."""
     return B * T * (283_824_136 + 24_576 * T) + B * 236_982_272
+
+
+def random_nar_decoder_state_dict(dim=512, ffn=2048, layers=6, vocab=1004, pad=1, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the NAR S2UT decoder under the reference's parameter names (`decoder.*` of NARS2UTTransformerModel's
+    state dict, research/TranSpeech/nar_transformer.py:84-122 on fairseq's TransformerDecoder): nar_s2ut_transformer's sizes by default."""
+    g = torch.Generator().manual_seed(seed)
+    n = lambda *shape, scale=1.0: torch.randn(*shape, generator=g) * scale
+    sd = {"embed_tokens.weight": n(vocab, dim, scale=dim ** -0.5), "embed_length.weight": n(256, dim, scale=dim ** -0.5)}
+    sd["embed_tokens.weight"][pad] = 0
+    for l in range(layers):
+        p = f"layers.{l}."
+        for att in ("self_attn", "encoder_attn"):
+            for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                sd[p + f"{att}.{proj}.weight"], sd[p + f"{att}.{proj}.bias"] = n(dim, dim, scale=dim ** -0.5), n(dim, scale=0.02)
+            sd[p + att + "_layer_norm.weight"], sd[p + att + "_layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+        sd[p + "fc1.weight"], sd[p + "fc1.bias"] = n(ffn, dim, scale=dim ** -0.5), n(ffn, scale=0.02)
+        sd[p + "fc2.weight"], sd[p + "fc2.bias"] = n(dim, ffn, scale=ffn ** -0.5), n(dim, scale=0.02)
+        sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+    sd["layer_norm.weight"], sd["layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+    sd["output_projection.weight"] = n(vocab, dim, scale=dim ** -0.5)
+    return sd

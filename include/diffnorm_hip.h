@@ -55,7 +55,8 @@ enum {
                            packed row 16 t + i = value row 8 t + i (i < 8) or gate row 8 t + i - 8 (i >= 8)        */
   DN_EPI_FILM_GATE = 3, /* h=(acc+bias)[*gamma+beta]; out = tanh(h)*sigmoid(h) + res      latent_module.py:525-530 */
   DN_EPI_RESADD = 4,    /* out = res + acc + bias  (fp32 residual stream)                  latent_module.py:692,704 */
-  DN_EPI_POSEMB = 5     /* out = acc + bias + pe[pos(b,t)]                                 latent_module.py:867-868 */
+  DN_EPI_POSEMB = 5,    /* out = acc + bias + pe[pos(b,t)]                                 latent_module.py:867-868 */
+  DN_EPI_RELU = 6       /* out = relu(acc + bias)   (the S2UT decoder's FFN, fairseq/modules/transformer_layer.py:505-508) */
 };
 
 #define DN_MAX_TERMS 8
@@ -619,6 +620,36 @@ int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch*
 
 const char* dn_last_error(void);
 int dn_version(void);
+
+/* ------------------------------------------------------------------ the model inside the mask-predict loop */
+/* The DECODER side of the reference's NAR S2UT model NARS2UTTransformerModel (research/TranSpeech/nar_transformer.py:569-976; task
+ * speech_to_speech_fasttranslate, fairseq/tasks/nat_s2s_task.py:107-127), which the research IterativeRefinementGenerator drives
+ * (research/TranSpeech/iterative_refinement_generator.py:131-160).  The speech encoder is out of scope: its output is a given
+ * tensor.  Packed tensors (diffnorm_amd/nar_decoder.py::pack_nar; matrices [rows -> 128][K] in cfg.dtype, biases / norms fp32):
+ *   emb fp32 [V, D]   pos fp32 [max_pos, D] (sinusoidal, row `pad` zero)   len_W fp32 [256, D] (embed_length.weight)
+ *   per layer, stacked: qkv_W [3D] + qkv_b (q ; k ; v of self_attn), so_W / so_b (out_proj), cq_W / cq_b (encoder_attn.q_proj),
+ *   ckv_W [2D] / ckv_b (encoder_attn k ; v), co_W / co_b, fc1_W [F] / fc1_b, fc2_W / fc2_b, ln_g / ln_b [3, D] (self_attn_layer_norm,
+ *   encoder_attn_layer_norm, final_layer_norm);  fin_g / fin_b (decoder.layer_norm);  out_W [V -> 128-row multiple, D].      */
+typedef struct DnNar DnNar;
+typedef struct {
+  int32_t dim, ffn, layers, heads, vocab, max_pos, pad, dtype;
+} DnNarConfig;
+int dn_nar_create(const DnNarConfig* cfg, const void* const* weights, int32_t n_weights, DnNar** out);
+void dn_nar_destroy(DnNar* m);
+size_t dn_nar_workspace_bytes(const DnNar* m, int32_t B, int32_t T, int32_t S);
+size_t dn_nar_cross_kv_bytes(const DnNar* m, int32_t B, int32_t S);
+/* Keys / values of every layer's encoder attention (fairseq/modules/transformer_layer.py:455-470), which depend on the encoder
+ * output only: enc_out fp32 [B, S, D] (batch-major) -> ckv [layers][B*S][k(D) ; v(D)] in cfg.dtype (fp32 for DN_BF16X3), computed
+ * once per utterance batch and reused by every refinement iteration.                                                        */
+int dn_nar_cross_kv(DnNar* m, const float* enc_out, int32_t B, int32_t S, void* ckv, void* workspace, size_t workspace_bytes, void* stream);
+/* forward_length + forward_length_prediction (nar_transformer.py:436-480, no offset): masked mean of the encoder output over the
+ * src_lengths[b] valid frames -> embed_length projection (fp32) -> arg-max.  lengths int32 [B].                              */
+int dn_nar_predict_lengths(DnNar* m, const float* enc_out, const int32_t* src_lengths, int32_t B, int32_t S, int32_t* lengths,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* TransformerUnitDecoder.forward (nar_transformer.py:321-420, inference): tokens int32 [B, T] (`pad` after each row's tokens) ->
+ * logits fp32 [B, T, vocab]; dn_cmlm_step turns them into the mask-predict update of forward_decoder (:791-842).            */
+int dn_nar_decoder_forward(DnNar* m, const int32_t* tokens, const void* ckv, const int32_t* src_lengths, int32_t B, int32_t T, int32_t S,
+                           float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

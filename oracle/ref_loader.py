@@ -183,3 +183,146 @@ def load_reference_optim():
                   "fairseq/optim/lr_scheduler/inverse_square_root_schedule.py")
     _CACHE["optim"] = (adam.Adam, sys.modules["fairseq.utils"].clip_grad_norm_, sched.InverseSquareRootSchedule)
     return _CACHE["optim"]
+
+
+def load_reference_nar():
+    """The REAL reference classes behind SURVEY 8 f4's loop, loaded where they lie: fairseq's TransformerDecoder stack
+    (fairseq/models/transformer/transformer_decoder.py, fairseq/modules/{transformer_layer,multihead_attention,layer_norm,...}.py),
+    the research model file research/TranSpeech/nar_transformer.py (TransformerUnitDecoder, NARS2UTTransformerModel.forward_decoder /
+    initialize_output_tokens / regenerate_length_beam) and the research generator research/TranSpeech/iterative_refinement_generator.py.
+    What the path does not touch is stubbed: the dataclass config machinery (omegaconf) -- `TransformerConfig.from_namespace` is
+    replaced by a plain nested namespace with the attributes the decoder reads --, FSDP / checkpoint wrappers (identity), the
+    speech encoder, CTC decoder and NAT base classes the model file merely imports or subclasses, and `ipdb`.
+    -> namespace(nar=module, gen=module, TransformerDecoder=..., cfg_from_namespace=...)."""
+    if "nar" in _CACHE:
+        return _CACHE["nar"]
+    load_reference()
+    import torch
+    import torch.nn as nn
+
+    if "omegaconf" not in sys.modules:  # fairseq.utils.safe_getattr asks OmegaConf.is_config(obj) before a plain getattr: never a config here
+        oc = types.ModuleType("omegaconf")
+        oc.OmegaConf = type("OmegaConf", (), {"is_config": staticmethod(lambda obj: False)})
+        sys.modules["omegaconf"] = oc
+    fs = sys.modules["fairseq"]
+    for name, rel in (("fairseq.incremental_decoding_utils", "fairseq/incremental_decoding_utils.py"),
+                      ("fairseq.modules.fairseq_dropout", "fairseq/modules/fairseq_dropout.py"),
+                      ("fairseq.modules.quant_noise", "fairseq/modules/quant_noise.py"),
+                      ("fairseq.modules.layer_norm", "fairseq/modules/layer_norm.py"),
+                      ("fairseq.modules.layer_drop", "fairseq/modules/layer_drop.py")):
+        _load(name, rel)
+    models = sys.modules["fairseq.models"]
+    models.FairseqDecoder = _load("fairseq.models.fairseq_decoder", "fairseq/models/fairseq_decoder.py").FairseqDecoder
+    models.FairseqIncrementalDecoder = _load("fairseq.models.fairseq_incremental_decoder",
+                                             "fairseq/models/fairseq_incremental_decoder.py").FairseqIncrementalDecoder
+    for n in ("FairseqEncoderModel", "FairseqEncoderDecoderModel", "FairseqLanguageModel"):
+        setattr(models, n, type(n, (nn.Module,), {}))
+    models.register_model = lambda name: (lambda cls: cls)
+    models.register_model_architecture = lambda model_name=None, arch_name=None, *a, **k: (lambda fn: fn)
+    mods = sys.modules["fairseq.modules"]
+    mods.FairseqDropout = sys.modules["fairseq.modules.fairseq_dropout"].FairseqDropout
+    mods.LayerNorm = sys.modules["fairseq.modules.layer_norm"].LayerNorm
+    mods.LayerDropModuleList = sys.modules["fairseq.modules.layer_drop"].LayerDropModuleList
+    mods.SinusoidalPositionalEmbedding = sys.modules["fairseq.modules.sinusoidal_positional_embedding"].SinusoidalPositionalEmbedding
+    gelu_mod = _load("fairseq.modules.gelu", "fairseq/modules/gelu.py")  # fairseq.utils.get_activation_fn imports both names (relu is what runs)
+    mods.gelu, mods.gelu_accurate = gelu_mod.gelu, gelu_mod.gelu_accurate
+    mods.AdaptiveSoftmax = type("AdaptiveSoftmax", (nn.Module,), {})
+    mods.BaseLayer = type("BaseLayer", (nn.Module,), {})
+    mods.MultiheadAttention = _load("fairseq.modules.multihead_attention", "fairseq/modules/multihead_attention.py").MultiheadAttention
+    ck = types.ModuleType("fairseq.modules.checkpoint_activations")
+    ck.checkpoint_wrapper = lambda m, **k: m
+    sys.modules[ck.__name__] = ck
+    dist = types.ModuleType("fairseq.distributed")
+    dist.fsdp_wrap = lambda m, **k: m
+    sys.modules[dist.__name__] = dist
+    fs.distributed = dist
+
+    def cfg_from_namespace(args):
+        """The attributes TransformerDecoderBase / TransformerDecoderLayerBase read (transformer_decoder.py, transformer_layer.py),
+        as the dataclass's from_namespace would nest them."""
+        if hasattr(args, "quant_noise") and hasattr(args, "decoder"):  # already nested (the dataclass's from_namespace is idempotent too)
+            return args
+        g = lambda k, d=None: getattr(args, k, d)
+        side = lambda p: types.SimpleNamespace(embed_dim=g(p + "_embed_dim"), ffn_embed_dim=g(p + "_ffn_embed_dim"), layers=g(p + "_layers"),
+                                               attention_heads=g(p + "_attention_heads"), normalize_before=g(p + "_normalize_before", False),
+                                               learned_pos=g(p + "_learned_pos", False), layerdrop=g(p + "_layerdrop", 0.0),
+                                               xformers_att_config=None, output_dim=g(p + "_output_dim", g(p + "_embed_dim")),
+                                               input_dim=g(p + "_input_dim", g(p + "_embed_dim")))
+        return types.SimpleNamespace(
+            encoder=side("encoder"), decoder=side("decoder"), dropout=g("dropout", 0.0), attention_dropout=g("attention_dropout", 0.0),
+            activation_dropout=g("activation_dropout", 0.0), relu_dropout=0.0, activation_fn=g("activation_fn", "relu"), export=False,
+            quant_noise=types.SimpleNamespace(pq=0, pq_block_size=8, scalar=0), cross_self_attention=False, tie_adaptive_weights=False,
+            tie_adaptive_proj=False, adaptive_softmax_cutoff=None, adaptive_softmax_factor=4, adaptive_softmax_dropout=0, adaptive_input=False,
+            share_decoder_input_output_embed=g("share_decoder_input_output_embed", False), offload_activations=False,
+            no_token_positional_embeddings=g("no_token_positional_embeddings", False), no_scale_embedding=g("no_scale_embedding", False),
+            no_decoder_final_norm=False, min_params_to_wrap=10 ** 12, max_target_positions=g("max_target_positions", 1024),
+            layernorm_embedding=g("layernorm_embedding", False), checkpoint_activations=False, base_layers=0)
+
+    tr = types.ModuleType("fairseq.models.transformer")
+    tr.__path__ = []
+    tr.TransformerConfig = type("TransformerConfig", (), {"from_namespace": staticmethod(cfg_from_namespace)})
+    sys.modules[tr.__name__] = tr
+    mods.transformer_layer = _load("fairseq.modules.transformer_layer", "fairseq/modules/transformer_layer.py")
+    dec = _load("fairseq.models.transformer.transformer_decoder", "fairseq/models/transformer/transformer_decoder.py")
+    tr.TransformerDecoder, tr.TransformerDecoderBase, tr.Linear = dec.TransformerDecoder, dec.TransformerDecoderBase, dec.Linear
+    tr.TransformerModelBase = type("TransformerModelBase", (nn.Module,), {})
+
+    def Embedding(num_embeddings, embedding_dim, padding_idx):  # fairseq/models/transformer/transformer_base.py:175-179 (the module drags the dataclasses)
+        m = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)
+        nn.init.normal_(m.weight, mean=0, std=embedding_dim ** -0.5)
+        if padding_idx is not None:
+            nn.init.constant_(m.weight[padding_idx], 0)
+        return m
+
+    tr.Embedding = Embedding
+    # what nar_transformer.py imports besides the decoder stack
+    gen_f = _load("fairseq.iterative_refinement_generator", "fairseq/iterative_refinement_generator.py")
+    fs.checkpoint_utils = types.ModuleType("fairseq.checkpoint_utils")
+    sys.modules["fairseq.checkpoint_utils"] = fs.checkpoint_utils
+    sys.modules["ipdb"] = types.ModuleType("ipdb")
+    fd = _pkg("fairseq.data") if "fairseq.data" not in sys.modules else sys.modules["fairseq.data"]
+    if "fairseq.data.data_utils" not in sys.modules:
+        du = types.ModuleType("fairseq.data.data_utils")
+        du.lengths_to_padding_mask = lambda lens: torch.arange(int(lens.max()))[None, :] >= lens[:, None]
+        sys.modules[du.__name__] = du
+        fd.data_utils = du
+    s2t = types.ModuleType("fairseq.models.speech_to_text")
+    s2t.S2TTransformerEncoder = type("S2TTransformerEncoder", (nn.Module,), {})
+    sys.modules[s2t.__name__] = s2t
+    _pkg("fairseq.models.speech_to_speech")
+    _pkg("fairseq.models.speech_to_speech.modules")
+    ctc = types.ModuleType("fairseq.models.speech_to_speech.modules.ctc_decoder")
+    ctc.CTCDecoder = type("CTCDecoder", (nn.Module,), {})
+    sys.modules[ctc.__name__] = ctc
+    _load("fairseq.models.speech_to_speech.modules.stacked_embedding", "fairseq/models/speech_to_speech/modules/stacked_embedding.py")
+    nat = types.ModuleType("fairseq.models.nat")
+    nat.__path__ = []
+    nat.NATransformerModel = type("NATransformerModel", (nn.Module,), {})
+    nat.FairseqNATDecoder = type("FairseqNATDecoder", (nn.Module,), {})
+    nat.ensemble_decoder = lambda fn: fn  # (a single model: the decorator's ensemble branch is never taken)
+    sys.modules[nat.__name__] = nat
+
+    def _mean_pooling(enc_feats, src_masks):  # fairseq/models/nat/nonautoregressive_transformer.py:20-34, compiled from its source
+        raise RuntimeError("replaced below")
+
+    import ast
+
+    def compile_fn(rel, fn_name, ns):
+        path = os.path.join(REF, rel)
+        tree = ast.parse(open(path).read())
+        fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn_name)
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+        return ns[fn_name]
+
+    nrt = types.ModuleType("fairseq.models.nat.nonautoregressive_transformer")
+    nrt._mean_pooling = compile_fn("fairseq/models/nat/nonautoregressive_transformer.py", "_mean_pooling", {"torch": torch})
+    sys.modules[nrt.__name__] = nrt
+    cm = types.ModuleType("fairseq.models.nat.cmlm_transformer")
+    cm._skeptical_unmasking = compile_fn("fairseq/models/nat/cmlm_transformer.py", "_skeptical_unmasking",
+                                         {"new_arange": sys.modules["fairseq.utils"].new_arange})
+    sys.modules[cm.__name__] = cm
+    nar = _load("refnar.nar_transformer", "research/TranSpeech/nar_transformer.py")
+    gen = _load("refnar.iterative_refinement_generator", "research/TranSpeech/iterative_refinement_generator.py")
+    out = types.SimpleNamespace(nar=nar, gen=gen, gen_fairseq=gen_f, TransformerDecoder=dec.TransformerDecoder, cfg_from_namespace=cfg_from_namespace)
+    _CACHE["nar"] = out
+    return out

@@ -41,3 +41,51 @@ def test_refinement_loop_with_the_kernel(golden):
     for k, kw in enumerate(toy_nat.SETTINGS):
         model = toy_nat.ToyCMLM(d, hip_update, device=DEV)
         check_hypos(IterativeRefinementGenerator(d, **kw).generate([model], toy_nat.toy_sample(d, DEV)), g, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the model inside the loop
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 6e-2)])
+def test_nar_decoder_pass_matches_the_real_reference(golden, dtype, tol):
+    """SURVEY 8 f4, the model inside the mask-predict loop: one pass of the NAR S2UT decoder on the HIP engine (dn_nar_decoder_forward:
+    embedding + positions, pre-norm self-attention / encoder attention / ReLU FFN layers, final LayerNorm, 1004-way projection) and
+    the length predictor against the REAL reference classes' outputs (tests/golden/nar_decoder.npz: fairseq's TransformerDecoder
+    stack under research/TranSpeech/nar_transformer.py's TransformerUnitDecoder) on a ragged, partially masked batch."""
+    import nar_oracle as N
+    from diffnorm_amd import nar_decoder
+    from gen_golden_nar_configs import CFG
+
+    g = golden("nar_decoder")
+    eng = nar_decoder.NarDecoderEngine(N.make_nar_state_dict(CFG, "nar"), CFG.embed_dim, CFG.ffn_dim, CFG.layers, CFG.heads, CFG.vocab, dtype=dtype, device=DEV)
+    enc = torch.from_numpy(g["enc_out"]).transpose(0, 1).contiguous().to(DEV)  # [S,B,D] -> [B,S,D]
+    slen = torch.from_numpy(g["src_lens"]).to(DEV).int()
+    tok = torch.from_numpy(g["tokens"])
+    ckv = eng.cross_kv(enc)
+    logits = eng.forward(tok.to(DEV).int().contiguous(), ckv, slen).cpu()
+    valid = tok.ne(CFG.pad)
+    err = (logits - torch.from_numpy(g["logits"]))[valid].abs().max().item()
+    print(f"NAR decoder logits {dtype}: max abs err {err:.3e} (logit scale {np.abs(g['logits']).max():.2f})")
+    assert err < tol * max(1.0, float(np.abs(g["logits"]).max()) / 4)
+    assert eng.predict_lengths(enc, slen).cpu().tolist() == g["pred_lengths"].tolist()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_hip_nar_model_in_the_research_generator_reproduces_the_reference_hypotheses(golden, dtype):
+    """The loop for real: the generator mirror in its research/TranSpeech flavour (3-D speech source, initialize_output_tokens(encoder_out,
+    src_lengths)) driving NARS2UTDecoderModel -- HIP decoder passes + dn_cmlm_step -- reproduces every hypothesis (tokens, steps,
+    history exactly; scores 2e-4) the REAL reference generator produced with the REAL reference model: adaptive early stop with a
+    shrinking batch, a fixed 10 iterations with history, a length beam of 3, and max_iter = 0."""
+    import nar_oracle as N
+    from diffnorm_amd import nar_decoder
+    from diffnorm_amd.iterative_refinement import IterativeRefinementGenerator
+    from gen_golden_nar_configs import CFG, SETTINGS, Dict1004, encoder_out
+    from test_nar_oracle import check_hypotheses
+
+    g = golden("nar_decoder")
+    model = nar_decoder.NARS2UTDecoderModel(N.make_nar_state_dict(CFG, "nar"), CFG.embed_dim, CFG.ffn_dim, CFG.layers, CFG.heads, CFG.vocab, dtype=dtype,
+                                            device=DEV)
+    lens = torch.from_numpy(g["src_lens"])
+    enc = encoder_out(lens.numel(), g["enc_out"].shape[0], lens, 801)
+    to_dev = lambda e: {k: [x.to(DEV) for x in v] for k, v in e.items()}
+    model.forward_encoder = lambda inputs: to_dev(enc)
+    sample = {"net_input": {"src_tokens": torch.zeros(lens.numel(), g["enc_out"].shape[0], 80, device=DEV), "src_lengths": lens.to(DEV)}}
+    check_hypotheses(g, lambda kw: IterativeRefinementGenerator(Dict1004(), speech_source=True, **kw), model, sample)
