@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-x3", action="store_true", help="skip the split-operand (bf16x3) leg")
     ap.add_argument("--no-train", action="store_true", help="skip the two training legs of the default line")
     ap.add_argument("--no-refine", action="store_true", help="skip the mask-predict refinement leg (SURVEY 8 f4)")
+    ap.add_argument("--no-cond", action="store_true", help="skip the conditional-variant (guided chain) leg (SURVEY 8 f3)")
     ap.add_argument("--train-loss", default="vae", choices=["vae", "diffusion"], help="--mode train: which loss's update is the step")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 legs (20 steps + the full chain for the unit agreement)")
     return ap.parse_args()
@@ -361,6 +362,36 @@ def refine_leg(args, dev, stream):
                                f"S = {S} encoder frames, {iters} iterations (decoder pass + dn_cmlm_step each), host-stepped like the reference's generator"}}
 
 
+def cond_leg(args, dev, stream, B, T):
+    """The conditional variant (use_cond=True: pooled-prompt condition, PerceiverResampler, a cross-attention block per
+    layer, classifier-free guidance at scale 2 = conditioned + null rows in ONE 2B-row pass) at the recipe's sizes: guided denoising
+    steps per second of the prompted chain, one step captured into a hipGraph and replayed."""
+    import torch
+
+    from diffnorm_amd import engine, ops, scheduler, synthetic
+
+    cfg = synthetic.eps_config(dim_prompt=768, num_latents_m=64)
+    eng = engine.EpsEngine(synthetic.random_eps_state_dict(cfg, seed=2), cfg, dtype=args.dtype, device=dev)
+    Tp = 256
+    coef = scheduler.DDPMScheduler(args.timesteps).ddim_coef_table(dev)
+    lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
+    plens = torch.full((B,), Tp, dtype=torch.int32, device=dev)
+    n = 21
+    with torch.cuda.stream(stream):
+        x = ops.randn((B, T, cfg.latent_dim), seed=77, device=dev)
+        prompt = ops.randn((B, Tp, 768), seed=78, device=dev)
+        eng.guided_ddim_chain(x, lengths, prompt, plens, 5, coef, cond_scale=2.0)  # warm-up: workspaces, attributes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evals = eng.guided_ddim_chain(x, lengths, prompt, plens, n + 1, coef, cond_scale=2.0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(x).all().item()
+    return {"cond": {"guided_steps_per_s": evals / dt, "ms_per_guided_step": dt / evals * 1e3, "dtype": args.dtype, "cond_scale": 2.0,
+                     "what": f"prompted + guided chain of the conditional eps-predictor (dim 512, prompt 768 x {Tp} frames, 64 resampler latents) on [B={B},T={T}] "
+                             f"latents: every step = one pass over 2B rows (conditioned ; null) + guidance + DDIM update, {evals} steps incl. graph capture"}}
+
+
 # Which arithmetic mode meets which of north_star's budgets ("1e-3 fp32 / 1e-2 bf16", max-abs vs the reference's fp32 outputs),
 # as measured by the -m gpu tests on the reference-generated goldens (tests/test_hip_engine.py; BASELINE config 2 = eps_full_cfg2).
 TOLERANCE = {
@@ -487,6 +518,8 @@ def run_sampling(args, ctx):
             result.update(x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths))
         if world == 1 and not args.no_full_chain:
             result.update(full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched))
+        if world == 1 and not args.no_cond:
+            result.update(cond_leg(args, dev, stream, B, T))
         if world == 1 and not args.no_refine:
             result.update(refine_leg(args, dev, stream))
         if world == 1 and not args.no_train:

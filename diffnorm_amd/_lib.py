@@ -196,6 +196,7 @@ SYMBOLS = {
     "dn_ddim_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "dn_ddim_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
     "dn_ddpm_loop": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, C.c_uint64, _vp, _i32, _vp, _sz, _vp]),
+    "dn_cfg_combine": (C.c_int, [_vp, C.c_float, _i64, _vp, _vp]),
     "dn_nar_create": (C.c_int, [C.POINTER(NarConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "dn_nar_destroy": (None, [_vp]),
     "dn_nar_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),

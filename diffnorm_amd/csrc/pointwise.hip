@@ -537,6 +537,21 @@ extern "C" int dn_ddim_step(const float* x, const float* eps, float* x_out, void
   return DN_OK;
 }
 
+// forward_with_cond_scale's combination (latent_module.py:813-826): out = null + (cond - null) * scale over the two halves of one
+// 2B-batch pass ([cond rows ; null rows])
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ both, float scale, int64_t n, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float c = both[i], u = both[n + i];
+    out[i] = __fadd_rn(u, __fmul_rn(__fsub_rn(c, u), scale));
+  }
+}
+extern "C" int dn_cfg_combine(const float* both, float scale, int64_t n, float* out, void* stream) {
+  DN_CHECK_ARG(both && out && n > 0, "dn_cfg_combine: bad argument");
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, both, scale, n, out);
+  DN_CHECK_LAUNCH("dn_cfg_combine");
+  return DN_OK;
+}
+
 // (engine.hip: the ancestral update of dn_ddpm_loop)
 int dn_ddpm_step_launch(float* x, const float* eps, int M, int C, int T, const float* table, const int32_t* t, int clip, const float* noise,
                         int64_t noise_row, int t_top, uint64_t seed, hipStream_t stream) {

@@ -123,14 +123,81 @@ class EpsEngine(_Engine):
                        "dn_eps_forward_cond")
         return out
 
+    def _guided_inputs(self, lengths, prompt, prompt_lengths):
+        """Static inputs of a guided pass over 2B rows = [conditioned ; null-conditioned] (the drop mask is per sample, :843-859)."""
+        B = prompt.shape[0]
+        two = lambda t: torch.cat([t, t]).contiguous()
+        drop2 = torch.cat([torch.zeros(B, dtype=torch.int32), torch.ones(B, dtype=torch.int32)]).to(self.device)
+        return two(_i32(lengths, self.device)), two(_f32(prompt, self.device)), two(_i32(prompt_lengths, self.device)), drop2
+
     def forward_with_cond_scale(self, x, times, lengths, prompt, prompt_lengths, cond_scale: float = 1.0) -> torch.Tensor:
-        """Classifier-free guidance (latent_module.py:813-826): null + (cond - null) * cond_scale; one pass when the scale is 1."""
+        """Classifier-free guidance (latent_module.py:813-826): null + (cond - null) * cond_scale.  The conditioned and the null pass
+        are ONE launch sequence over 2B rows (the engine's drop mask is per sample); a scale of 1 needs the conditioned rows only."""
         B = x.shape[0]
-        cond = self.forward_cond(x, times, lengths, prompt, prompt_lengths, torch.zeros(B, dtype=torch.bool))
         if cond_scale == 1.0:
-            return cond
-        null = self.forward_cond(x, times, lengths, prompt, prompt_lengths, torch.ones(B, dtype=torch.bool))
-        return torch.add(null, cond - null, alpha=cond_scale)
+            return self.forward_cond(x, times, lengths, prompt, prompt_lengths, torch.zeros(B, dtype=torch.bool))
+        x = _f32(x, self.device)
+        l2, p2, pl2, drop2 = self._guided_inputs(lengths, prompt, prompt_lengths)
+        t2 = torch.cat([_i32(times, self.device)] * 2)
+        both = self.forward_cond(torch.cat([x, x]).contiguous(), t2, l2, p2, pl2, drop2)
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_cfg_combine(both.data_ptr(), float(cond_scale), x.numel(), out.data_ptr(), _lib.current_stream()), "dn_cfg_combine")
+        return out
+
+    def guided_ddim_chain(self, x: torch.Tensor, lengths, prompt, prompt_lengths, start_step: int, coef: torch.Tensor, cond_scale: float = 1.0,
+                          use_graph: bool = True) -> int:
+        """The prompted chain of the conditional variant, in place on x [B,T,z]: for t = start_step-1 .. 1 (t = 0 only when start_step
+        == 1, like the reference's loop :1411-1445) the guided prediction (one 2B-row pass, or B rows at scale 1) and the DDIM eta = 0
+        update.  One step -- timestep fill from a device counter, the pass, the guidance combination, the update, the decrement -- is
+        captured into a hipGraph (torch.cuda.CUDAGraph over this library's launches on the capture stream) and replayed: the host only
+        issues graph launches.  Returns the number of model evaluations."""
+        from . import ops
+
+        B, T, z = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.device == self.device
+        guided = cond_scale != 1.0
+        n = 2 * B if guided else B
+        if guided:
+            l2, p2, pl2, drop2 = self._guided_inputs(lengths, prompt, prompt_lengths)
+        else:
+            l2, p2, pl2 = _i32(lengths, self.device), _f32(prompt, self.device), _i32(prompt_lengths, self.device)
+            drop2 = torch.zeros(B, dtype=torch.int32, device=self.device)
+        tvec = torch.full((n,), start_step - 1, dtype=torch.int32, device=self.device)
+        xin = torch.empty(n, T, z, dtype=torch.float32, device=self.device) if guided else x
+        both = torch.empty(n, T, z, dtype=torch.float32, device=self.device)
+        eps = torch.empty_like(x) if guided else both
+
+        def one_step():
+            if guided:
+                xin[:B].copy_(x)
+                xin[B:].copy_(x)
+            self.forward_cond(xin, tvec, l2, p2, pl2, drop2, out=both)
+            if guided:
+                _lib.check(self.lib.dn_cfg_combine(both.data_ptr(), float(cond_scale), x.numel(), eps.data_ptr(), _lib.current_stream()), "dn_cfg_combine")
+            ops.ddim_step(x, eps, coef, tvec[:B], T, out=x)
+            tvec.sub_(1)
+
+        n_eval = max(1, start_step - 1)
+        with torch.cuda.device(self.device):
+            one_step()  # eager first step: settles workspaces and kernel attributes outside capture
+            done = 1
+            if use_graph and n_eval > 2:
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(cur)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        one_step()
+                    done += 0  # (capture does not execute)
+                    for _ in range(n_eval - done):
+                        g.replay()
+                cur.wait_stream(side)
+                done = n_eval
+            for _ in range(n_eval - done):
+                one_step()
+        return n_eval
 
     def ddim_loop(self, x: torch.Tensor, lengths: torch.Tensor, start_step: int, coef: torch.Tensor,
                   use_graph: bool = True, max_evals: int = 0, split: bool = True, keep_table: bool = False) -> int:

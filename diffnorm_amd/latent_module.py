@@ -503,18 +503,12 @@ class LatentDiscreteModel(nn.Module):
         x = ops.q_sample(z, start_noise.to(dev, torch.float32).contiguous(), sa, s1, t_start, T)  # (:1405-1409)
         if self.use_cond:
             # prompted chain (f3): the reference's loop drops the prompt it was given (:1413-1417 -- with use_cond it cannot run at
-            # all); here every step is the guided prediction forward_with_cond_scale (:813-826) followed by the same DDIM update.
-            # The device-resident graph loop covers the unconditional model; this one steps from the host.
+            # all); here every step is the guided prediction forward_with_cond_scale (:813-826) -- conditioned and null rows in ONE pass of
+            # twice the batch -- followed by the same DDIM update, one step captured into a hipGraph and replayed (EpsEngine.guided_ddim_chain).
             if prompt is None or prompt_mask is None:
                 raise ValueError("use_cond: ddim_sample needs prompt and prompt_mask")
-            eng = self.model.engine()
             plens = _mask_to_lengths(prompt_mask.to(dev))
-            for time in range(start_step - 1, -1, -1):
-                tt = torch.full((B,), time, dtype=torch.int32, device=dev)
-                eps = eng.forward_with_cond_scale(x, tt, lengths, prompt, plens, cond_scale=cond_scale)
-                x = ops.ddim_step(x, eps, coef, tt, T)
-                if time == 1:
-                    break
+            self.model.engine().guided_ddim_chain(x, lengths, prompt, plens, start_step, coef, cond_scale=cond_scale, use_graph=use_graph)
         else:
             self.model.engine().ddim_loop(x, lengths, start_step, coef, use_graph=use_graph)    # (:1411-1445)
         recon, _, units = self.speech_decoder.engine().decode(x, lengths, want_logits=False)     # (:1448-1451)

@@ -621,6 +621,10 @@ int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch*
 const char* dn_last_error(void);
 int dn_version(void);
 
+/* Classifier-free guidance (Model.forward_with_cond_scale, latent_module.py:813-826) over ONE pass of twice the batch: `both` fp32
+ * [2, n] = the conditioned predictions followed by the null-conditioned ones -> out[i] = null + (cond - null) * scale.           */
+int dn_cfg_combine(const float* both, float scale, int64_t n, float* out, void* stream);
+
 /* ------------------------------------------------------------------ the model inside the mask-predict loop */
 /* The DECODER side of the reference's NAR S2UT model NARS2UTTransformerModel (research/TranSpeech/nar_transformer.py:569-976; task
  * speech_to_speech_fasttranslate, fairseq/tasks/nat_s2s_task.py:107-127), which the research IterativeRefinementGenerator drives

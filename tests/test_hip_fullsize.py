@@ -250,3 +250,40 @@ def test_manifests_to_normalised_unit_tsv_through_the_hip_path(tmp_path):
         tot += len(a)
     assert agree / tot >= 0.99, (agree, tot)  # f32: identical except where the reference's top-2 logit margin is below round-off
     assert open(out).readline().strip() == N.TSV_HEADER
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 4e-2)])
+def test_fullsize_conditional_variant_vs_oracle_and_captured_guided_chain(dtype, tol):
+    """SURVEY 8 f3 at the recipe's sizes -- Model(512, 128, condition_on_prompt=True, dim_prompt=768, num_latents_m=64): twice the
+    conditioning width (4096), the PerceiverResampler over a ragged 768-wide prompt and a cross-attention block in each of the 12
+    layers.  (a) the guided prediction (cond_scale 2: conditioned and null rows in ONE 2B-row pass) against the CPU oracle on a
+    [2, 64] batch; (b) a 6-step prompted, guided DDIM chain: one step captured into a hipGraph and replayed equals the eager
+    host-stepped chain bit for bit."""
+    from diffnorm_amd import engine, scheduler
+
+    cfg = O.EpsConfig(dim_prompt=768, num_latents_m=64)
+    sd = O.make_eps_state_dict(cfg, "condfull")
+    e = engine.EpsEngine(sd, cfg, dtype=dtype, device=DEV)
+    g = torch.Generator().manual_seed(7)
+    B, T, Tp = 2, 64, 48
+    x = torch.randn(B, T, 128, generator=g)
+    prompt = torch.randn(B, Tp, 768, generator=g)
+    lens, plens = torch.tensor([64, 37]), torch.tensor([48, 20])
+    t = torch.tensor([7, 7])  # (small t: O(1) FiLM / adaptive-norm gains, the regime where plain bf16 keeps its budget)
+    mask, pmask = O.lengths_to_mask(lens, T), O.lengths_to_mask(plens, Tp)
+    with torch.no_grad():
+        want = O.eps_forward_with_cond_scale(sd, cfg, x, t, mask, prompt, pmask, 2.0)
+    got = e.forward_with_cond_scale(x.to(DEV), t, lens, prompt.to(DEV), plens, cond_scale=2.0).cpu()
+    err = (got - want)[mask].abs().max().item()
+    print(f"full-size conditional variant, guided (scale 2) {dtype}: max abs err {err:.3e}")
+    assert err < tol
+    coef = scheduler.DDPMScheduler(200).ddim_coef_table(DEV)
+    outs = []
+    for graph in (False, True):
+        xs = x.to(DEV).clone()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            assert e.guided_ddim_chain(xs, lens, prompt.to(DEV), plens, 7, coef, cond_scale=2.0, use_graph=graph) == 6
+        torch.cuda.synchronize()
+        assert torch.isfinite(xs).all()
+        outs.append(xs.cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], x)
