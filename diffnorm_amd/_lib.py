@@ -26,7 +26,7 @@ LAYOUT_A_KBLOCKED, LAYOUT_W_KBLOCKED, LAYOUT_OUT_KBLOCKED = 1, 2, 1
 class GemmTerm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("lda", C.c_int32), ("shift", C.c_int32),
                 ("a_gstride", C.c_int64), ("w_gstride", C.c_int64), ("shift_by_group", C.c_int32),
-                ("layout", C.c_int32)]
+                ("layout", C.c_int32), ("ldw", C.c_int32), ("pad_ldw_", C.c_int32)]
 
 
 class GemmParams(C.Structure):

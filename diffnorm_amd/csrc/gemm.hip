@@ -66,6 +66,9 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
     DN_CHECK_ARG(!p.norm_gb || (p.norm_gb_ld % 4 == 0 && p.norm_gb_half % 4 == 0), "dn_conv_gemm: norm_gb strides must be multiples of 4");
   }
   for (int i = 0; i < p.n_terms; ++i)
+    DN_CHECK_ARG(p.terms[i].ldw == 0 || (p.terms[i].ldw >= p.K && p.terms[i].layout == 0 && p.dtype != DN_BF16X3 && !(p.norm_out && !p.norm_split)),
+                 "dn_conv_gemm: term %d: ldw=%d needs ldw >= K, row-major operands, bf16 / f32 and no whole-row fused norm", i, p.terms[i].ldw);
+  for (int i = 0; i < p.n_terms; ++i)
     DN_CHECK_ARG((p.terms[i].layout & ~3) == 0 && (p.terms[i].layout == 0 || p.dtype == DN_BF16),
                  "dn_conv_gemm: term %d layout=%d (K-blocked operands are bf16 only)", i, p.terms[i].layout);
   if (p.out_layout)

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
       a_inc[i] = valid ? ROWB : 0;
     }
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) w_ptr[i] = W + (int64_t)(n0 + (wave * WPW + i) * 8 + srow) * p.K * ES;
+    for (int i = 0; i < WPW; ++i) w_ptr[i] = W + (int64_t)(n0 + (wave * WPW + i) * 8 + srow) * (tm.ldw ? tm.ldw : p.K) * ES;
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   auto stage = [&](int slot) {
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
     // K-blocked operands ([K/32][rows][32], DN_LAYOUT_*): rows are 64 bytes apart, K-tiles a whole block apart
     const bool a_kb = tm.layout & DN_LAYOUT_A_KBLOCKED, w_kb = tm.layout & DN_LAYOUT_W_KBLOCKED;
-    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)tm.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)p.K * ES;
+    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)tm.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)(tm.ldw ? tm.ldw : p.K) * ES;
     const int a_step = a_kb ? p.M * ROWB2 : ROWB2;
     w_inc = w_kb ? w_rows * ROWB2 : ROWB2;
 #pragma unroll
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     const DnGemmTerm& t1 = p.terms[1];
     const int sh0 = t0.shift_by_group ? (t0.shift << g) : t0.shift, sh1 = t1.shift_by_group ? (t1.shift << g) : t1.shift;
     const bool a_kb = t0.layout & DN_LAYOUT_A_KBLOCKED, w_kb = t0.layout & DN_LAYOUT_W_KBLOCKED;
-    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)t0.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)p.K * ES;
+    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)t0.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)(t0.ldw ? t0.ldw : p.K) * ES;
     tap_shift0 = sh0; tap_sstep = sh0 - sh1;
     tap_delta0 = sh0 * a_rowb; tap_dstep = tap_sstep * a_rowb;
     tap_wstride = (int64_t)((intptr_t)t1.W - (intptr_t)t0.W);
@@ -1907,6 +1907,14 @@ static inline int choose_tile(const DnGemmParams& p) {
   const bool bf = p.dtype == DN_BF16;
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split && p.dtype != DN_BF16X3) return 5;
   const int force = forced_tile(p);
+  bool has_ldw = false;
+  for (int i = 0; i < p.n_terms; ++i) has_ldw = has_ldw || p.terms[i].ldw != 0;
+  if (has_ldw && p.dtype != DN_BF16X3) {  // a weight row stride other than K: the 128x128 / 256x128 / 256x256 tiles (row-major operands)
+    const int npw = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
+    const long tb = (long)((p.M + 255) / 256) * ((npw + 255) / 256) * p.groups, ts = (long)((p.M + 127) / 128) * ((npw + BN - 1) / BN) * p.groups;
+    if (force >= 1 && force <= 3) return force;
+    return tb >= 256 ? 3 : ts >= 512 ? 2 : 1;
+  }
   if (p.dtype == DN_BF16X3) {  // split operands run on the two 128-byte-K-tile kernels (row-major operands only)
     for (int i = 0; i < p.n_terms; ++i)
       if (p.terms[i].layout != 0) return -1;

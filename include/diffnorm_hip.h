@@ -73,6 +73,9 @@ typedef struct {
   int64_t w_gstride;  /* elements added to W per group                                              */
   int32_t shift_by_group; /* 1: effective shift = shift * 2^group (WaveNet dilation 2^i)            */
   int32_t layout;     /* DN_LAYOUT_* bits; 0 = row-major A and W as described above                 */
+  int32_t ldw;        /* elements between rows of W when it is not K (0 = K): a K-slice of a wider packed matrix -- with `groups`,
+                         a_gstride and w_gstride = the slice width this is a split-K contraction whose groups write partial sums */
+  int32_t pad_ldw_;
 } DnGemmTerm;
 
 /* K-blocked operand layout, bf16 only: [K/32][rows][32] instead of [rows][K] -- the 32 K-elements (64 bytes) a K-tile
