@@ -86,42 +86,47 @@ def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters, 2.0 * M * (3 * inner) * inner
 
 
-def traffic_from_profiles():
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic*.json:
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 x2 read correction); None when no pass is committed."""
+def _build_id():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_id import build_id
+
+    return build_id()
+
+
+def _latest_profile(pattern):
+    """(contents, belongs to this build?) of the newest committed profile JSON matching `pattern`; (None, None) when there is none.  The
+    counters are collected in separate rocprofv3 --pmc passes (tools/collect_profiles_r03.sh) and committed under profiles/ with the hash
+    of the kernel sources they were measured on: a pass that no longer belongs to the kernels being run is flagged, not silently quoted."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+        d = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None, None
+    return d, (d.get("build_id") == _build_id()) if "build_id" in d else None
+
+
+def traffic_from_profiles(dtype="bf16"):
+    """Fabric-side bytes per launch of the dominant kernel, (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 x2 read correction
+    -> (bytes or None, profile matches this build?)."""
+    d, ok = _latest_profile("r*_x3_pmc_traffic_ffn_conv*.json" if dtype == "bf16x3" else "r[0-9][0-9]_pmc_traffic_ffn_conv*.json")
+    return (d.get("hbm_bytes_per_launch") if d else None), ok
 
 
 def train_traffic_from_profiles():
     """Fabric-side bytes per launch of the training leg's roofline kernel from the committed PMC passes
-    (profiles/*pmc_train_wgrad*.json, tools/collect_traffic_r02.sh); None when absent."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_train_wgrad*.json")))
-    try:
-        return json.load(open(files[-1]))["hbm_bytes_per_launch"] if files else None
-    except (OSError, KeyError, ValueError):
-        return None
+    (profiles/*pmc_train_wgrad*.json); None when absent."""
+    d, _ = _latest_profile("*pmc_train_wgrad*.json")
+    return d.get("hbm_bytes_per_launch") if d else None
 
 
-def step_traffic_from_profiles():
-    """Fabric-side bytes of one denoising step at [32,512] bf16 from the committed PMC passes (profiles/*pmc_step_traffic*.json,
-    tools/collect_step_traffic.sh); None when absent."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_traffic*.json")))
-    try:
-        return json.load(open(files[-1]))["bytes_per_step"] if files else None
-    except (OSError, KeyError, ValueError):
-        return None
+def step_traffic_from_profiles(dtype="bf16"):
+    """Fabric-side bytes of one denoising step at [32,512] from the committed PMC passes -> (bytes or None, matches this build?)."""
+    d, ok = _latest_profile("r*_x3_pmc_step_traffic.json" if dtype == "bf16x3" else "r[0-9][0-9]_pmc_step_traffic.json")
+    return (d.get("bytes_per_step") if d else None), ok
 
 
 def usable_cores(cap):
@@ -317,7 +322,9 @@ def x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths):
                                "accumulator; peak = dense bf16 MFMA peak / 3 (algorithmic FLOPs, three MFMAs each)",
                        "roofline": {"bound": "mfma", "kernel": f"conv_gemm_big_kernel<bf16x3, BIAS> FFN causal conv k=3 [{B * T} x 4095] x [4095 x 1365]",
                                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flops_per_launch": kflops,
-                                    "avg_launch_ms": avg_ms.value, "launches_timed": n_l.value, "traffic": None}}}
+                                    "avg_launch_ms": avg_ms.value, "launches_timed": n_l.value, "traffic": traffic_from_profiles("bf16x3")[0],
+                                    "traffic_profile_matches_build": traffic_from_profiles("bf16x3")[1]},
+                       "hbm_bytes_per_step": step_traffic_from_profiles("bf16x3")[0]}}
 
 
 def refine_leg(args, dev, stream):
@@ -491,15 +498,17 @@ def run_sampling(args, ctx):
                                                     f"[{B * T} x 4095] x [4095 x 1365]",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "launches_timed": n_l.value,
-                         "avg_launch_ms_isolated_back_to_back": ksec_iso * 1e3, "traffic": traffic_from_profiles()},
+                         "avg_launch_ms_isolated_back_to_back": ksec_iso * 1e3, "traffic": traffic_from_profiles(args.dtype)[0],
+                         "traffic_profile_matches_build": traffic_from_profiles(args.dtype)[1]},
         }
         # BASELINE config 2 asks for an HBM rate beside steps/s: the measured fabric-side bytes of one step (PMC, committed under
         # profiles/; an upper bound on HBM bytes, Infinity-Cache hits included) x the measured step rate.  Only for the shape and
         # dtype the passes were collected on.
-        sb = step_traffic_from_profiles()
-        if sb is not None and (B, T, args.dtype) == (32, 512, "bf16"):
+        sb, sb_ok = step_traffic_from_profiles(args.dtype)
+        if sb is not None and (B, T) == (32, 512) and args.dtype in ("bf16", "bf16x3"):
             result["hbm_bytes_per_step"] = sb
             result["hbm_gbps_per_gpu"] = sb * K / dt / 1e9
+            result["hbm_profile_matches_build"] = sb_ok
         # BASELINE configs[2] read literally ("DDPM reverse sampling"): the same chain with the ancestral update of
         # GaussianDiffusion.p_sample, noise drawn in the update kernel (dn_ddpm_loop) -- 20 steps after a 3-step set-up
         if world == 1:
