@@ -73,6 +73,14 @@ __device__ __forceinline__ void glds_set_m0(uint32_t lds_addr) {
 __device__ __forceinline__ void glds_go(const void* src) {
   asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src) : "memory");
 }
+// The same load from lanes 0..15 only (a 256-byte sub-piece: 4 rows of a 64-byte K-tile); EXEC is restored inside the statement.
+__device__ __forceinline__ void glds_go_lanes16(const void* src) {
+  uint64_t keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+               : "=&s"(keep)
+               : "v"(src)
+               : "memory");
+}
 // saddr form.  Hazard the compiler cannot see through inline asm: an SGPR written by a VALU instruction
 // (v_readfirstlane, which is how a uniform value computed in VGPRs reaches an "s" operand) needs 5 wait states before
 // a VMEM instruction reads it.  So the base is first copied by a SALU instruction -- in the M0 statement, one MFMA gap
@@ -1386,9 +1394,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // every epilogue (64 accumulator tiles, all in AGPRs).
 // WAVES = 8 (NTW = 8 only) runs the same instruction stream with TWO waves per SIMD, each on a 64 x 128 sub-tile: the partner's
 // MFMAs cover a wave's DMA-issue stalls without the segment barriers of the staggered two-group kernels.
-template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES>
+// HALO (256 x 352 tile, three taps of one causal conv with shifts 2d, d, 0, d <= 8, sequences a multiple of 256 frames long so that
+// a sequence starts only where a tile starts): the activation rows of a 32-element K-chunk are staged ONCE, as the tile's 256 rows
+// plus the 16 rows in front of them (zeros where the tile starts a sequence), and the three taps read them at row offsets
+// 16 - shift -- instead of three shifted copies of the same rows.  A chunk then moves 17 + 3 x 22 KiB into LDS instead of
+// 3 x (16 + 22): the L2 -> LDS path, which this loop keeps ~70 % busy, carries 27 % less and each wave issues 23 instead of 30 DMA
+// pieces per chunk.  Same K order as TAPS_INNER (chunk-major, tap-minor), so the same bits.
+template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES, bool HALO = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
   static_assert(std::is_same<E, BF16>::value, "the hand-scheduled tiles are built for bf16 operands only");
+  static_assert(!HALO || (TAPS_INNER && NTW == 11 && WAVES == 4), "the halo staging is built for the 256 x 352 tile in tap-inner order");
   static_assert(NTW == 11 || NTW == 8, "n-tiles per wave");
   static_assert(WAVES == 4 || (WAVES == 8 && NTW == 8), "4 waves (one per SIMD) or, on the 256 x 256 tile, 8");
   static_assert(NTW == 8 || EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU,
@@ -1482,6 +1497,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
   uint64_t tap_wbase = 0, tap_wbase0 = 0;
   int64_t tap_wstride = 0;
   int tap_akinc = ROWB2;  // bytes from a K-chunk of an activation row to the next
+  const char* halo_ptr = nullptr;  // HALO: this lane's row of the 16 rows in front of the tile (lanes 0..15), or the zero page
+  int halo_inc = 0;
   auto setup_taps = [&]() {
     const DnGemmTerm& t0 = p.terms[0];
     const DnGemmTerm& t1 = p.terms[1];
@@ -1507,6 +1524,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
       a_inc[i] = m % p.T;
     }
     w_voff = (uint32_t)(srow * w_rowb + schunk * 16);
+    if constexpr (HALO) {  // lanes 0..15 of wave w: rows m0 - 16 + 4 w + (lane >> 2), which land in LDS rows 4 w + (lane >> 2) of the halo piece
+      const int hchunk = (lane & 3) ^ ((wave >> 1) << 1);  // the swizzle of LDS rows 8..15
+      const bool starts = m0 % p.T == 0;  // the tile's first row starts a sequence: the frames in front of it are zeros
+      const char* A0 = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + hchunk * 16;
+      halo_ptr = starts ? reinterpret_cast<const char*>(g_zero_page) + hchunk * 16 : A0 + (int64_t)(m0 - 16 + wave * 4 + ((lane >> 2) & 3)) * a_rowb;
+      halo_inc = starts ? 0 : tap_akinc;
+    }
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
   // one of the wave's PER DMA pieces of a stage: 0..5 weight pieces, 6..9 row pieces.  Two halves (M0 <- LDS address,
@@ -1665,16 +1689,167 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     });
   };
 
+  // ---- HALO form of the K loop.  LDS: a 4-stage ring of weight K-tiles (one per tap of a chunk) and a 2-stage ring of activation
+  // chunks, each [16 halo rows ; 256 tile rows] x 64 bytes; tap t reads LDS rows 16 + r - shift_t.  K-tile kt = tap kt % 3 of
+  // chunk kt / 3 stages the weight tile of K-tile kt + 3 (6 pieces per wave) and its share of an activation chunk: tap 2 of chunk c
+  // the first three row pieces of chunk c + 2 (into chunk c's own slot, which nobody reads any more once every wave is past this
+  // K-tile's barrier: the fragments of tap 2 were requested during tap 1), tap 0 of chunk c + 1 the fourth row piece and the wave's
+  // 4-row share of the halo.  Chunk c + 2 is first read (the next K-tile's fragments) under tap 2 of chunk c + 1, whose barrier
+  // waits for everything but the 6 pieces of the K-tile before it.
+  constexpr int A_RING = STAGES * W_BYTES, A_HALO_BYTES = 17 * 1024;
+  [[maybe_unused]] uint32_t a_rdh[3] = {0, 0, 0};  // per tap: this lane's fragment address in slot 0 of the activation ring (+ mt * 1024)
+  [[maybe_unused]] auto ktile_h = [&](int slot, int aslot, auto tap_c, auto stw_c, auto sta_c, auto sync_c) {
+    constexpr int TAP = decltype(tap_c)::value, SYNC = decltype(sync_c)::value;
+    constexpr bool STW = decltype(stw_c)::value, STA = decltype(sta_c)::value;
+    constexpr int NA = !STA ? 0 : TAP == 2 ? 3 : TAP == 0 ? 2 : 0;  // activation pieces this K-tile stages
+    constexpr int PERH = (STW ? WPW : 0) + NA;
+    static_assert(STW || NA == 0, "activation pieces ride behind the weight pieces");
+    const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
+    const uint32_t w_cur = w_rd + slot * W_BYTES, w_nxt = w_rd + nslot * W_BYTES;
+    const uint32_t a_nxt = a_rdh[(TAP + 1) % 3] + (TAP == 2 ? (aslot ^ 1) : aslot) * A_HALO_BYTES;
+    const int fill = slot == 0 ? STAGES - 1 : slot - 1;       // weights of K-tile kt + 3: the slot K-tile kt - 1 lived in
+    const int afill = TAP == 2 ? aslot : (aslot ^ 1);          // chunk c + 2 -> chunk c's slot; (tap 0 of chunk c) chunk c + 1 -> the other one
+    auto h_setup = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      if constexpr (i < WPW) {
+        int pc = wave + WAVES * i;
+        pc = pc < pc_max ? pc : pc_max;
+        piece_base = glds_set_m0_base(lds_base + fill * W_BYTES + pc * 1024, tap_wbase + pc * piece_stride);
+      } else {
+        constexpr int j = i - WPW + (TAP == 0 ? 3 : 0);  // 0..3: the wave's row pieces, 4: its share of the halo
+        if constexpr (j < 4) glds_set_m0(lds_base + A_RING + afill * A_HALO_BYTES + 1024 + (wave * APW + j) * 1024);
+        else glds_set_m0(lds_base + A_RING + afill * A_HALO_BYTES + wave * 256);
+      }
+    };
+    auto h_go = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      if constexpr (i < WPW) {
+        glds_go_s(w_voff, piece_base);
+      } else {
+        constexpr int j = i - WPW + (TAP == 0 ? 3 : 0);
+        if constexpr (j < 4) glds_go(a_ptr[j]);
+        else glds_go_lanes16(halo_ptr);
+      }
+    };
+    auto h_advance = [&]() {  // behind the K-tile's last piece
+      if constexpr (TAP == 2) { tap_wbase = tap_wbase0; w_voff += w_step; }
+      else tap_wbase += tap_wstride;
+      if constexpr (TAP == 0 && NA > 0) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_ptr[i] += tap_akinc;
+        halo_ptr += halo_inc;
+      }
+    };
+    static_for<NT>([&](auto nt_c) {
+      constexpr int nt = decltype(nt_c)::value;
+      if constexpr (nt == BG) pipe_sync<SYNC>();
+      u32x4& w = [&]() -> u32x4& {
+        if constexpr (nt == 0) return wa;
+        else if constexpr (nt == 1) return wb;
+        else return wr[(nt - 2) % 3];
+      }();
+      lds_wait<Sched::younger_w(nt)>(w);
+      constexpr bool dma = nt >= BG && nt - BG < PERH;
+      constexpr bool dma_last = dma && nt - BG == PERH - 1;
+      static_assert(!dma || nt < NT - 1, "no piece in the last n-tile");
+      constexpr int a_first = (nt - BG) * NPG;
+      constexpr bool a_req = nt >= BG && a_first < MT;
+      using std::integral_constant;
+      static_for<MT>([&](auto mt_c) {
+        constexpr int mt = decltype(mt_c)::value;
+        if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
+        else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
+        if constexpr (nt < NT - 1) {
+          if constexpr (mt == 0) {
+            if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
+            else lds_request<0>(wa, w_nxt);
+          }
+          if constexpr (mt == 1 && a_req) lds_request<a_first * 1024>(nxt[a_first], a_nxt);
+          if constexpr (dma) {
+            if constexpr (mt == 2) h_setup(integral_constant<int, nt - BG>{});
+            if constexpr (mt == 3) h_go(integral_constant<int, nt - BG>{});
+            if constexpr (mt == 4 && dma_last) h_advance();
+          }
+        } else {
+          if constexpr (mt == 0) lds_request<1024>(wb, w_nxt);
+          if constexpr (mt == MT - 1) lds_wait_all_but<Sched::younger_copy()>();
+          copy_after_wait(cur[mt], nxt[mt]);
+        }
+      });
+    });
+  };
+
 #ifdef DN_FAT_STAMPS  // diagnostic build only (tools/fat_clock.py): in-kernel clock and K-loop cycles
   const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t dbg_c1 = 0;
 #endif
   if constexpr (taps_inner) setup_taps(); else setup_term(0);
+  if constexpr (HALO) {
+    using std::integral_constant;
+    const int chunks = p.K / KT;  // >= 3 (launch_fat)
+    {
+      const int tshift[3] = {(int)p.terms[0].shift, (int)p.terms[1].shift, (int)p.terms[2].shift};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int row = 16 + wm * RPW + frow - tshift[t];
+        a_rdh[t] = lds_base + A_RING + row * ROWB2 + ((fq ^ (((row >> 3) & 1) << 1)) << 4);
+      }
+    }
+    // prologue: chunk 0 (whole), the weight tiles of K-tiles 0..2, the first three row pieces of chunk 1
+    auto stage_rows = [&](int aslot, int first, int last) {
+      for (int j = first; j <= last; ++j) {
+        if (j < 4) { glds_set_m0(lds_base + A_RING + aslot * A_HALO_BYTES + 1024 + (wave * APW + j) * 1024); asm volatile("s_nop 0"); glds_go(a_ptr[j]); }
+        else { glds_set_m0(lds_base + A_RING + aslot * A_HALO_BYTES + wave * 256); asm volatile("s_nop 0"); glds_go_lanes16(halo_ptr); }
+      }
+    };
+    stage_rows(0, 0, 4);
+#pragma unroll
+    for (int i = 0; i < APW; ++i) a_ptr[i] += tap_akinc;
+    halo_ptr += halo_inc;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      static_for<WPW>([&](auto i_c) {
+        int pc = wave + WAVES * decltype(i_c)::value;
+        pc = pc < pc_max ? pc : pc_max;
+        piece_base = glds_set_m0_base(lds_base + t * W_BYTES + pc * 1024, tap_wbase + pc * piece_stride);
+        asm volatile("s_nop 0");
+        glds_go_s(w_voff, piece_base);
+      });
+      if (t == 2) { tap_wbase = tap_wbase0; w_voff += w_step; } else tap_wbase += tap_wstride;
+    }
+    stage_rows(1, 0, 2);
+    pipe_sync<2 * WPW + 3>();  // chunk 0 and the first weight tile have landed (two weight tiles and three row pieces may be in flight)
+#ifdef DN_FAT_STAMPS
+    dbg_c1 = __builtin_readcyclecounter();
+#endif
+    static_for<MT>([&](auto mt_c) { lds_request<decltype(mt_c)::value * 1024>(cur[decltype(mt_c)::value], a_rdh[0]); });
+    lds_request<0>(wa, w_rd);
+    lds_request<1024>(wb, w_rd);
+    int slot = 0, aslot = 0;
+    auto next_slot = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; };
+    using T_ = integral_constant<bool, true>;
+    using F_ = integral_constant<bool, false>;
+    for (int c = 0; c + 2 < chunks; ++c) {
+      ktile_h(slot, aslot, integral_constant<int, 0>{}, T_{}, T_{}, integral_constant<int, WPW + 3>{}); next_slot();
+      ktile_h(slot, aslot, integral_constant<int, 1>{}, T_{}, T_{}, integral_constant<int, WPW + 2>{}); next_slot();
+      ktile_h(slot, aslot, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, WPW>{}); next_slot();
+      aslot ^= 1;
+    }
+    // chunk C - 2: its last tap has no activation chunk left to stage; chunk C - 1: nothing left at all
+    ktile_h(slot, aslot, integral_constant<int, 0>{}, T_{}, T_{}, integral_constant<int, WPW + 3>{}); next_slot();
+    ktile_h(slot, aslot, integral_constant<int, 1>{}, T_{}, T_{}, integral_constant<int, WPW + 2>{}); next_slot();
+    ktile_h(slot, aslot, integral_constant<int, 2>{}, T_{}, F_{}, integral_constant<int, WPW>{}); next_slot();
+    aslot ^= 1;
+    ktile_h(slot, aslot, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, WPW>{}); next_slot();
+    ktile_h(slot, aslot, integral_constant<int, 1>{}, F_{}, F_{}, integral_constant<int, 0>{}); next_slot();
+    ktile_h(slot, aslot, integral_constant<int, 2>{}, F_{}, F_{}, integral_constant<int, 0>{});
+  } else {
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
   if (nkt > 2) pipe_sync<2 * PER>(); else if (nkt > 1) pipe_sync<PER>(); else pipe_sync<0>();
 #ifdef DN_FAT_STAMPS
-  const uint64_t dbg_c1 = __builtin_readcyclecounter();
+  dbg_c1 = __builtin_readcyclecounter();
 #endif
   static_for<MT>([&](auto mt_c) { lds_request<decltype(mt_c)::value * 1024>(cur[decltype(mt_c)::value], a_rd); });
   lds_request<0>(wa, w_rd);
@@ -1691,6 +1866,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     if (nkt >= 2) { ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{}); next_slot(); }
     ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{});
   }
+  }  // !HALO
   // The last K-tile still issued its cross-tile requests (stale slot, values unused).  To the compiler those registers
   // are dead the moment they are requested, so it would hand them to epilogue temporaries while the LDS data is still
   // in flight -- and the late return would overwrite them.  Drain the LDS queue with every such register as an operand.
@@ -1851,15 +2027,26 @@ static int launch_row(const DnGemmParams& p, hipStream_t s) {
   return DN_OK;
 }
 
-template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES>
+template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES, bool HALO = false>
 static void launch_fat_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES, HALO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES>), grid, dim3(64 * WAVES), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_fat_kernel<E, EPI, TAPS_INNER, NTW, WAVES, HALO>), grid, dim3(64 * WAVES), lds, s, p);
+}
+
+// Can the three taps share ONE staged copy of the activation rows (the HALO form of the 256 x 352 tile)?  Taps of one causal conv
+// with shifts (2d, d, 0), d <= 8; sequences a multiple of 256 frames long (a sequence then starts only where a tile starts: the
+// frames in front of it are the tile's halo rows, staged as zeros); at least three K-chunks.  DN_FAT_HALO=0 or bit 21 of pad_
+// switch it off (A/B timing, tests).
+static inline bool taps_share_rows(const DnGemmParams& p) {
+  static const bool env_off = getenv("DN_FAT_HALO") && atoi(getenv("DN_FAT_HALO")) == 0;
+  if (env_off || ((p.pad_ >> 21) & 1) || p.n_terms != 3 || p.T % 256 != 0 || p.K < 96) return false;
+  const DnGemmTerm &t0 = p.terms[0], &t1 = p.terms[1], &t2 = p.terms[2];
+  return !t0.shift_by_group && t2.shift == 0 && t1.shift >= 1 && t1.shift <= 8 && t0.shift == 2 * t1.shift;
 }
 
 // NTW = 11: the 256 x 352 tile (caller guarantees N % 352 == 0, BIAS epilogue); NTW = 8: the 256 x 256 tile, with one
@@ -1874,7 +2061,15 @@ static int launch_fat(const DnGemmParams& p, hipStream_t s) {
   const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
   const bool taps = terms_are_taps(p);  // tap-inner K order for the taps of one causal conv (see the kernel and terms_are_taps)
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-  if (taps) launch_fat_variant<E, EPI, true, NTW, WAVES>(p, grid, lds, s);
+  bool shared = false;
+  if constexpr (NTW == 11 && WAVES == 4 && EPI == DN_EPI_BIAS) {
+    if (taps && taps_share_rows(p)) {
+      launch_fat_variant<E, EPI, true, NTW, WAVES, true>(p, grid, lds, s);
+      shared = true;
+    }
+  }
+  if (shared) {}
+  else if (taps) launch_fat_variant<E, EPI, true, NTW, WAVES>(p, grid, lds, s);
   else launch_fat_variant<E, EPI, false, NTW, WAVES>(p, grid, lds, s);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
   DN_CHECK_LAUNCH("dn_conv_gemm (one-wave-per-SIMD tile)");

@@ -374,6 +374,36 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
         ops_.conv_gemm([(xb, W[j], (k - 1 - j) * dil) for j in range(k)], ref, T, N, bias=bias, tile=1, a_kblocked=True)
 
 
+@pytest.mark.parametrize("cin,cout,dil,B,T", [(1408, 1408, 1, 4, 512), (96, 352, 1, 3, 256), (192, 704, 2, 2, 512), (128, 352, 8, 5, 256),
+                                              (96, 352, 1, 1, 768), (160, 1056, 4, 2, 1024)])
+def test_taps_share_one_staged_copy_of_the_rows_on_the_352_tile(ops, cin, cout, dil, B, T):
+    """The 256x352 tile's shared staging (three taps of a causal conv read ONE staged copy of the tile's rows plus the 16 rows in
+    front of them; sequences a multiple of 256 frames): bit-identical to the tap-inner form that stages a shifted copy per tap,
+    row-major and K-blocked operands, and no frame of the previous sequence leaks into the first frames of the next."""
+    ops_, packing, _lib = ops
+    k = 3
+    x = seeded((B, T, cin), 31) + 3.0  # a large mean: a leak across a sequence start would be far outside the tolerance
+    w = seeded((cout, cin, k), 32, (1.0 / (cin * k)) ** 0.5)
+    b = seeded((cout,), 33, 0.1)
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+    W = packing._conv(w, _lib.DN_BF16).to(DEV)
+    bias = packing._vec(b, W.shape[1]).to(DEV)
+    xb, Wb = packing.kblock(xa), packing.kblock(W)
+    N = cout
+    outs = {}
+    for kb in (False, True):
+        terms = [(xb if kb else xa, (Wb if kb else W)[j], (k - 1 - j) * dil) for j in range(k)]
+        for shared in (None, False):
+            out = torch.full((B * T, N), float("nan"), device=DEV)
+            ops_.conv_gemm(terms, out, T, N, bias=bias, tile=4, a_kblocked=kb, w_kblocked=kb, taps_inner=True, shared_rows=shared)
+            outs[kb, shared] = out
+    ref = outs[False, False]
+    for key, out in outs.items():
+        assert torch.equal(out, ref), key
+    want = O.causal_conv1d(bf16r(x), bf16r(w), b, dil)
+    assert maxerr(ref.cpu().view(B, T, -1)[..., :cout], want) < 2e-3
+
+
 @pytest.mark.parametrize("tile", [0, 1, 3, 4])
 def test_geglu_emits_kblocked_output(ops, tile):
     """The GEGLU epilogue writing its output K-blocked for a 352-tile consumer: same values, other addresses."""
