@@ -1394,9 +1394,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // every epilogue (64 accumulator tiles, all in AGPRs).
 // WAVES = 8 (NTW = 8 only) runs the same instruction stream with TWO waves per SIMD, each on a 64 x 128 sub-tile: the partner's
 // MFMAs cover a wave's DMA-issue stalls without the segment barriers of the staggered two-group kernels.
-// HALO (256 x 352 tile, three taps of one causal conv with shifts 2d, d, 0, d <= 8, sequences a multiple of 256 frames long so that
-// a sequence starts only where a tile starts): the activation rows of a 32-element K-chunk are staged ONCE, as the tile's 256 rows
-// plus the 16 rows in front of them (zeros where the tile starts a sequence), and the three taps read them at row offsets
+// HALO (256 x 352 tile, three taps of one causal conv with shifts 2d, d, 0, d <= 8; tiles without a sequence start inside them, the
+// others run the shifted-copies loop): the activation rows of a 32-element K-chunk are staged ONCE, as the tile's 256 rows
+// plus the 16 rows in front of them (zeros for frames in front of the sequence), and the three taps read them at row offsets
 // 16 - shift -- instead of three shifted copies of the same rows.  A chunk then moves 17 + 3 x 22 KiB into LDS instead of
 // 3 x (16 + 22): the L2 -> LDS path, which this loop keeps ~70 % busy, carries 27 % less and each wave issues 23 instead of 30 DMA
 // pieces per chunk.  Same K order as TAPS_INNER (chunk-major, tap-minor), so the same bits.
@@ -1526,10 +1526,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     w_voff = (uint32_t)(srow * w_rowb + schunk * 16);
     if constexpr (HALO) {  // lanes 0..15 of wave w: rows m0 - 16 + 4 w + (lane >> 2), which land in LDS rows 4 w + (lane >> 2) of the halo piece
       const int hchunk = (lane & 3) ^ ((wave >> 1) << 1);  // the swizzle of LDS rows 8..15
-      const bool starts = m0 % p.T == 0;  // the tile's first row starts a sequence: the frames in front of it are zeros
+      const int hrow = wave * 4 + ((lane >> 2) & 3) - 16;   // row relative to the tile's first one
+      const bool before = m0 % p.T + hrow < 0;              // a frame in front of the tile's sequence: zeros
       const char* A0 = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + hchunk * 16;
-      halo_ptr = starts ? reinterpret_cast<const char*>(g_zero_page) + hchunk * 16 : A0 + (int64_t)(m0 - 16 + wave * 4 + ((lane >> 2) & 3)) * a_rowb;
-      halo_inc = starts ? 0 : tap_akinc;
+      halo_ptr = before ? reinterpret_cast<const char*>(g_zero_page) + hchunk * 16 : A0 + (int64_t)(m0 + hrow) * a_rowb;
+      halo_inc = before ? 0 : tap_akinc;
     }
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
@@ -1784,7 +1785,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
   uint64_t dbg_c1 = 0;
 #endif
   if constexpr (taps_inner) setup_taps(); else setup_term(0);
+  // A tile can share the staged rows between the taps if no sequence starts INSIDE it (a frame in front of a sequence must read as
+  // zero for the later taps and as the previous sequence's data for its own row): the tile's rows end with its first row's sequence,
+  // or what follows lies beyond M.  Other tiles of the launch run the shifted-copies loop below: same K order, same bits.
+  bool shared_rows = false;
   if constexpr (HALO) {
+    const int t_first = m0 % p.T;
+    shared_rows = t_first + BMF <= p.T || m0 + (p.T - t_first) >= p.M;
+  }
+  if constexpr (HALO) {
+  if (shared_rows) {
     using std::integral_constant;
     const int chunks = p.K / KT;  // >= 3 (launch_fat)
     {
@@ -1843,7 +1853,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     ktile_h(slot, aslot, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, WPW>{}); next_slot();
     ktile_h(slot, aslot, integral_constant<int, 1>{}, F_{}, F_{}, integral_constant<int, 0>{}); next_slot();
     ktile_h(slot, aslot, integral_constant<int, 2>{}, F_{}, F_{}, integral_constant<int, 0>{});
-  } else {
+  }
+  }
+  if (!shared_rows) {
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
@@ -1866,7 +1878,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     if (nkt >= 2) { ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{}); next_slot(); }
     ktile(slot, integral_constant<bool, false>{}, integral_constant<int, 0>{});
   }
-  }  // !HALO
+  }  // !shared_rows
   // The last K-tile still issued its cross-tile requests (stale slot, values unused).  To the compiler those registers
   // are dead the moment they are requested, so it would hand them to epilogue temporaries while the LDS data is still
   // in flight -- and the late return would overwrite them.  Drain the LDS queue with every such register as an operand.
@@ -2039,12 +2051,12 @@ static void launch_fat_variant(const DnGemmParams& p, dim3 grid, int lds, hipStr
 }
 
 // Can the three taps share ONE staged copy of the activation rows (the HALO form of the 256 x 352 tile)?  Taps of one causal conv
-// with shifts (2d, d, 0), d <= 8; sequences a multiple of 256 frames long (a sequence then starts only where a tile starts: the
-// frames in front of it are the tile's halo rows, staged as zeros); at least three K-chunks.  DN_FAT_HALO=0 or bit 21 of pad_
-// switch it off (A/B timing, tests).
+// with shifts (2d, d, 0), d <= 8; at least three K-chunks.  The kernel decides per tile: one with a sequence start inside runs the
+// shifted-copies loop (with sequences a multiple of 256 frames long no tile has one).  DN_FAT_HALO=0 or bit 21 of pad_ switch it
+// off (A/B timing, tests).
 static inline bool taps_share_rows(const DnGemmParams& p) {
   static const bool env_off = getenv("DN_FAT_HALO") && atoi(getenv("DN_FAT_HALO")) == 0;
-  if (env_off || ((p.pad_ >> 21) & 1) || p.n_terms != 3 || p.T % 256 != 0 || p.K < 96) return false;
+  if (env_off || ((p.pad_ >> 21) & 1) || p.n_terms != 3 || p.K < 96) return false;
   const DnGemmTerm &t0 = p.terms[0], &t1 = p.terms[1], &t2 = p.terms[2];
   return !t0.shift_by_group && t2.shift == 0 && t1.shift >= 1 && t1.shift <= 8 && t0.shift == 2 * t1.shift;
 }

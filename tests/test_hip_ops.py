@@ -375,11 +375,15 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
 
 
 @pytest.mark.parametrize("cin,cout,dil,B,T", [(1408, 1408, 1, 4, 512), (96, 352, 1, 3, 256), (192, 704, 2, 2, 512), (128, 352, 8, 5, 256),
-                                              (96, 352, 1, 1, 768), (160, 1056, 4, 2, 1024)])
+                                              (96, 352, 1, 1, 768), (160, 1056, 4, 2, 1024),
+                                              # sequences that are not whole tiles: tiles with a start inside run the shifted-copies loop, the
+                                              # others share (T = 1270: the tile at row 1280 starts 10 frames into a sequence, d = 8)
+                                              (192, 704, 1, 3, 100), (64, 352, 2, 2, 300), (96, 352, 1, 3, 700), (96, 352, 8, 2, 1270),
+                                              (128, 352, 4, 7, 263)])
 def test_taps_share_one_staged_copy_of_the_rows_on_the_352_tile(ops, cin, cout, dil, B, T):
     """The 256x352 tile's shared staging (three taps of a causal conv read ONE staged copy of the tile's rows plus the 16 rows in
-    front of them; sequences a multiple of 256 frames): bit-identical to the tap-inner form that stages a shifted copy per tap,
-    row-major and K-blocked operands, and no frame of the previous sequence leaks into the first frames of the next."""
+    front of them; decided per tile): bit-identical to the tap-inner form that stages a shifted copy per tap, row-major and
+    K-blocked operands, and no frame of the previous sequence leaks into the first frames of the next."""
     ops_, packing, _lib = ops
     k = 3
     x = seeded((B, T, cin), 31) + 3.0  # a large mean: a leak across a sequence start would be far outside the tolerance
