@@ -81,6 +81,18 @@ __device__ __forceinline__ void glds_go_lanes16(const void* src) {
                : "v"(src)
                : "memory");
 }
+// glds16 from the lanes of `mask` only (a sub-piece of fewer than 16 rows).
+__device__ __forceinline__ void glds16_lanes(const void* src, uint32_t lds_addr, uint64_t mask) {
+  uint32_t keep;
+  uint64_t keepx;
+  const uint32_t ml = __builtin_amdgcn_readfirstlane((uint32_t)mask), mh = __builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32));
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(keepx)
+      : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "s"(((uint64_t)mh << 32) | ml)
+      : "memory");
+}
 // saddr form.  Hazard the compiler cannot see through inline asm: an SGPR written by a VALU instruction
 // (v_readfirstlane, which is how a uniform value computed in VGPRs reaches an "s" operand) needs 5 wait states before
 // a VMEM instruction reads it.  So the base is first copied by a SALU instruction -- in the M0 statement, one MFMA gap
@@ -831,8 +843,11 @@ constexpr int ROWB2 = 64;
 // them padding).  The weight tile's 12 staging pieces go 2 per wave to waves 0-3 and 1 per wave to waves 4-7, so the two wave
 // groups count different numbers of DMA pieces per stage.  Epilogues whose bookkeeping assumes 64-aligned wave columns (the
 // split norm's producer) do not run on it.
-template <typename E, int EPI, bool TAPS, int BNB = 256>
+// HALO (TAPS, three taps with shifts 2d, d, 0): as on the 256 x 352 tile, the taps share one staged copy of the tile's rows plus
+// the H = 16 * ceil(2d / 16) rows in front of them (decided per tile and, with shifts scaled by the group, per group: 2d <= 128).
+template <typename E, int EPI, bool TAPS, int BNB = 256, bool HALO = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParams p) {
+  static_assert(!HALO || (TAPS && BNB == 256 && !std::is_same<E, BF16X3>::value), "shared staging: tap-inner order on the 256 x 256 tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
@@ -906,6 +921,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   int tap_shift = 0, tap_shift0 = 0, tap_sstep = 0;
   int64_t tap_delta = 0, tap_delta0 = 0, tap_dstep = 0, tap_woff = 0, tap_wstride = 0;
   int tap_ainc = ROWB2;
+  [[maybe_unused]] const char* halo_ptr = nullptr;  // HALO: this lane's row of the rows in front of the tile, or the zero page
+  [[maybe_unused]] int halo_inc = 0, halo_rows = 0, a_rdh[3] = {0, 0, 0};  // a_rdh: per tap, this lane's fragment offset inside an activation slot
+  [[maybe_unused]] uint64_t halo_mask = 0;
   auto setup_taps = [&]() {
     const DnGemmTerm& t0 = p.terms[0];
     const DnGemmTerm& t1 = p.terms[1];
@@ -924,6 +942,22 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     for (int i = 0; i < 2; ++i) {
       a_ptr[i] = A + (int64_t)a_row[i] * a_rowb;
       w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
+    }
+    if constexpr (HALO) {  // wave w stages halo rows [w H/8, (w + 1) H/8), four lanes per row
+      halo_rows = (2 * sh1 + 15) / 16 * 16;
+      const int per_wave = halo_rows >> 3;
+      const int R = wave * per_wave + (lane >> 2);           // LDS row of the activation slot
+      const int hchunk = (lane & 3) ^ (((R >> 3) & 1) << 1);
+      const bool before = m0 % p.T + R - halo_rows < 0;      // a frame in front of the tile's sequence: zeros
+      const char* A0 = reinterpret_cast<const char*>(t0.A) + (t0.a_gstride * g) * ES + hchunk * 16;
+      halo_ptr = before ? reinterpret_cast<const char*>(g_zero_page) + hchunk * 16 : A0 + (int64_t)(m0 + R - halo_rows) * a_rowb;
+      halo_inc = before ? 0 : tap_ainc;
+      halo_mask = per_wave >= 16 ? ~0ull : (1ull << (4 * per_wave)) - 1;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int row = halo_rows + wm * 64 + (lane & 15) - (2 - t) * sh1;
+        a_rdh[t] = row * ROWB2 + (((lane >> 4) ^ (((row >> 3) & 1) << 1)) << 4);
+      }
     }
   };
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
@@ -1018,6 +1052,35 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   const RowSsqReq rs_req = row_scale_request<EPI>(p, m0 + wm * 64, lane);
   if constexpr (TAPS) setup_taps(); else setup_term(0);
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  // (HALO) can this tile share the staged rows between the taps?  No sequence start inside it, and a halo of at most 128 rows
+  bool shared_rows = false;
+  if constexpr (HALO) {
+    const int t_first = m0 % p.T;
+    shared_rows = halo_rows <= 128 && (t_first + BMB <= p.T || m0 + (p.T - t_first) >= p.M);
+  }
+  if constexpr (HALO) {
+    if (shared_rows) {  // chunk 0 (rows, halo), the weight tiles of K-tiles 0..2
+      const uint32_t abase = lds_base + STAGES * TILE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        glds16(a_ptr[i], abase + halo_rows * ROWB2 + wave * 2048 + i * 1024);
+        a_ptr[i] += tap_ainc;
+      }
+      glds16_lanes(halo_ptr, abase + wave * (halo_rows >> 3) * ROWB2, halo_mask);
+      halo_ptr += halo_inc;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(w_ptr[i] + tap_woff, lds_base + t * TILE + wave * 2048 + i * 1024);
+        tap_woff += tap_wstride;
+      }
+      tap_woff = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w_ptr[i] += w_inc;
+      pipe_sync<4>();  // chunk 0 and the first weight tile have landed
+    }
+  }
+  if (!shared_rows) {
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nkt) stage(st);
@@ -1025,6 +1088,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     if (nkt > 2) pipe_sync<2 * PER_LATE>(); else if (nkt > 1) pipe_sync<PER_LATE>(); else pipe_sync<0>();
   } else {
     if (nkt > 2) pipe_sync<2 * PER_STAGE>(); else if (nkt > 1) pipe_sync<PER_STAGE>(); else pipe_sync<0>();
+  }
   }
   const float row_scale = row_scale_finish(p, rs_req);
   __builtin_amdgcn_sched_barrier(0);
@@ -1076,7 +1140,78 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
     ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill, P0{});
     }
   };
-  if (late) run(std::true_type{}); else run(std::false_type{});
+  // ---- HALO form.  LDS: a 4-slot ring of weight K-tiles (16 KiB each) and two activation slots of up to 24 KiB ([H halo rows ; 256
+  // tile rows] x 64 bytes); K-tile kt = tap kt % 3 of chunk kt / 3 stages the weight tile of K-tile kt + 3 (2 pieces per wave) and,
+  // tap 0: the wave's two row pieces of chunk c + 1, tap 1: its share of that chunk's halo (into the slot of chunk c - 1, last
+  // read by K-tile 3c - 1).  Chunk c + 1 is first read by K-tile 3c + 3, so the counted wait that closes tap 2 leaves only that
+  // K-tile's own two pieces in flight; the other two waits leave everything issued after the next K-tile's weights.
+  constexpr int A_RING = STAGES * TILE, A_SLOT = (256 + 128) * ROWB2;
+  [[maybe_unused]] auto ktile_h = [&](auto late_c, auto tap_c, auto stage_c, auto sync_c, int slot, int fill, int aslot) {
+    constexpr bool LATE = decltype(late_c)::value, STAGE = decltype(stage_c)::value;
+    constexpr int TAP = decltype(tap_c)::value, SYNC = decltype(sync_c)::value;
+    // ---- L segment
+    {
+      const char* sw = smem + slot * TILE;
+      const char* sa = smem + A_RING + aslot * A_SLOT + a_rdh[TAP];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) wf[i] = *reinterpret_cast<const uint4*>(sw + w_rd + i * 16 * ROWB2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + i * 16 * ROWB2);
+    }
+    if constexpr (STAGE) {
+      const uint32_t wbase = lds_base + fill * TILE + wave * 2048;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(w_ptr[i] + tap_woff, wbase + i * 1024);
+      if constexpr (TAP == 2) {
+        tap_woff = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_ptr[i] += w_inc;
+      } else {
+        tap_woff += tap_wstride;
+      }
+      const uint32_t abase = lds_base + A_RING + (aslot ^ 1) * A_SLOT;
+      if constexpr (TAP == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          glds16(a_ptr[i], abase + halo_rows * ROWB2 + wave * 2048 + i * 1024);
+          a_ptr[i] += tap_ainc;
+        }
+      }
+      if constexpr (TAP == 1) {
+        glds16_lanes(halo_ptr, abase + wave * (halo_rows >> 3) * ROWB2, halo_mask);
+        halo_ptr += halo_inc;
+      }
+    }
+    if constexpr (LATE) pipe_sync<SYNC>(); else pipe_sync<63>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C segment
+    __builtin_amdgcn_s_setprio(1);
+    mma_all(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LATE) pipe_sync<63>(); else pipe_sync<SYNC>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  [[maybe_unused]] auto run_h = [&](auto late_c) {
+    using std::integral_constant;
+    using T0 = integral_constant<int, 0>; using T1 = integral_constant<int, 1>; using T2 = integral_constant<int, 2>;
+    int slot = 0, fill = STAGES - 1, aslot = 0;
+    auto adv = [&]() { slot = slot == STAGES - 1 ? 0 : slot + 1; fill = fill == STAGES - 1 ? 0 : fill + 1; };
+    const int chunks = ktiles_per_term;  // >= 2 (launch_big)
+    for (int c = 0; c + 1 < chunks; ++c) {
+      ktile_h(late_c, T0{}, std::true_type{}, integral_constant<int, 6>{}, slot, fill, aslot); adv();
+      ktile_h(late_c, T1{}, std::true_type{}, integral_constant<int, 7>{}, slot, fill, aslot); adv();
+      ktile_h(late_c, T2{}, std::true_type{}, integral_constant<int, 2>{}, slot, fill, aslot); adv();
+      aslot ^= 1;
+    }
+    ktile_h(late_c, T0{}, std::false_type{}, integral_constant<int, 3>{}, slot, fill, aslot); adv();
+    ktile_h(late_c, T1{}, std::false_type{}, integral_constant<int, 0>{}, slot, fill, aslot); adv();
+    ktile_h(late_c, T2{}, std::false_type{}, integral_constant<int, 0>{}, slot, fill, aslot);
+  };
+  if (!shared_rows) { if (late) run(std::true_type{}); else run(std::false_type{}); }
+  if constexpr (HALO) {
+    if (shared_rows) { if (late) run_h(std::true_type{}); else run_h(std::false_type{}); }
+  }
   if (!late) pipe_sync<63>();
 
   // ---- epilogue: two 64 x 64 halves of the wave's 64 (m) x 128 (n) tile through its LDS slab
@@ -1991,15 +2126,25 @@ static inline bool terms_are_taps(const DnGemmParams& p) {
   return taps;
 }
 
-template <typename E, int EPI, bool TAPS, int BNB = 256>
+template <typename E, int EPI, bool TAPS, int BNB = 256, bool HALO = false>
 static void launch_big_variant(const DnGemmParams& p, dim3 grid, int lds, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI, TAPS, BNB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_big_kernel<E, EPI, TAPS, BNB, HALO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI, TAPS, BNB>), grid, dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<E, EPI, TAPS, BNB, HALO>), grid, dim3(512), lds, s, p);
+}
+
+// Shared staging of the taps' rows on the 256 x 256 tile: three taps with shifts (2d, d, 0) and at least two K-chunks; per group
+// (dilation = shift << group) and per tile the kernel falls back to shifted copies (halo over 128 rows, a sequence start inside the
+// tile).  DN_BIG_HALO=0 or bit 21 of pad_ switch it off.
+static inline bool big_taps_share_rows(const DnGemmParams& p, int kt_elems) {
+  static const bool env_off = getenv("DN_BIG_HALO") && atoi(getenv("DN_BIG_HALO")) == 0;
+  if (env_off || ((p.pad_ >> 21) & 1) || p.n_terms != 3 || p.K / kt_elems < 2) return false;
+  const DnGemmTerm &t0 = p.terms[0], &t1 = p.terms[1], &t2 = p.terms[2];
+  return t2.shift == 0 && t1.shift >= 1 && t0.shift == 2 * t1.shift && (t0.shift_by_group || 2 * t1.shift <= 128);
 }
 
 template <typename E, int EPI, int BNB = 256>
@@ -2013,7 +2158,8 @@ static int launch_big(const DnGemmParams& p, hipStream_t s) {
   bool tapped = false;
   if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_FILM_GATE) && !std::is_same<E, BF16X3>::value && BNB == 256) {  // the epilogues a causal conv has (CausalConv1d + bias; the WaveNet block); split operands pair K-tiles along a row: term-outer only
     if (terms_are_taps(p)) {
-      launch_big_variant<E, EPI, true>(p, grid, lds, s);
+      if (big_taps_share_rows(p, ROWB2 / Elem<E>::bytes)) launch_big_variant<E, EPI, true, 256, true>(p, grid, lds, s);
+      else launch_big_variant<E, EPI, true>(p, grid, lds, s);
       tapped = true;
     }
   }

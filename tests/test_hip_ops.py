@@ -408,6 +408,44 @@ def test_taps_share_one_staged_copy_of_the_rows_on_the_352_tile(ops, cin, cout, 
     assert maxerr(ref.cpu().view(B, T, -1)[..., :cout], want) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("cin,cout,B,T,L", [(64, 128, 3, 512, 8), (128, 256, 2, 700, 8), (64, 64, 5, 263, 4), (96, 352, 2, 1270, 6)])
+def test_taps_share_one_staged_copy_of_the_rows_on_the_256_tile(ops, dtype, cin, cout, B, T, L):
+    """The 256x256 tile's shared staging over a stack of dilated convs (dilation 2^group: halos of 16 .. 128 rows, the 256-row
+    halo of group 7 and tiles with a sequence start inside fall back to shifted copies): bit-identical to the shifted-copies
+    form for every group, against the oracle, plain (one group, fixed dilation) and grouped launches."""
+    ops_, packing, _lib = ops
+    code = _lib.DN_BF16 if dtype == "bf16" else _lib.DN_F32
+    rnd = bf16r if dtype == "bf16" else (lambda z: z)
+    k = 3
+    x = seeded((B, T, cin), 41) + 3.0
+    ws = [seeded((cout, cin, k), 50 + i, (1.0 / (cin * k)) ** 0.5) for i in range(L)]
+    bs = torch.stack([seeded((cout,), 70 + i, 0.1) for i in range(L)])
+    M, Np = B * T, padk(cout)
+    xa = act(pad_cols(x, padk(cin)).view(M, -1), dtype)
+    W = torch.stack([packing._conv(w, code) for w in ws]).to(DEV)  # [L, 3, rows, K]
+    bias = torch.stack([packing._vec(b, W.shape[2]) for b in bs]).to(DEV)
+    terms = [(xa, W[:, j].contiguous(), k - 1 - j) for j in range(k)]
+    outs = {}
+    for shared in (None, False):
+        out = torch.full((L, M, Np), float("nan"), device=DEV)
+        ops_.conv_gemm(terms, out, T, Np, bias=bias, groups=L, a_grouped=False, shift_by_group=True, tile=3, taps_inner=True, shared_rows=shared)
+        outs[shared] = out
+    assert torch.equal(outs[None], outs[False])
+    tol = 2e-3 if dtype == "bf16" else 1e-4
+    for i in range(L):
+        want = O.causal_conv1d(rnd(x), rnd(ws[i]), bs[i], 2 ** i)
+        assert maxerr(outs[None][i].cpu().view(B, T, -1)[..., :cout], want) < tol, i
+    # one group at a fixed dilation (the plain CausalConv1d call)
+    for dil in (1, 8, 32, 64):
+        t1 = [(xa, W[2, j].contiguous(), (k - 1 - j) * dil) for j in range(k)]
+        a, b_ = torch.empty((M, Np), device=DEV), torch.empty((M, Np), device=DEV)
+        ops_.conv_gemm(t1, a, T, Np, bias=bias[2], tile=3, taps_inner=True)
+        ops_.conv_gemm(t1, b_, T, Np, bias=bias[2], tile=3, taps_inner=True, shared_rows=False)
+        assert torch.equal(a, b_), dil
+        assert maxerr(a.cpu().view(B, T, -1)[..., :cout], O.causal_conv1d(rnd(x), rnd(ws[2]), bs[2], dil)) < tol, dil
+
+
 @pytest.mark.parametrize("tile", [0, 1, 3, 4])
 def test_geglu_emits_kblocked_output(ops, tile):
     """The GEGLU epilogue writing its output K-blocked for a 352-tile consumer: same values, other addresses."""
