@@ -1,6 +1,6 @@
 # Round-3 evidence, one gpurun call: the default bench line, rocprofv3 per-shape summaries (bf16 one stream / two streams, bf16x3,
 # both training losses) and the PMC passes (counters only, one counter per run) for the step traffic and the dominant kernels of
-# the bf16 and bf16x3 chains.  Everything lands under gpurun_out/r03/; the summaries are copied to profiles/ by hand.
+# the bf16 and bf16x3 chains.  Everything lands under gpurun_out/r03/; tools/publish_profiles_r03.py copies the summaries to profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -15,6 +15,7 @@ LEGS="--no-cpu-baseline --no-full-chain --no-f32 --no-x3 --no-train --no-refine 
 prof() {  # name, bench flags
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$1 -o bench -- python3 $R/bench.py $2 > $O/rocprof_$1.json 2> $O/rocprof_$1.err
   python tools/summarize_trace.py $(find $O/prof_$1 -name "*kernel_trace.csv" | head -1) > $O/per_shape_$1.txt
+  python tools/step_sequence.py $(find $O/prof_$1 -name "*kernel_trace.csv" | head -1) > $O/step_sequence_$1.txt 2>/dev/null || true
   cp $(find $O/prof_$1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$1.csv
   find $O/prof_$1 -name "*.csv" -size +1M -delete
   echo "profile $1 done"
