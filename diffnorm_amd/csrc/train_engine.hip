@@ -187,7 +187,34 @@ struct DnVaeTrain {
 
 namespace {
 
+// Second stream for the weight gradients of a transformer layer (leaves of the backward: nothing downstream reads them before the
+// layer's gradient range is handed to the all-reduce).  Their contractions are 144 / 192-tile launches that leave a quarter to
+// half of the CUs idle, and each is preceded by its operand transposes; on a stream of their own they run beside the
+// data-gradient chain.  Fork: the side stream waits for an event recorded on the main stream when the call is made (its dY operand
+// has been enqueued by then).  Join: the main stream waits for the weight gradient's `done` event before it overwrites one of its
+// operands, and for the last one at the end of the layer.  One process-wide stream (the shared scratch serialises the weight
+// gradients on it); DN_WGRAD_STREAM=0 keeps everything on the caller's stream (read per step).
+struct WgSide {
+  hipStream_t s = nullptr;
+  hipEvent_t ready = nullptr, done[8] = {};
+  int next = 0;
+};
+WgSide* wg_side() {
+  static WgSide side;
+  static bool tried = false, ok = false;
+  const char* e = getenv("DN_WGRAD_STREAM");
+  if (e && atoi(e) == 0) return nullptr;
+  if (!tried) {
+    tried = true;
+    ok = hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&side.ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&side.done[i], hipEventDisableTiming) == hipSuccess;
+  }
+  return ok ? &side : nullptr;
+}
+
 struct Ctx {
+  WgSide* side = nullptr;  // weight gradients that pass a handle run here (transformer layers)
   const float* master;  // fp32 parameters (vectors are read from here in every mode)
   const void* work;     // the same layout in the arithmetic dtype (matrices)
   char* aux;            // transposed matrices, then derived fp32 vectors
@@ -250,9 +277,32 @@ void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int 
                      pl.cols_total, static_cast<T*>(dst), rows, rows_total, row0, pl.chunk);
 }
 
-// grad[tap][Np][Kp] += dY^T . shift_tap(X_tap); dY [M, lddy] (cout valid columns), X_tap [M, ldx] (cin valid columns)
-int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad, int tag = 0) {
-  if (c.frozen) return DN_OK;
+// main stream: wait for weight gradient `handle` (weight_grad's `overlap` result; < 0: it ran on the main stream)
+int wg_wait(const Ctx& c, int handle) {
+  if (handle < 0 || !c.side) return DN_OK;
+  return hipStreamWaitEvent(c.s, c.side->done[handle], 0) == hipSuccess ? DN_OK : DN_ELAUNCH;
+}
+
+// grad[tap][Np][Kp] += dY^T . shift_tap(X_tap); dY [M, lddy] (cout valid columns), X_tap [M, ldx] (cin valid columns).
+// overlap != nullptr: run on the side stream if there is one and return the handle to wait on (wg_wait) before dY or X is
+// overwritten and before the gradient is used; -1 = it ran on c.s.
+int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad, int tag = 0,
+                int* overlap = nullptr) {
+  if (overlap) *overlap = -1;
+  if (c0.frozen) return DN_OK;
+  Ctx c = c0;
+  WgSide* const side = overlap ? c0.side : nullptr;
+  if (side) {
+    if (hipEventRecord(side->ready, c0.s) != hipSuccess || hipStreamWaitEvent(side->s, side->ready, 0) != hipSuccess) return DN_ELAUNCH;
+    c.s = side->s;
+  }
+  auto finish = [&](int rc) {
+    if (rc != DN_OK || !side) return rc;
+    const int h = side->next++ & 7;
+    if (hipEventRecord(side->done[h], side->s) != hipSuccess) return (int)DN_ELAUNCH;
+    *overlap = h;
+    return rc;
+  };
   int max_shift = 0;
   for (int j = 0; j < n_taps; ++j) max_shift = taps[j].shift > max_shift ? taps[j].shift : max_shift;
   const WgPlan pl = plan_wgrad(cin, cout, n_taps, max_shift, c.B, c.T, c.es);
@@ -279,7 +329,7 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
     p.epilogue = DN_EPI_RESADD; p.res = grad; p.ldr = Kp; p.res_gstride = (int64_t)Np * Kp;
     p.out = grad; p.ldo = Kp; p.out_dtype = DN_F32; p.out_gstride = (int64_t)Np * Kp;
     p.pad_ = tag << 8;
-    return dn_conv_gemm(&p, c.s);
+    return finish(dn_conv_gemm(&p, c.s));
   }
   DnGemmParams p = gemm_base(c.dtype, cout, pl.N, pl.chunk, cout);
   p.groups = pl.k_slices;
@@ -288,7 +338,7 @@ int weight_grad(const Ctx& c, const WgTap* taps, int n_taps, int cin, const void
   p.out = part; p.ldo = pl.N; p.out_dtype = DN_F32; p.out_gstride = (int64_t)cout * pl.N;
   p.pad_ = tag << 8;
   DN_TRY(dn_conv_gemm(&p, c.s));
-  return dn_wgrad_reduce(part, pl.k_slices, cout, pl.N, pl.rows_w, n_taps, grad, padn(cout), padk(cin), c.s);
+  return finish(dn_wgrad_reduce(part, pl.k_slices, cout, pl.N, pl.rows_w, n_taps, grad, padn(cout), padk(cin), c.s));
 }
 
 int bias_grad(const Ctx& c, const void* dy, int ld, int dtype, int groups, int rows_per_group, int C, float* grad, int out_ld) {
@@ -632,16 +682,21 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   const void* fc = eoff(sv.fc, (size_t)l * M * ip, es);
   const bool ada = gb && w.cond_col >= 0;
   const size_t col1 = ada ? w.cond_col + (size_t)(2 * l) * 2 * Dp : 0, col2 = col1 + 2 * Dp;
+  // weight gradients on the side stream (WgSide): their operands are this layer's temporaries, so the chain waits for
+  //   h_ffout before ff_norm's backward rewrites tb.dx_act, h_out before attn_norm's backward does, and for the last one (the side
+  //   stream runs in order) at the end of the layer -- the next layer rewrites tb.d_fc / d_pre / d_qkv, and the caller hands this
+  //   layer's gradient range to the all-reduce.
+  int h_ffout = -1, h_out = -1, h_last = -1;
   {  // Linear(inner -> D) (:902)
     WgTap tap{fc, ip, 0};
-    DN_TRY(weight_grad(c, &tap, 1, w.inner, tb.dx_act, Dp, D, c.G(w.ffout_W(l))));
+    DN_TRY(weight_grad(c, &tap, 1, w.inner, tb.dx_act, Dp, D, c.G(w.ffout_W(l)), 0, &h_ffout));
     DN_TRY(bias_grad(c, tb.dx, Dp, DN_F32, 1, M, Dp, c.G(w.ffout_b(l)), 0));
     DN_TRY(linear_dgrad(c, tb.dx_act, Dp, Dp, eoff(c.Wt(w.t_ffout), (size_t)l * padn(ip) * Dp, es), tb.d_fc, ip, dtype));
   }
   {  // CausalConv1d(inner, inner, 3) (:894)
     WgTap taps[3];
     for (int j = 0; j < 3; ++j) taps[j] = WgTap{gg, ip, 2 - j};
-    DN_TRY(weight_grad(c, taps, 3, w.inner, tb.d_fc, ip, w.inner, c.G(w.ffconv_W(l)), DN_TAG_FFN_CONV_WGRAD));
+    DN_TRY(weight_grad(c, taps, 3, w.inner, tb.d_fc, ip, w.inner, c.G(w.ffconv_W(l)), DN_TAG_FFN_CONV_WGRAD, &h_last));
     DN_TRY(bias_grad(c, tb.d_fc, ip, dtype, 1, M, ip, c.G(w.ffconv_b(l)), 0));
     DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
     p.n_terms = 3;
@@ -655,17 +710,18 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   DN_TRY(dn_geglu_backward(tb.d_gg, pre, tb.d_pre, dtype, M, ip, c.s));  // (:881-884)
   {  // Linear(D -> 2*inner) (:899), packed columns
     WgTap tap{xn2, Dp, 0};
-    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_pre, 2 * ip, 2 * ip, c.G(w.ffin_W(l))));
+    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_pre, 2 * ip, 2 * ip, c.G(w.ffin_W(l)), 0, &h_last));
     DN_TRY(bias_grad(c, tb.d_pre, 2 * ip, dtype, 1, M, 2 * ip, c.G(w.ffin_b(l)), 0));
     DN_TRY(linear_dgrad(c, tb.d_pre, 2 * ip, 2 * ip, eoff(c.Wt(w.t_ffin), (size_t)l * padn(Dp) * 2 * ip, es), tb.d_xn, Dp, dtype));
   }
   // ff_norm (:703): d xmid = d x[l+1] + norm'(xmid) d xn2
+  DN_TRY(wg_wait(c, h_ffout));
   DN_TRY(dn_rmsnorm_backward(xmid, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g2(l)), ada ? gb + col2 : nullptr, gb_ld, Dp, tb.dx,
                              tb.dx, tb.dx_act, dtype, Dp, (ada || c.frozen) ? nullptr : c.G(w.g2(l)), ada ? d_gb + col2 : nullptr, gb_ld,
                              c.red_scratch, c.s));
   {  // to_out (:932)
     WgTap tap{ao, hd, 0};
-    DN_TRY(weight_grad(c, &tap, 1, hd, tb.dx_act, Dp, D, c.G(w.out_W(l))));
+    DN_TRY(weight_grad(c, &tap, 1, hd, tb.dx_act, Dp, D, c.G(w.out_W(l)), 0, &h_out));
     DN_TRY(linear_dgrad(c, tb.dx_act, Dp, Dp, eoff(c.Wt(w.t_out), (size_t)l * padn(hd) * Dp, es), tb.d_ao, hd, dtype));
   }
   {  // Attend (:299-343)
@@ -682,13 +738,15 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   }
   {  // to_q ; to_kv (:930-931)
     WgTap tap{xn1, Dp, 0};
-    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_qkv, 3 * hd, 3 * hd, c.G(w.qkv_W(l))));
+    DN_TRY(weight_grad(c, &tap, 1, D, tb.d_qkv, 3 * hd, 3 * hd, c.G(w.qkv_W(l)), 0, &h_last));
     DN_TRY(linear_dgrad(c, tb.d_qkv, 3 * hd, 3 * hd, eoff(c.Wt(w.t_qkv), (size_t)l * padn(Dp) * 3 * hd, es), tb.d_xn, Dp, dtype));
   }
   // attn_norm (:691)
-  return dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g1(l)), ada ? gb + col1 : nullptr, gb_ld, Dp, tb.dx, tb.dx,
+  DN_TRY(wg_wait(c, h_out));
+  DN_TRY(dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g1(l)), ada ? gb + col1 : nullptr, gb_ld, Dp, tb.dx, tb.dx,
                              tb.dx_act, dtype, Dp, (ada || c.frozen) ? nullptr : c.G(w.g1(l)), ada ? d_gb + col1 : nullptr, gb_ld, c.red_scratch,
-                             c.s);
+                             c.s));
+  return wg_wait(c, h_last);
 }
 
 // ------------------------------------------------------------------------------------------ workspace plan
@@ -782,6 +840,7 @@ Ctx make_ctx(const DnVaeTrain* m, int B, int T, const VaePlan& pl, hipStream_t s
   c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = frozen;
   c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
   c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  c.side = frozen ? nullptr : wg_side();
   return c;
 }
 
@@ -1287,6 +1346,7 @@ Ctx eps_ctx(const DnEpsTrain* m, int B, int T, const EpsPlan& pl, hipStream_t s)
   c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = false;
   c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
   c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  c.side = wg_side();
   return c;
 }
 

@@ -397,6 +397,45 @@ def test_diffusion_gradients_bf16_follow_the_oracle(golden):
     assert dot / (n1 * n2) > 0.995 and abs(float(n1 / n2) - 1) < 5e-2
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_weight_gradients_on_the_side_stream_change_nothing(golden, dtype, monkeypatch):
+    """The transformer layers' weight gradients run on a second stream beside the data-gradient chain (train_engine.hip: WgSide);
+    DN_WGRAD_STREAM=0 keeps them on the caller's stream.  Same kernels, same reductions: the flat gradient buffers agree bit for
+    bit, whole and staged backward, VAE and diffusion step, over repeated runs (a missing wait would show as a difference)."""
+    g = golden("vae_train")
+    feat, units, lens = _batch(g)
+    noise = torch.from_numpy(g["post_noise"])
+    eng, _ = _engine(dtype)
+    grads = {}
+    for mode in ("0", "1", "1", "0", "1"):
+        monkeypatch.setenv("DN_WGRAD_STREAM", mode)
+        eng.forward(feat, units, lens, noise=noise)
+        eng.zero_grad()
+        if mode == "1" and "staged" not in grads:
+            for st in range(eng.n_stages):
+                eng.backward(st, st)
+            grads["staged"] = eng.grads.clone()
+        else:
+            eng.backward()
+        torch.cuda.synchronize()
+        grads.setdefault(mode, eng.grads.clone())
+        assert torch.equal(eng.grads, grads["0"]), mode
+    assert torch.equal(grads["staged"], grads["0"])
+    ge = golden("eps_train")
+    eps, vae, esd, vsd, ecfg = _eps_setup(dtype)
+    T = lambda k: torch.from_numpy(ge[k])
+    z = O.vae_encode(vsd, CFG, feat, T("post_noise"))
+    ref = None
+    for mode in ("0", "1", "1", "0", "1"):
+        monkeypatch.setenv("DN_WGRAD_STREAM", mode)
+        eps.forward(feat, torch.from_numpy(ge["units"]), torch.from_numpy(ge["lens"]), z, T("times"), T("jitter"), T("true_noise"))
+        eps.zero_grad()
+        eps.backward()
+        torch.cuda.synchronize()
+        ref = eps.grads.clone() if ref is None else ref
+        assert torch.equal(eps.grads, ref), mode
+
+
 def _grads_close(got, want, rtol):
     total = float(torch.sqrt(sum(v.double().pow(2).sum() for v in want.values())))
     worst = 0.0
