@@ -642,15 +642,28 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
         assert torch.isfinite(logged).all().item() and torch.isfinite(norm).item(), "training diverged"
         # the dominant backward kernel, timed where it runs: HIP events around the FFN causal conv's weight-gradient contraction
         # (one per transformer layer of the trained model) inside two more updates of the first batch shape
+        # Twice: as the updates above ran it (on the second stream beside the data-gradient chain -- train_engine.hip: WgSide -- so
+        # the events also span the launches it shares the GPU with), and alone on the caller's stream (DN_WGRAD_STREAM=0): the
+        # kernel's own rate, which is what the roofline object quotes.
         lib = _lib.load()
-        _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV_WGRAD, 24), "dn_profile_start")
-        for _ in range(2):
-            if kind == "vae":
-                tr.train_step([batches[0]], noises=[("philox", 7 + rank, 1 << 40)])
-            else:
-                tr.train_step([batches[0]])
-        k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
-        _lib.check(lib.dn_profile_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "dn_profile_stop")
+        timed = {}
+        for mode in ("overlapped", "alone"):
+            prev = os.environ.get("DN_WGRAD_STREAM")
+            if mode == "alone":
+                os.environ["DN_WGRAD_STREAM"] = "0"
+            try:
+                _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV_WGRAD, 24), "dn_profile_start")
+                for _ in range(2):
+                    if kind == "vae":
+                        tr.train_step([batches[0]], noises=[("philox", 7 + rank, 1 << 40)])
+                    else:
+                        tr.train_step([batches[0]])
+                k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+                _lib.check(lib.dn_profile_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "dn_profile_stop")
+                timed[mode] = k_ms.value
+            finally:
+                if mode == "alone":
+                    os.environ.pop("DN_WGRAD_STREAM") if prev is None else os.environ.__setitem__("DN_WGRAD_STREAM", prev)
         ar_ms = 0.0
         if world > 1:  # all-reduce time of one update (buckets timed with events on the side stream)
             tr.reducer.measure = True
@@ -659,7 +672,7 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
             tr.reducer.measure = False
     ip = (inner + 63) // 64 * 64
     return {"dt": dt, "sent": float(sent), "toks": float(toks), "frames": float(frames), "flops": flops, "ar_ms": ar_ms,
-            "k_flops": 2.0 * ip * (3 * ip) * batches[0]["frames"], "k_ms": k_ms.value, "k_n": k_n.value, "k_frames": batches[0]["frames"], "inner": ip,
+            "k_flops": 2.0 * ip * (3 * ip) * batches[0]["frames"], "k_ms": timed["alone"], "k_ms_overlapped": timed["overlapped"], "k_n": k_n.value, "k_frames": batches[0]["frames"], "inner": ip,
             "loss": float(logged[0]), "grad_norm": float(norm), "buckets": len(tr.reducer.buckets), "gradient_bytes": eng.n_params * 4}
 
 
@@ -679,6 +692,9 @@ def train_summary(kind, dtype, max_tokens, K, m, world):
                                                     f"[{m['k_frames']} x {3 * m['inner']}] over the padded frames, accumulated into the fp32 gradient",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flops_per_launch": m["k_flops"],
                          "avg_launch_ms": m["k_ms"], "launches_timed": m["k_n"],
+                         "avg_launch_ms_beside_the_data_gradient_chain": m.get("k_ms_overlapped"),
+                         "timed": "alone on the caller's stream (DN_WGRAD_STREAM=0); in the measured updates it runs on a second stream beside the "
+                                  "data-gradient chain and its events span the launches it shares the GPU with",
                          "traffic": train_traffic_from_profiles() if kind == "vae" else None}}
 
 

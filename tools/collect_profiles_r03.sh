@@ -32,7 +32,7 @@ done; done
   python tools/step_traffic.py $O/pmc_$dt 10 30 > $O/step_traffic_$dt.json
 done
 python tools/pmc_summary.py "conv_gemm_fat_kernel" $O/pmc_bf16/FETCH_SIZE_30 $O/pmc_bf16/WRITE_SIZE_30 > $O/pmc_ffn_conv_bf16.json
-python tools/pmc_summary.py "conv_gemm_big_kernel<dn::BF16X3, 0, false, 256>@196608" $O/pmc_bf16x3/FETCH_SIZE_30 $O/pmc_bf16x3/WRITE_SIZE_30 > $O/pmc_ffn_conv_bf16x3.json
+python tools/pmc_summary.py "conv_gemm_big_kernel<dn::BF16X3, 0, false, 256@196608" $O/pmc_bf16x3/FETCH_SIZE_30 $O/pmc_bf16x3/WRITE_SIZE_30 > $O/pmc_ffn_conv_bf16x3.json
 python tools/step_traffic_by_kernel.py $O/pmc_bf16 > $O/step_traffic_by_kernel_bf16.txt 2>/dev/null || true
 python tools/step_traffic_by_kernel.py $O/pmc_bf16x3 > $O/step_traffic_by_kernel_bf16x3.txt 2>/dev/null || true
 find $O -name "*.csv" -size +2M -delete
