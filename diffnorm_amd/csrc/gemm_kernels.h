@@ -2111,6 +2111,10 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
 // with it the last bits, relative to the 128-byte-K-tile variants (term-outer): a batch large enough to route to these tiles and
 // a smaller one do not agree to the last bit; equal-size shards do.  DN_TAPS_INNER=0 (or DN_FAT_TAPS_INNER=0, the older name)
 // or bit 23 of pad_ restores term-outer everywhere (bit 22 forces tap-inner).
+static inline bool taps_route_by_shape() {
+  const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
+  return e && atoi(e) == 2;
+}
 static inline bool terms_are_taps(const DnGemmParams& p) {
   const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
   if (!e) e = getenv("DN_FAT_TAPS_INNER");
@@ -2293,6 +2297,10 @@ static inline int choose_tile(const DnGemmParams& p) {
     return sm > ss ? 2 : 1;
   }
   if (routes_to_352(p)) return 4;
+  // DN_TAPS_INNER=2: the taps of a causal conv run on the 64-byte-K-tile kernels (tap-inner order, shared rows) WHATEVER M is, so a
+  // batch and its shards sum every output in the same order -- bit-for-bit sharding invariance at the fast order's speed on
+  // large batches (small ones pay for 256-row tiles); the sharded driver's default (normalize.py).
+  if (force == 0 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && taps_route_by_shape() && terms_are_taps(p)) return 3;
   bool kblocked = false;
   for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
   if (kblocked) return bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them

@@ -74,15 +74,17 @@ def normalize(ddim_sample: Callable, utterances: Sequence[Utterance], start_step
     """Runs `ddim_sample(feat, input_mask=..., ref_units=..., start_step=...)` (LatentDiscreteModel.ddim_sample) over this
     rank's batches and gathers the TSV lines of all ranks in utterance order (every rank returns the full list)."""
     rank, world = sharding.rank_world(group)
-    # Sharded runs must give the results of the unsharded run whatever sizes the shards' last batches have.  The bf16 contractions'
-    # fast K order (taps of a causal conv innermost on the two 256-row tiles) sums in a different order than the small-batch tiles:
-    # a batch and its shards can differ in the last bit of an fp32 sum.  With more than one rank the shard-invariant order (every
-    # tile term-outer) is therefore the default -- about 2 % per step -- unless the caller has chosen (DN_TAPS_INNER set).  The
-    # bf16x3 and f32 modes are invariant in every order.
+    # Sharded runs must give the results of the unsharded run whatever sizes the shards' last batches have.  The bf16 / f32
+    # contractions' fast K order (taps of a causal conv innermost, one staged copy of the rows, on the two 256-row tiles) sums in a
+    # different order than the small-batch tiles: a batch and its shards can differ in the last bit of an fp32 sum when they route
+    # to different tiles.  With more than one rank the tap contractions are therefore routed by SHAPE, not by batch size
+    # (DN_TAPS_INNER=2: always the 256-row tiles and their order) -- full speed on the large batches a sharded run has, 256-row
+    # tiles on a short last batch -- unless the caller has chosen (DN_TAPS_INNER set; 0 = term-outer everywhere, the older
+    # invariant setting, about 6 % per step slower).  The bf16x3 mode is invariant by construction.
     import os
 
     if world > 1 and "DN_TAPS_INNER" not in os.environ:
-        os.environ["DN_TAPS_INNER"] = "0"
+        os.environ["DN_TAPS_INNER"] = "2"
     batches = sharding.batch_indices(len(utterances), batch_size)
     mine = sharding.my_batches(len(batches), rank, world)
     local = []

@@ -51,7 +51,8 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeyp
     (DN_TAPS_INNER=0) units and recon are identical bit for bit whatever tile variants the shard sizes route to; in the
     default order the 256x352 tile sums the FFN conv's taps innermost, so shards small enough to leave that tile (here the
     half-batch streams of an 8-utterance shard: M = 4096 rows) differ from the big batch in the last bits of fp32 sums --
-    units agree but for rare near-ties (<= 1 %), recon within the bf16 rounding level (3e-2 of its scale); (b) a truncated chain (start_step=3) on 2 utterances matches the CPU oracle
+    units agree but for rare near-ties (<= 1 %), recon within the bf16 rounding level (3e-2 of its scale); with the tap contractions
+    routed by shape (DN_TAPS_INNER=2) the fast order is invariant too; (b) a truncated chain (start_step=3) on 2 utterances matches the CPU oracle
     within the bf16 budget and agrees on units where the oracle's top-2 margin is clear."""
     from diffnorm_amd import ops
 
@@ -86,6 +87,14 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeyp
     monkeypatch.delenv("DN_TAPS_INNER")
     strict = full
     full = run(slice(0, 16))
+    # DN_TAPS_INNER=2 (the sharded driver's default): tap contractions routed by shape -> the fast order AND bit-for-bit invariance,
+    # down to single-utterance shards (the big batch's narrow convs leave the 128-byte-K-tile kernels too, so it need not equal `full`)
+    monkeypatch.setenv("DN_TAPS_INNER", "2")
+    routed = run(slice(0, 16))
+    parts = [run(slice(0, 8)), run(slice(8, 15)), run(slice(15, 16))]
+    assert torch.equal(torch.cat([q[2] for q in parts]), routed[2])
+    assert torch.equal(torch.cat([q[0] for q in parts]), routed[0])
+    monkeypatch.delenv("DN_TAPS_INNER")
     a, b = run(slice(0, 8)), run(slice(8, 16))
     valid = torch.arange(T)[None, :] < lens[:, None]
     for got in (torch.cat([a[2], b[2]]), strict[2]):  # shards vs batch, and the batch in the other K order
