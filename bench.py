@@ -119,8 +119,8 @@ def traffic_from_profiles(dtype="bf16"):
 def train_traffic_from_profiles():
     """Fabric-side bytes per launch of the training leg's roofline kernel from the committed PMC passes
     (profiles/*pmc_train_wgrad*.json); None when absent."""
-    d, _ = _latest_profile("*pmc_train_wgrad*.json")
-    return d.get("hbm_bytes_per_launch") if d else None
+    d, ok = _latest_profile("*pmc_train_wgrad*.json")
+    return d.get("hbm_bytes_per_launch") if (d and ok) else None  # (only a measurement of THIS build's kernel: round 2's was the transposed-copies form)
 
 
 def step_traffic_from_profiles(dtype="bf16"):
@@ -688,8 +688,9 @@ def train_summary(kind, dtype, max_tokens, K, m, world):
             "step_tflops_per_gpu": m["flops"] / m["dt"] / 1e12 / world, "step_mfma_frac": m["flops"] / m["dt"] / 1e12 / world / peak,
             "all_reduce_ms_per_update": m["ar_ms"], "gradient_bytes": m["gradient_bytes"], "buckets": m["buckets"],
             "final_loss": m["loss"], "grad_norm": m["grad_norm"],
-            "roofline": {"bound": "mfma", "kernel": f"dn_conv_gemm weight gradient of the FFN causal conv k=3 (inner {m['inner']}): [{m['inner']} x {m['k_frames']}] x "
-                                                    f"[{m['k_frames']} x {3 * m['inner']}] over the padded frames, accumulated into the fp32 gradient",
+            "roofline": {"bound": "mfma", "kernel": f"weight gradient of the FFN causal conv k=3 (inner {m['inner']}): [{m['inner']} x {m['k_frames']}] x "
+                                                    f"[{m['k_frames']} x {3 * m['inner']}] over the frames, straight from the row-major operands (wgrad_tn_kernel: "
+                                                    f"transposing LDS reads; DN_WGRAD_TN=0: transposed copies + dn_conv_gemm)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flops_per_launch": m["k_flops"],
                          "avg_launch_ms": m["k_ms"], "launches_timed": m["k_n"],
                          "avg_launch_ms_beside_the_data_gradient_chain": m.get("k_ms_overlapped"),

@@ -170,6 +170,7 @@ SYMBOLS = {
     "dn_sum_groups": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i64, _vp]),
     "dn_transpose_weights": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "dn_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "dn_conv_weight_grad_tn": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_add_broadcast": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "dn_transpose_pad_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dn_rmsnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),

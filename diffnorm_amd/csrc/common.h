@@ -168,6 +168,14 @@ __device__ __forceinline__ uint32_t dn_drop_row(uint32_t row, uint32_t seed_lo) 
 __device__ __forceinline__ bool dn_drop_keep(uint32_t row_hash, uint32_t key, uint32_t seed_hi, uint32_t thr) {
   return dn_mix32(row_hash + key * 0x9E3779B9U + seed_hi) >= thr;
 }
+// In-chain launch timing (dn_profile_start / dn_profile_stop, gemm.hip): HIP events recorded on the launch stream around every
+// tagged contraction launch.
+struct LaunchProfile {
+  int tag = 0, cap = 0, n = 0;
+  hipEvent_t* ev = nullptr;  // 2*cap events
+};
+extern LaunchProfile g_prof;  // defined in gemm.hip
+
 }  // namespace dn
 
 // host-side error plumbing (defined in capi.hip)

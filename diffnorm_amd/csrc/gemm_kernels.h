@@ -2079,11 +2079,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
 
 // In-chain launch timing (dn_profile_start / dn_profile_stop): HIP events recorded on the launch stream
 // around every dn_conv_gemm whose tag (bits 8..15 of DnGemmParams.pad_) matches.  Eager launches only.
-struct LaunchProfile {
-  int tag = 0, cap = 0, n = 0;
-  hipEvent_t* ev = nullptr;  // 2*cap events
-};
-extern LaunchProfile g_prof;  // defined in gemm.hip
+// (struct LaunchProfile / g_prof: common.h -- wgrad_tn.hip times its launches the same way)
 
 template <typename E, int EPI, int BM, int STAGES>
 static int launch_tile(const DnGemmParams& p, hipStream_t s) {

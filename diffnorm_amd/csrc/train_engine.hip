@@ -270,6 +270,13 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
 }
 
 struct WgTap { const void* x; int ldx; int shift; };
+}  // namespace
+namespace dn {
+int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, const int* ldx, const int* shift, int n_taps, int cin, int B, int T,
+                    int slices, float* part, float* grad, void* stream, int tag);  // wgrad_tn.hip
+}
+using dn::wgrad_tn_launch;
+namespace {
 
 template <typename T>
 void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int front, const WgPlan& pl, void* dst, int rows, int rows_total,
@@ -309,6 +316,23 @@ int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const voi
   for (int j = 0; j < n_taps; ++j) max_shift = taps[j].shift > max_shift ? taps[j].shift : max_shift;
   const WgPlan pl = plan_wgrad(cin, cout, n_taps, max_shift, c.B, c.T, c.es);
   char* base = static_cast<char*>(c.wg_scratch);
+  // bf16: straight from the row-major operands (wgrad_tn.hip: transposing LDS reads, no channel-major copies).  Slices of the
+  // frames until about 160 tile-slices (at least 256 frames each), partial sums in the scratch the transposed copies would use;
+  // a contraction that has its tiles anyway accumulates straight into the gradient.  DN_WGRAD_TN=0: the transposed-copies form.
+  const char* tn_env = getenv("DN_WGRAD_TN");
+  if (c.es == 2 && !(tn_env && atoi(tn_env) == 0)) {
+    const int rows_w = padn(cin), n_total = n_taps * rows_w;
+    const long tiles = (long)((cout + 255) / 256) * ((n_total + 255) / 256);
+    int slices = 1;
+    while (slices < 16 && tiles * slices < 160 && (long)c.M / (slices * 2) >= 256 &&
+           (size_t)(slices * 2) * cout * n_total * 4 <= pl.total()) slices *= 2;
+    const void* xs[DN_MAX_TERMS]; int ldx[DN_MAX_TERMS], sh[DN_MAX_TERMS];
+    for (int j = 0; j < n_taps; ++j) { xs[j] = taps[j].x; ldx[j] = taps[j].ldx; sh[j] = taps[j].shift; }
+    float* part = slices > 1 ? reinterpret_cast<float*>(base) : nullptr;
+    int rc = wgrad_tn_launch(dy, lddy, cout, xs, ldx, sh, n_taps, cin, c.B, c.T, slices, part, slices > 1 ? nullptr : grad, c.s, tag);
+    if (rc == DN_OK && slices > 1) rc = dn_wgrad_reduce(part, slices, cout, n_total, rows_w, n_taps, grad, padn(cout), padk(cin), c.s);
+    return finish(rc);
+  }
   void* dyT = base;
   void* xT = base + pl.b_dyT;
   float* part = reinterpret_cast<float*>(base + pl.b_dyT + pl.b_xT);

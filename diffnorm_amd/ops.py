@@ -183,6 +183,33 @@ def convert_rows(src, dst, C_):
     return dst
 
 
+def conv_weight_grad_tn(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: int, shifts: Sequence[int],
+                        slices: int = 1) -> torch.Tensor:
+    """conv_weight_grad without transposed operand copies (dn_conv_weight_grad_tn, bf16): the contraction over frames reads the
+    row-major x / dy through transposing LDS reads.  x [B*T, ldx], dy [B*T, lddy] with zero pad columns.  -> fp32 [taps, cout, cin]."""
+    import ctypes as C_
+
+    lib = _lib.load()
+    assert x.dtype == dy.dtype == torch.bfloat16 and x.dim() == 2 and dy.dim() == 2 and x.is_contiguous() and dy.is_contiguous()
+    M = x.shape[0]
+    B = M // T
+    n_taps = len(shifts)
+    rows_w, Np, Kp = (cin + 127) // 128 * 128, (cout + 127) // 128 * 128, (cin + 63) // 64 * 64
+    xs = (C_.c_void_p * n_taps)(*([x.data_ptr()] * n_taps))
+    ld = (C_.c_int32 * n_taps)(*([x.shape[1]] * n_taps))
+    sh = (C_.c_int32 * n_taps)(*[int(s_) for s_ in shifts])
+    grad = torch.zeros((n_taps, Np, Kp), device=x.device, dtype=torch.float32)
+    if slices == 1:
+        _lib.check(lib.dn_conv_weight_grad_tn(dy.data_ptr(), dy.shape[1], cout, xs, ld, sh, n_taps, cin, B, T, 1, None, grad.data_ptr(), _stream()),
+                   "dn_conv_weight_grad_tn")
+    else:
+        part = torch.empty((slices, cout, n_taps * rows_w), device=x.device, dtype=torch.float32)
+        _lib.check(lib.dn_conv_weight_grad_tn(dy.data_ptr(), dy.shape[1], cout, xs, ld, sh, n_taps, cin, B, T, slices, part.data_ptr(), None, _stream()),
+                   "dn_conv_weight_grad_tn")
+        _lib.check(lib.dn_wgrad_reduce(part.data_ptr(), slices, cout, n_taps * rows_w, rows_w, n_taps, grad.data_ptr(), Np, Kp, _stream()), "dn_wgrad_reduce")
+    return grad[:, :cout, :cin]
+
+
 def conv_weight_grad(x: torch.Tensor, dy: torch.Tensor, T: int, cin: int, cout: int, shifts: Sequence[int],
                      k_slices: int = 0) -> torch.Tensor:
     """Weight gradient of a causal conv / Linear, y[t] = sum_j W_j x[t - shifts[j]]: dW_j = sum_frames

@@ -424,6 +424,15 @@ int dn_wgrad_reduce(const float* part, int32_t slices, int32_t cout, int32_t n_t
 /* dst[j * ld + c] += src[c], j < count (the L skip-conv biases of a WaveNet share one gradient). */
 int dn_add_broadcast(const float* src, float* dst, int32_t C, int32_t ld, int32_t count, void* stream);
 
+/* The same weight gradient straight from the row-major operands, no transposed copies (bf16; autograd of CausalConv1d
+ * latent_module.py:476-485 / nn.Linear): sum over frames m of dY[m][n] * X_tap[m - shift_tap][k] (zero where the frame index of m
+ * within its sequence is < shift_tap), the contraction over frames fed to the MFMA through transposing LDS reads
+ * (csrc/wgrad_tn.hip).  dY [B*T][lddy], X_tap [B*T][ldx[tap]] bf16, rows 16-byte multiples (pad columns may hold anything).
+ * slices == 1: grad[tap][padn(cout)][padk(cin)] += result (part == NULL); slices > 1:
+ * part[slice][cout][n_taps * padn(cin)] = the partial sums of that slice of the frames (then dn_wgrad_reduce), grad unused.  */
+int dn_conv_weight_grad_tn(const void* dy, int32_t lddy, int32_t cout, const void* const* x, const int32_t* ldx, const int32_t* shift,
+                           int32_t n_taps, int32_t cin, int32_t B, int32_t T, int32_t slices, float* part, float* grad, void* stream);
+
 /* dn_transpose_pad for fp32 operands (exact-fp32 mode); chunk a multiple of 32. */
 int dn_transpose_pad_f32(const float* src, int32_t ld, int32_t B, int32_t T, int32_t C, int32_t front, int32_t Tp, float* dst,
                          int32_t rows, int32_t rows_total, int32_t row0, int32_t chunk, void* stream);

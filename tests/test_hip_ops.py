@@ -537,6 +537,27 @@ def test_weight_gradient_contraction_over_frames(ops, cin, cout, k, dil, B, T, s
     assert maxerr(got, want) < 1e-4 * max(1.0, want.abs().max().item())  # fp32 accumulation of exact bf16 products, other order
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,B,T,slices", [(192, 96, 3, 1, 3, 100, 1), (64, 352, 3, 2, 2, 300, 4), (1408, 1408, 3, 1, 4, 512, 1),
+                                                        (128, 1000, 1, 1, 1, 515, 2), (1365, 1365, 3, 1, 2, 263, 3), (512, 1536, 1, 1, 5, 77, 1),
+                                                        (200, 72, 3, 16, 3, 130, 1)])
+def test_weight_gradient_from_row_major_operands(ops, cin, cout, k, dil, B, T, slices):
+    """dn_conv_weight_grad_tn: the same weight gradient without transposed operand copies -- the contraction over frames reads the
+    row-major x / dY through transposing LDS reads (ds_read_tr16_b64).  Against torch autograd of the oracle's causal conv on the
+    bf16-rounded operands (frames before a sequence start contribute nothing, ragged frame counts, widths that are not multiples
+    of the tile, accumulation into the gradient and partial sums over slices of the frames)."""
+    ops_, packing, _lib = ops
+    x = bf16r(seeded((B, T, cin), 41))
+    w = seeded((cout, cin, k), 42, (1.0 / (cin * k)) ** 0.5).requires_grad_(True)
+    dy = bf16r(seeded((B, T, cout), 43))
+    O.causal_conv1d(x, w, None, dil).backward(dy)
+    want = w.grad.permute(2, 0, 1)  # [k, cout, cin]
+    xa = act(pad_cols(x, padk(cin)).view(B * T, -1), "bf16")
+    dya = act(pad_cols(dy, padk(cout)).view(B * T, -1), "bf16")
+    got = ops_.conv_weight_grad_tn(xa, dya, T, cin, cout, [(k - 1 - j) * dil for j in range(k)], slices=slices).cpu()
+    assert got.shape == want.shape
+    assert maxerr(got, want) < 1e-4 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4])
 def test_geglu_on_the_352_wide_tile(ops, tile):
     """GEGLU projection whose packed width (2 x padk(inner) = 1408) is a multiple of 352: the one-wave-per-SIMD tile cuts the

@@ -3,7 +3,7 @@
 hand-scheduled K loop is a slowdown and breaks its counted vmcnt waits: scratch loads share that counter) or keeps a stack object
 other than register spills.  Spills that are stored before a kernel's loops and reloaded after them (epilogue constants carried
 across the K loop of the 256-register tiles) are reported, not fatal.
-Usage: check_resources.py [file.hip ...]   (default: gemm_bf16.hip gemm_f32.hip gemm_x3.hip attention.hip)"""
+Usage: check_resources.py [file.hip ...]   (default: gemm_bf16.hip gemm_f32.hip gemm_x3.hip attention.hip wgrad_tn.hip)"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,7 +66,7 @@ def check(files):
 
 
 if __name__ == "__main__":
-    bad = check(sys.argv[1:] or ["gemm_bf16.hip", "gemm_f32.hip", "gemm_x3.hip", "attention.hip"])
+    bad = check(sys.argv[1:] or ["gemm_bf16.hip", "gemm_f32.hip", "gemm_x3.hip", "attention.hip", "wgrad_tn.hip"])
     for b in bad:
         print("SPILL/SCRATCH:", b)
     sys.exit(1 if bad else 0)
