@@ -6,7 +6,7 @@ import collections, csv, re, sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 marker = sys.argv[2] if len(sys.argv) > 2 else "ddim_step_kernel"
-name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
 cuts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 segs = [rows[a + 1: b + 1] for a, b in zip(cuts, cuts[1:])]
 sig = lambda s: tuple((name(r), r["Grid_Size_X"], r["Grid_Size_Y"]) for r in s)

@@ -14,7 +14,7 @@ def table(counter, steps):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+            name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
             key = (name, r["Grid_Size"])
             acc[key][0] += float(r["Counter_Value"])
             if r["Dispatch_Id"] not in seen:

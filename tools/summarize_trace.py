@@ -6,7 +6,7 @@ import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
     grid = r.get("Grid_Size") or "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
     wg = r.get("Workgroup_Size") or r.get("Workgroup_Size_X", "?")
     key = (name, grid, wg)

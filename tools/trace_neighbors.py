@@ -3,7 +3,7 @@
 CSV, in start order): where in the step does it sit?  Usage: trace_neighbors.py <kernel_trace.csv> <substring> [max matches]"""
 import csv, re, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:70]
+name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")[:70]
 lim = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 skip = len(rows) // 2  # steady state
 n = 0

@@ -13,7 +13,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
-            key = (re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", ""), r["Grid_Size"])
+            key = (re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", ""), r["Grid_Size"])
             acc[key][c] += float(r["Counter_Value"])
             if c == "FETCH_SIZE" and r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])
