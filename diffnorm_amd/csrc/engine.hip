@@ -23,6 +23,9 @@ inline bool fuse_norm_enabled(int Dp, int dtype) {
   return on && Dp <= 512 && dtype != DN_BF16X3;  // (the whole-row tile is not built for split operands)
 }
 
+// set by the two-stream sampling loop while it enqueues (or captures) a step: dn_conv_gemm's tile choice counts the twin launch
+static thread_local bool g_twin_launches = false;
+
 // Split RMSNorm (DnGemmParams.norm_split / row_ssq): every RMSNorm of the transformer is divided between the residual-
 // closing contraction that produces its input and the projection that consumes its output, so the 2*depth+1 norm passes
 // over the residual stream disappear (measured: -6 % per denoising step at [32,512] x dim 512).  DN_NO_SPLIT_NORM=1 runs
@@ -265,7 +268,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       pc.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
     }
     pc.bias = w.ffconv_b + (size_t)l * ip; pc.out = tb.fc; pc.ldo = ip;
-    pc.pad_ = DN_TAG_FFN_CONV << 8;
+    pc.pad_ = (DN_TAG_FFN_CONV << 8) | (g_twin_launches ? 128 : 0);  // (bit 7: an identical half-batch launch runs beside this one)
     const int conv_tile = dn_conv_gemm_tile(&pc);  // 4 = 256 x 352 (the eps-predictor's width), 3 = 256 x 256 (the VAE's)
     const bool kblocked = kblock_mode() != 0 && dtype == DN_BF16 && w.ffconv_Wkb && (kblock_mode() == 1 || conv_tile == 4 || conv_tile == 3);
     if (kblocked)
@@ -612,6 +615,8 @@ static int sampler_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, i
     m->table_ws = workspace; m->table_B = B; m->table_T = T; m->table_split = (int)split; m->table_rows = start_step;
   }
   const int noise_top = start_step - 1;  // injected noise: row (noise_top - t) belongs to step t
+  g_twin_launches = split;  // tile choice of the half-batch launches (host side, also at graph capture)
+  struct TwinReset { ~TwinReset() { g_twin_launches = false; } } twin_reset;
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
     hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_row, counter, bufs.gb);

@@ -2250,8 +2250,21 @@ static inline bool routes_to_352(const DnGemmParams& p) {
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split) return false;
   const int force = forced_tile(p);
   const int npk = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
-  const long tiles_fat = (long)((p.M + 255) / 256) * (npk / 352) * p.groups;
-  return npk % 352 == 0 && (force == 4 || (force == 0 && p.epilogue == DN_EPI_BIAS && tiles_fat >= 100));
+  if (npk % 352 != 0) return false;
+  if (force == 4) return true;
+  if (force != 0 || p.epilogue != DN_EPI_BIAS) return false;
+  // One workgroup per CU on both 256-row tiles, so what decides is how much of the chip a launch fills: the 352-wide tile is
+  // ~1.3x the 256-wide one per flop on a full chip (1.33 vs 0.95-1.0 PFLOP/s on the FFN conv) but has 1/1.375 of its tiles.  A
+  // half-batch launch of the two-stream sampling chain (bit 7 of pad_: an identical twin runs beside it) counts double: 128 + 128
+  // workgroups fill the chip.  Alone, a 128-tile launch leaves half the chip idle: the training step's FFN conv at M = 8192 takes
+  // 138 us on this tile against 98 us on 192 tiles of 256 x 256.
+  const long twin = (p.pad_ & 128) ? 2 : 1;
+  const long tiles_fat = (long)((p.M + 255) / 256) * (npk / 352) * p.groups * twin;
+  const long tiles_big = (long)((p.M + 255) / 256) * ((npk + 255) / 256) * p.groups * twin;
+  auto fill = [](long tiles) { const double r = (double)tiles / 256.0; return r / ceil(r); };
+  static const bool old_rule = getenv("DN_352_ROUTE") && atoi(getenv("DN_352_ROUTE")) == 0;  // A/B timing: at least 100 tiles, whatever they fill
+  if (old_rule) return tiles_fat / twin >= 100;
+  return tiles_fat >= 100 && 1.3 * fill(tiles_fat) >= fill(tiles_big);
 }
 
 // The tile variant a contraction runs on: 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256, 4 = 256 x 352, 5 = whole-row (fused norm),
