@@ -501,10 +501,13 @@ class DiffusionTrainer(VaeTrainer):
     """The same update loop for --task speech_diffusion_discrete --criterion ddpm_discrete_loss (scripts/diffusion/train.sh:
     lr 1e-4, Adam (0.9, 0.98), clip-norm 2.0, inverse_sqrt): `ldm` is the mirror LatentDiscreteModel; its frozen VAE encodes the
     features (no gradient), the HIP diffusion engine does the rest.  `noises[k]` (optional) = dict(times, post_noise, jitter_noise,
-    true_noise) injected for micro-batch k; otherwise drawn like the reference (t ~ U{1..T-1}, CPU posterior noise, device noise)."""
+    true_noise) injected for micro-batch k; otherwise t ~ U{1..T-1} and every noise tensor drawn ON THE DEVICE.  (The reference draws
+    the posterior noise with the CPU generator and copies it over, distributions.py:41 -- a million normals and a pageable H2D copy
+    per update, host work that showed as 31 vs 36-39 ms per update between boxes; `reference_rng=True` keeps that behaviour.)"""
 
-    def __init__(self, ldm, lr: float = 1e-4, **kw):
+    def __init__(self, ldm, lr: float = 1e-4, reference_rng: bool = False, **kw):
         self.ldm = ldm
+        self.reference_rng = reference_rng
         super().__init__(ldm.enable_training(), lr=lr, **kw)
 
     def _forward(self, sample: dict, draws):
@@ -515,8 +518,11 @@ class DiffusionTrainer(VaeTrainer):
         times = draws.get("times")
         if times is None:
             times = torch.randint(1, ldm.timesteps, (B,), device=eng.device)
+        post = draws.get("post_noise")
+        if post is None and not self.reference_rng:
+            post = torch.randn(B, feat.shape[1], ldm.speech_decoder.engine().z, device=eng.device)
         with torch.no_grad():
-            z = ldm.speech_decoder.encode_feature(feat, noise=draws.get("post_noise")).transpose(1, 2).contiguous()
+            z = ldm.speech_decoder.encode_feature(feat, noise=post).transpose(1, 2).contiguous()
         jn = draws.get("jitter_noise")
         tn = draws.get("true_noise")
         jn = torch.randn(z.shape, device=eng.device) if jn is None else jn
