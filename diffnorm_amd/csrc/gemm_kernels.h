@@ -2337,7 +2337,13 @@ static inline int choose_tile(const DnGemmParams& p) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
   };
-  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = 0.90 * fill(tiles_mid, 1), s_small = 0.92 * fill(tiles_small, 2);
+  // The taps of a causal conv share one staged copy of their rows on the 256 x 256 tile only, and a long-K contraction has no
+  // prologue / epilogue for a neighbour workgroup to cover: there the smaller tiles are worth 0.72-0.78 of it per output, not 0.9
+  // (conv k = 3, 2048 wide, M = 12288: 265 us on 384 tiles of 256 x 256 = 1.5 rounds against 285 us on 1536 of 128 x 128 = 3 full
+  // rounds; M = 15360: 293 against 411).  DN_GEMM_HEUR=4: the short-K factors for every shape (A/B timing).
+  const bool long_taps = heur != 4 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && (long)p.K * p.n_terms >= 1024 && terms_are_taps(p);
+  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = (long_taps ? 0.78 : 0.90) * fill(tiles_mid, 1),
+               s_small = (long_taps ? 0.72 : 0.92) * fill(tiles_small, 2);
   if (s_big >= s_mid && s_big >= s_small) return 3;
   return s_mid > s_small ? 2 : 1;
 }
