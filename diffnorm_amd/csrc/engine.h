@@ -83,6 +83,15 @@ struct TransformerW {
 };
 constexpr int kTransformerTensors = 15;
 
+// grouped launch of the row-major weight gradient (wgrad_tn.hip): the blocks of a WaveNet stack in one launch
+struct WgTnGroups {
+  int groups;
+  int64_t dy_gstride, x_gstride, grad_gstride;  // elements between the groups' dY / X / packed gradients
+  int shift_by_group;                           // shifts scaled by 2^group
+};
+int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, const int* ldx, const int* shift, int n_taps, int cin, int B, int T,
+                    int slices, float* part, float* grad, void* stream, int tag, const WgTnGroups* grp);
+
 }  // namespace dn
 
 struct DnEps {

@@ -228,6 +228,7 @@ struct Ctx {
   int dtype, es, B, T, M;
   hipStream_t s;
   void* wg_scratch;     // weight-gradient operands + partial sums
+  size_t wg_scratch_bytes = 0;
   float* red_scratch;   // column-sum / norm-backward partials
   const void* W(int64_t off) const { return static_cast<const char*>(work) + off * es; }
   const float* P(int64_t off) const { return master + off; }       // fp32 vectors (biases, gammas)
@@ -270,13 +271,7 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
 }
 
 struct WgTap { const void* x; int ldx; int shift; };
-}  // namespace
-namespace dn {
-int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, const int* ldx, const int* shift, int n_taps, int cin, int B, int T,
-                    int slices, float* part, float* grad, void* stream, int tag);  // wgrad_tn.hip
-}
-using dn::wgrad_tn_launch;
-namespace {
+
 
 template <typename T>
 void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int front, const WgPlan& pl, void* dst, int rows, int rows_total,
@@ -296,7 +291,7 @@ int wg_wait(const Ctx& c, int handle) {
 // overlap != nullptr: run on the side stream if there is one and return the handle to wait on (wg_wait) before dY or X is
 // overwritten and before the gradient is used; -1 = it ran on c.s.
 int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const void* dy, int lddy, int cout, float* grad, int tag = 0,
-                int* overlap = nullptr) {
+                int* overlap = nullptr, const WgTnGroups* grp = nullptr) {
   if (overlap) *overlap = -1;
   if (c0.frozen) return DN_OK;
   Ctx c = c0;
@@ -320,17 +315,32 @@ int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const voi
   // frames until about 160 tile-slices (at least 256 frames each), partial sums in the scratch the transposed copies would use;
   // a contraction that has its tiles anyway accumulates straight into the gradient.  DN_WGRAD_TN=0: the transposed-copies form.
   const char* tn_env = getenv("DN_WGRAD_TN");
-  if (c.es == 2 && !(tn_env && atoi(tn_env) == 0)) {
-    const int rows_w = padn(cin), n_total = n_taps * rows_w;
-    const long tiles = (long)((cout + 255) / 256) * ((n_total + 255) / 256);
+  const bool use_tn = c.es == 2 && !(tn_env && atoi(tn_env) == 0);
+  const char* grp_env = getenv("DN_WGRAD_GROUPS");  // 0: one launch per block also in the row-major form (A/B timing)
+  if (grp && grp->groups > 1 && (!use_tn || (grp_env && atoi(grp_env) == 0))) {  // the transposed-copies form has no groups: one call per group
+    for (int g = 0; g < grp->groups; ++g) {
+      WgTap tg[DN_MAX_TERMS];
+      for (int j = 0; j < n_taps; ++j)
+        tg[j] = WgTap{eoff(taps[j].x, (size_t)g * grp->x_gstride, c.es), taps[j].ldx, grp->shift_by_group ? taps[j].shift << g : taps[j].shift};
+      DN_TRY(weight_grad(c0, tg, n_taps, cin, eoff(dy, (size_t)g * grp->dy_gstride, c.es), lddy, cout, grad + g * grp->grad_gstride, tag, nullptr, nullptr));
+    }
+    return DN_OK;
+  }
+  if (use_tn) {
+    const int rows_w = padn(cin), n_total = n_taps * rows_w, groups = grp ? grp->groups : 1;
+    const long tiles = (long)((cout + 255) / 256) * ((n_total + 255) / 256) * groups;
+    const size_t cap = c.wg_scratch_bytes > pl.total() ? c.wg_scratch_bytes : pl.total();
     int slices = 1;
     while (slices < 16 && tiles * slices < 160 && (long)c.M / (slices * 2) >= 256 &&
-           (size_t)(slices * 2) * cout * n_total * 4 <= pl.total()) slices *= 2;
+           (size_t)(slices * 2) * groups * cout * n_total * 4 <= cap) slices *= 2;
+    if (groups > 1 && slices == 1 && (size_t)groups * cout * n_total * 4 > cap) return DN_EWORKSPACE;  // (cannot happen: max_wgrad_bytes plans it)
     const void* xs[DN_MAX_TERMS]; int ldx[DN_MAX_TERMS], sh[DN_MAX_TERMS];
     for (int j = 0; j < n_taps; ++j) { xs[j] = taps[j].x; ldx[j] = taps[j].ldx; sh[j] = taps[j].shift; }
     float* part = slices > 1 ? reinterpret_cast<float*>(base) : nullptr;
-    int rc = wgrad_tn_launch(dy, lddy, cout, xs, ldx, sh, n_taps, cin, c.B, c.T, slices, part, slices > 1 ? nullptr : grad, c.s, tag);
-    if (rc == DN_OK && slices > 1) rc = dn_wgrad_reduce(part, slices, cout, n_total, rows_w, n_taps, grad, padn(cout), padk(cin), c.s);
+    int rc = wgrad_tn_launch(dy, lddy, cout, xs, ldx, sh, n_taps, cin, c.B, c.T, slices, part, slices > 1 ? nullptr : grad, c.s, tag, grp);
+    for (int g = 0; g < groups && rc == DN_OK && slices > 1; ++g)
+      rc = dn_wgrad_reduce(part + (size_t)g * slices * cout * n_total, slices, cout, n_total, rows_w, n_taps,
+                           grad + (grp ? g * grp->grad_gstride : 0), padn(cout), padk(cin), c.s);
     return finish(rc);
   }
   void* dyT = base;
@@ -515,14 +525,14 @@ int wave_backward(const Ctx& c, const WaveP& w, const void* in, const WaveSave& 
     }
     DN_TRY(bias_grad(c, d_out, cp, dtype, L, M, cp, c.G(w.res_b) + (size_t)st * L * cp, cp));
     DN_TRY(bias_grad(c, tb.d_h, cp, dtype, L, M, cp, c.G(w.conv_b) + (size_t)st * L * cp, cp));
-    for (int i = 0; i < L; ++i) {
-      const void* x_i = st == 0 ? in_s : eoff(in_s, (size_t)i * plane, es);
-      WgTap r{x_i, cp, 0};
-      DN_TRY(weight_grad(c, &r, 1, w.cout, eoff(d_out, (size_t)i * plane, es), cp, w.cout, c.G(w.res_W) + ((size_t)st * L + i) * mat));
+    {  // the L blocks of the stack as groups of one launch each (block i: input plane i -- stack 0: the shared input --, dilation 2^i)
+      WgTap r{in_s, cp, 0};
+      const WgTnGroups gr{L, plane, st == 0 ? 0 : plane, (int64_t)mat, 0};
+      DN_TRY(weight_grad(c, &r, 1, w.cout, d_out, cp, w.cout, c.G(w.res_W) + (size_t)st * L * mat, 0, nullptr, &gr));
       WgTap taps[3];
-      for (int j = 0; j < 3; ++j) taps[j] = WgTap{x_i, cp, (2 - j) << i};
-      DN_TRY(weight_grad(c, taps, 3, w.cout, eoff(tb.d_h, (size_t)i * plane, es), cp, w.cout,
-                         c.G(w.conv_W) + ((size_t)st * L + i) * 3 * mat));
+      for (int j = 0; j < 3; ++j) taps[j] = WgTap{in_s, cp, 2 - j};
+      const WgTnGroups gc{L, plane, st == 0 ? 0 : plane, (int64_t)(3 * mat), 1};
+      DN_TRY(weight_grad(c, taps, 3, w.cout, tb.d_h, cp, w.cout, c.G(w.conv_W) + (size_t)st * L * 3 * mat, 0, nullptr, &gc));
     }
     {  // d in_i = d out_i . W_res_i + sum_j d h_i[t + (2-j) 2^i] . W_conv_i,j   (one grouped contraction, 4 terms)
       DnGemmParams p = gemm_base(dtype, M, cp, cp, T);
@@ -793,6 +803,7 @@ struct VaePlan {
   void *d_rec_act, *d_mid0, *d_mid1, *d_params;
   float* dz;
   void* wg_scratch;
+  size_t wg_scratch_bytes = 0;
   float* red_scratch;
 };
 
@@ -808,6 +819,8 @@ size_t max_wgrad_bytes(const DnVaeTrain* m, int B, int T) {
       upd(w->cin, w->cout, 3, 2);
       upd(w->cout, w->cout, 3, 2 << (w->L - 1));
       upd(w->cout, w->cout, w->L, 0);
+      const size_t grouped = (size_t)w->L * 2 * w->cout * 3 * padn(w->cout) * 4;  // the stack's blocks as groups of one launch, two slices of partial sums
+      mx = grouped > mx ? grouped : mx;
     }
   const TfP& t = m->tf;
   const int hd = t.heads * t.dim_head, ip = padk(t.inner);
@@ -856,7 +869,8 @@ VaePlan plan_vae_train(const DnVaeTrain* m, int B, int T, Arena& ar, bool need_e
   p.d_mid0 = ar.take(wide); p.d_mid1 = ar.take(wide);
   p.d_params = ar.take(M * padk(2 * z) * es);
   p.dz = (float*)ar.take(M * padk(z) * 4);
-  p.wg_scratch = ar.take(max_wgrad_bytes(m, B, T));
+  p.wg_scratch_bytes = max_wgrad_bytes(m, B, T);
+  p.wg_scratch = ar.take(p.wg_scratch_bytes);
   p.red_scratch = (float*)ar.take(((size_t)1024 * 1024 + 4096) * 4 + dn_rmsnorm_backward_scratch_bytes(B, T, D));
   return p;
 }
@@ -865,7 +879,7 @@ Ctx make_ctx(const DnVaeTrain* m, int B, int T, const VaePlan& pl, hipStream_t s
   Ctx c;
   c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = frozen;
   c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
-  c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  c.wg_scratch = pl.wg_scratch; c.wg_scratch_bytes = pl.wg_scratch_bytes; c.red_scratch = pl.red_scratch;
   c.side = frozen ? nullptr : wg_side();
   return c;
 }
@@ -1307,6 +1321,7 @@ struct EpsPlan {
   TfTmp tt;
   VaePlan vae;
   void* wg_scratch;
+  size_t wg_scratch_bytes = 0;
   float* red_scratch;
 };
 
@@ -1322,7 +1337,8 @@ size_t eps_max_wgrad_bytes(const DnEpsTrain* m, int B, int T) {
   upd(D, 3 * hd, 1, 0, B, T, es); upd(hd, D, 1, 0, B, T, es); upd(D, 2 * ip, 1, 0, B, T, es); upd(m->tf.inner, m->tf.inner, 3, 2, B, T, es);
   upd(m->tf.inner, D, 1, 0, B, T, es); upd(D, D, 1, 0, B, T, es); upd(D, m->cfg.latent, 1, 0, B, T, es);
   upd(m->C, m->n_cond, 1, 0, 1, B, 4);  // the conditioning projection: the batch is its "frame" axis, fp32
-  return mx;
+  const size_t grouped = (size_t)m->wn.L * 2 * D * 3 * padn(D) * 4;  // the WaveNet stack's blocks as groups of one launch, two slices
+  return grouped > mx ? grouped : mx;
 }
 
 EpsPlan plan_eps_train(const DnEpsTrain* m, const DnVaeTrain* vae, int B, int T, Arena& ar) {
@@ -1358,7 +1374,8 @@ EpsPlan plan_eps_train(const DnEpsTrain* m, const DnVaeTrain* vae, int B, int T,
   p.wt.d_sk = ar.take(wide); p.wt.d_out0 = ar.take(wide * m->wn.L); p.wt.d_out1 = ar.take(wide * m->wn.L); p.wt.d_h = ar.take(wide * m->wn.L);
   p.wt.d_h0 = ar.take(wide);
   p.tt = plan_tf_tmp(m->tf, B, T, es, ar);
-  p.wg_scratch = ar.take(eps_max_wgrad_bytes(m, B, T));
+  p.wg_scratch_bytes = eps_max_wgrad_bytes(m, B, T);
+  p.wg_scratch = ar.take(p.wg_scratch_bytes);
   p.red_scratch = (float*)ar.take(((size_t)1024 * 1024 + 4096) * 4 + dn_rmsnorm_backward_scratch_bytes(B, T, D));
   if (vae) {
     p.vae = plan_vae_train(vae, B, T, ar, false);
@@ -1371,7 +1388,7 @@ Ctx eps_ctx(const DnEpsTrain* m, int B, int T, const EpsPlan& pl, hipStream_t s)
   Ctx c;
   c.master = m->master; c.work = m->work; c.aux = m->aux; c.grads = m->grads; c.n_trans = m->n_trans; c.frozen = false;
   c.dtype = m->cfg.dtype; c.es = esize(c.dtype); c.B = B; c.T = T; c.M = B * T; c.s = s;
-  c.wg_scratch = pl.wg_scratch; c.red_scratch = pl.red_scratch;
+  c.wg_scratch = pl.wg_scratch; c.wg_scratch_bytes = pl.wg_scratch_bytes; c.red_scratch = pl.red_scratch;
   c.side = wg_side();
   return c;
 }

@@ -31,6 +31,10 @@ struct WgTnParams {
   float* out; int64_t out_slice_stride;     // partial sums [slices][cout][n_total] (accumulate == 0)
   float* grad; int Np, Kp;                  // accumulate == 1 (one slice): grad[tap][Np][Kp] += result
   int accumulate;
+  // groups (blockIdx.z; the blocks of a WaveNet stack in one launch): element strides between the groups' operands and results;
+  // shift_by_group: the taps' shifts are scaled by 2^group (the stack's dilations)
+  int64_t dy_gstride, x_gstride[DN_MAX_TERMS], out_gstride, grad_gstride;
+  int shift_by_group;
 };
 
 __device__ uint4 g_zero_page_w[2];  // 32 bytes of zeros (static storage is zero-initialised)
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
   const int k_tiles = (p.n_total + 255) / 256;
   const int kq0 = (blockIdx.x % k_tiles) * 256, n0 = (blockIdx.x / k_tiles) * 256;
   const int slice = blockIdx.y;
+  const int g = blockIdx.z;
   const int f_begin = slice * p.frames_per_slice;
   int f_end = f_begin + p.frames_per_slice;
   f_end = f_end < p.M ? f_end : p.M;
@@ -87,15 +92,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
     const int k = kq - tap * p.rows_w;
     const bool ok = kq < p.n_total && k < p.cin;  // (a chunk that straddles cin relies on the buffer's zero pad columns)
     tap = tap < p.n_taps ? tap : 0;
-    x_shift[i] = p.shift[tap];
+    x_shift[i] = p.shift_by_group ? p.shift[tap] << g : p.shift[tap];
     x_col_ok[i] = ok;
     x_m[i] = m;
     x_t[i] = m % p.T;
     x_inc[i] = (int64_t)32 * p.ldx[tap] * 2;
-    x_ptr[i] = reinterpret_cast<const char*>(p.x[tap]) + ((int64_t)(m - x_shift[i]) * p.ldx[tap] + k) * 2;
+    x_ptr[i] = reinterpret_cast<const char*>(p.x[tap]) + (g * p.x_gstride[tap] + (int64_t)(m - x_shift[i]) * p.ldx[tap] + k) * 2;
     const int n = n0 + cs * 8;
     y_col_ok[i] = n < p.cout;  // (as above for a chunk that straddles cout)
-    y_ptr[i] = reinterpret_cast<const char*>(p.dy) + ((int64_t)m * p.lddy + n) * 2;
+    y_ptr[i] = reinterpret_cast<const char*>(p.dy) + (g * p.dy_gstride + (int64_t)m * p.lddy + n) * 2;
   }
   const int t_step = 32 % p.T;
   auto stage = [&](int slot) {
@@ -203,12 +208,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
       for (int r = 0; r < 4; ++r) v[r] = k + r < p.cin ? v[r] : 0.f;  // (pad columns of X need not be zero: their products stay in these columns)
       if (p.accumulate) {
         if (k >= p.Kp) continue;
-        float4* dst = reinterpret_cast<float4*>(p.grad + ((int64_t)tap * p.Np + n) * p.Kp + k);
+        float4* dst = reinterpret_cast<float4*>(p.grad + g * p.grad_gstride + ((int64_t)tap * p.Np + n) * p.Kp + k);
         float4 g = *dst;
         g.x += v[0]; g.y += v[1]; g.z += v[2]; g.w += v[3];
         *dst = g;
       } else {
-        *reinterpret_cast<float4*>(p.out + slice * p.out_slice_stride + (int64_t)n * p.n_total + kq) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p.out + g * p.out_gstride + slice * p.out_slice_stride + (int64_t)n * p.n_total + kq) =
+            make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
 
 // see include/diffnorm_hip.h
 int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, const int* ldx, const int* shift, int n_taps, int cin, int B, int T,
-                    int slices, float* part, float* grad, void* stream, int tag) {
+                    int slices, float* part, float* grad, void* stream, int tag, const WgTnGroups* grp) {
   WgTnParams p;
   memset(&p, 0, sizeof(p));
   DN_CHECK_ARG(dy && x && ldx && shift && n_taps >= 1 && n_taps <= DN_MAX_TERMS && cin > 0 && cout > 0 && B > 0 && T > 0 && slices >= 1,
@@ -237,13 +243,22 @@ int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, co
   DN_CHECK_ARG(p.accumulate ? (grad != nullptr && slices == 1) : true, "dn_conv_weight_grad_tn: accumulation needs grad and one slice");
   p.out = part; p.out_slice_stride = (int64_t)cout * p.n_total;
   p.grad = grad; p.Np = padn(cout); p.Kp = padk(cin);
+  int groups = 1;
+  if (grp && grp->groups > 1) {  // part: [group][slice][cout][n_total]
+    groups = grp->groups;
+    p.dy_gstride = grp->dy_gstride;
+    for (int j = 0; j < n_taps; ++j) p.x_gstride[j] = grp->x_gstride;
+    p.out_gstride = (int64_t)slices * p.out_slice_stride;
+    p.grad_gstride = grp->grad_gstride;
+    p.shift_by_group = grp->shift_by_group;
+  }
   static bool attr_done = false;
   constexpr int lds = TSTAGES * TSTAGE;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  dim3 grid(((p.n_total + 255) / 256) * ((cout + 255) / 256), slices);
+  dim3 grid(((p.n_total + 255) / 256) * ((cout + 255) / 256), slices, groups);
   const bool timed = tag != 0 && g_prof.cap > 0 && tag == g_prof.tag && g_prof.n < g_prof.cap;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
   hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(512), lds, (hipStream_t)stream, p);
@@ -256,5 +271,5 @@ int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, co
 
 extern "C" int dn_conv_weight_grad_tn(const void* dy, int32_t lddy, int32_t cout, const void* const* x, const int32_t* ldx, const int32_t* shift,
                                       int32_t n_taps, int32_t cin, int32_t B, int32_t T, int32_t slices, float* part, float* grad, void* stream) {
-  return dn::wgrad_tn_launch(dy, lddy, cout, x, ldx, shift, n_taps, cin, B, T, slices, part, grad, stream, 0);
+  return dn::wgrad_tn_launch(dy, lddy, cout, x, ldx, shift, n_taps, cin, B, T, slices, part, grad, stream, 0, nullptr);
 }
