@@ -561,7 +561,8 @@ def make_train_batches(n, max_tokens, dim, vocab, seed, dev):
         feat = torch.randn(B, T, dim, generator=g) * mask.unsqueeze(-1)
         unit = torch.randint(4, vocab, (B, T), generator=g) * mask
         out.append({"reduce_target": feat.to(dev), "reduce_target_unit": unit.to(dev, torch.int32),
-                    "reduce_target_lengths": lens.to(dev, torch.int32), "ntokens": int(lens.sum()), "nsentences": B, "frames": B * T})
+                    "reduce_target_lengths": lens.to(dev, torch.int32), "ntokens": int(lens.sum()), "n_units": int((unit != 0).sum()),
+                    "nsentences": B, "frames": B * T})
     return out
 
 

@@ -43,7 +43,7 @@ class SyntheticReprUnitDataset(torch.utils.data.Dataset):
                 "net_input": {"src_tokens": feat, "src_lengths": lens},
                 "target": feat, "target_unit": unit, "target_lengths": lens,
                 "reduce_target": feat, "reduce_target_unit": unit, "reduce_target_lengths": lens,
-                "ntokens": int(lens.sum()), "nsentences": B}
+                "ntokens": int(lens.sum()), "n_units": int((unit != 0).sum()), "nsentences": B}
 
 
 def _check_optimizer_holds_flat_params(enc, optimizer):

@@ -310,9 +310,12 @@ class EpsTrainEngine(_FlatEngine):
     def _vae_handle(self):
         return self.vae.handle if (self.vae is not None and self.multitask) else None
 
-    def forward(self, feat, units, lengths, z, times, jitter, true_noise, loss_scale: float = 1.0, want_eps: bool = False):
+    def forward(self, feat, units, lengths, z, times, jitter, true_noise, loss_scale: float = 1.0, want_eps: bool = False,
+                n_units: Optional[int] = None, n_frames: Optional[int] = None):
         """-> stats fp32 [8]: total_loss, nll_loss, recon_mse_loss, noise_loss, acc, n_units.  z [B,T,latent]: the frozen encoder's
-        posterior sample; times [B] in [1, timesteps); jitter / true_noise [B,T,latent]."""
+        posterior sample; times [B] in [1, timesteps); jitter / true_noise [B,T,latent].  n_units (non-pad units) / n_frames (sum of
+        the lengths) are host scalars of the loss normalisation: pass them (the collater knows both) or they are read back from the
+        device tensors here -- a stream synchronisation per update that keeps the host from enqueuing the next update behind this one."""
         dev = self.device
         B, T, _ = z.shape
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
@@ -322,8 +325,8 @@ class EpsTrainEngine(_FlatEngine):
         times = times.to(dev, torch.int32).contiguous()
         snr = self.sched.get_snr(times.long())
         weight = (snr.clamp(max=5.0) / snr).to(dev, torch.float32).contiguous()  # min-SNR-5 (:1565-1569)
-        n_units = int((units != 0).sum().item())
-        n_frames = int(lengths.sum().item())
+        n_units = int((units != 0).sum().item()) if n_units is None else int(n_units)
+        n_frames = int(lengths.sum().item()) if n_frames is None else int(n_frames)
         stats = torch.empty(8, dtype=torch.float32, device=dev)
         eps = torch.empty(B, T, self.cfg.latent_dim, dtype=torch.float32, device=dev) if want_eps else None
         b = _lib.EpsTrainBatch(feat.data_ptr(), units.data_ptr(), lengths.data_ptr(), z.data_ptr(), jitter.data_ptr(), true_noise.data_ptr(),
@@ -527,4 +530,8 @@ class DiffusionTrainer(VaeTrainer):
         tn = draws.get("true_noise")
         jn = torch.randn(z.shape, device=eng.device) if jn is None else jn
         tn = torch.randn(z.shape, device=eng.device) if tn is None else tn
-        return eng.forward(feat, sample["reduce_target_unit"], lens, z, times, jn, tn)
+        # host scalars of the loss normalisation without a device read-back: the sample dict carries ntokens (= the sum of the
+        # lengths) and, from this build's collaters, n_units; an unknown batch is counted once and remembered
+        if "n_units" not in sample:
+            sample["n_units"] = int((sample["reduce_target_unit"] != 0).sum())
+        return eng.forward(feat, sample["reduce_target_unit"], lens, z, times, jn, tn, n_units=sample["n_units"], n_frames=int(sample["ntokens"]))
