@@ -631,9 +631,13 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
         for i in range(max(W, len(batches))):  # warm-up visits every batch shape once (workspace growth, kernel attributes)
             logged, norm = step(i)
         barrier()
+        if os.environ.get("DN_SYNC_DEBUG"):  # diagnostic: warn on every host-synchronising call inside the timed updates
+            torch.cuda.set_sync_debug_mode("warn")
         t0 = time.perf_counter()
         for i in range(K):
             logged, norm = step(i)
+        if os.environ.get("DN_SYNC_DEBUG"):
+            torch.cuda.set_sync_debug_mode("default")
         barrier()
         dt = time.perf_counter() - t0
         used = [batches[i % len(batches)] for i in range(K)]

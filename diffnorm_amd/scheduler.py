@@ -52,8 +52,14 @@ class ScheduleTables:
 
     def f32(self, name_or_array, device=None) -> torch.Tensor:
         """fp32 cast of a table, the form every gather upstream produces (`.float()`, :1235)."""
-        arr = name_or_array if isinstance(name_or_array, np.ndarray) else getattr(self, name_or_array)
-        t = torch.from_numpy(np.ascontiguousarray(arr.astype(np.float32)))
+        if isinstance(name_or_array, str):  # the named tables are immutable: one device copy each (a pageable H2D copy per call
+            key = (name_or_array, str(device))  # synchronises the stream -- per training update, that drained the pipeline)
+            cache = self.__dict__.setdefault("_f32_cache", {})
+            if key not in cache:
+                t = torch.from_numpy(np.ascontiguousarray(getattr(self, name_or_array).astype(np.float32)))
+                cache[key] = t.to(device) if device is not None else t
+            return cache[key]
+        t = torch.from_numpy(np.ascontiguousarray(name_or_array.astype(np.float32)))
         return t.to(device) if device is not None else t
 
     def gaussian_table(self, device=None, fixed_large: bool = False) -> torch.Tensor:
