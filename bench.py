@@ -4,7 +4,8 @@
 A "step" = one denoising step: eps-predictor forward (`Model.forward`, reference latent_module.py:828-876)
 + DDIM eta=0 scheduler update (:1419-1442) on a batch of B x T latent frames.  Workload at N=1 =
 BASELINE.json configs[2]: [B=32, T=512] latents (z=128, hidden 512) on the 1000-step cosine schedule,
-bf16 MFMA arithmetic, synthetic N(0,1) latents and random-init weights of the recipe architecture.
+IEEE-half MFMA operands with fp32 accumulation by default (--dtype f16: the 2-byte mode whose outputs are inside north_star's
+1e-2 budget on every golden; bf16 / bf16x3 / f32 selectable), synthetic N(0,1) latents and random-init weights of the recipe architecture.
 With N > 1 every rank runs its own [32,512] batch (utterances are independent: weak scaling, no
 data-path collective); value = N*K steps / max-over-ranks time.
 
@@ -24,7 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md; bf16x3 = three bf16 MFMAs per product
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md; bf16x3 = three bf16 MFMAs per product
 
 
 def parse():
@@ -39,7 +40,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--timesteps", type=int, default=1000)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x3", "f32"],
+                    help="arithmetic of the contractions; f16 (default) = IEEE-half MFMA operands, the 2-byte mode inside north_star's 1e-2 budget")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="one stream per chain instead of two forked half-batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -62,7 +64,7 @@ def time_dominant_kernel(ops, _lib, packing, dev, B, T, dtype, iters=20):
 
     inner, ip = 1365, packing.padk(1365)
     M = B * T
-    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16 if dtype == "f16" else torch.float32
     a = torch.randn(M, ip, device=dev)
     a[:, inner:] = 0
     w = torch.randn(3, packing.padn(inner), ip, device=dev) * 0.02
@@ -266,7 +268,7 @@ def full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched):
     wall32, n32, x32, units32 = chain(eng32, vae32)
     valid = torch.ones_like(units_main, dtype=torch.bool)
     out["f32_full_chain_wall_s"] = wall32
-    out["bf16_vs_f32_after_full_chain"] = {
+    out[f"{args.dtype}_vs_f32_after_full_chain"] = {
         "unit_agreement": float((units_main == units32)[valid].float().mean()),
         "latent_rel_rms_diff": float((x_main - x32).pow(2).mean().sqrt() / x32.pow(2).mean().sqrt()),
         "what": f"same features, posterior and start noise through all {n32} evaluations in {args.dtype} and in exact fp32"}
@@ -280,6 +282,29 @@ def full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched):
             "latent_rel_rms_diff": float((xx - x32).pow(2).mean().sqrt() / x32.pow(2).mean().sqrt()),
             "what": f"the same chain in split-operand bf16x3 and in exact fp32, after all {nx} evaluations"}
     return out
+
+
+def other_mode_leg(args, dtype, sd, cfg, dev, stream, B, T, coef, lengths):
+    """The same chain on the OTHER 2-byte operand type (bf16 when the headline is f16 and vice versa): 20 mid-chain steps after the
+    same 3 + 3-step set-up, so the default line carries both rates from one box."""
+    import torch
+
+    from diffnorm_amd import engine, ops
+
+    eng = engine.EpsEngine(sd, cfg, dtype=dtype, device=dev)
+    start, n_steps = args.timesteps - 1, 20
+    with torch.cuda.stream(stream):
+        x = ops.randn((B, T, cfg.latent_dim), seed=1234, device=dev)
+        eng.ddim_loop(x, lengths, start, coef, use_graph=not args.no_graph, max_evals=3, split=not args.no_split)
+        eng.ddim_loop(x, lengths, start - 3, coef, use_graph=not args.no_graph, max_evals=3, split=not args.no_split, keep_table=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.ddim_loop(x, lengths, start - 6, coef, use_graph=not args.no_graph, max_evals=n_steps, split=not args.no_split, keep_table=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(x).all().item()
+    del eng
+    return {f"{dtype}_steps_per_s": n_steps / dt}
 
 
 def x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths):
@@ -404,9 +429,14 @@ def cond_leg(args, dev, stream, B, T):
 TOLERANCE = {
     "f32": {"budget": 1e-3, "config2_max_abs": 4.8e-6, "meets": True, "arithmetic": "exact fp32 MFMA"},
     "bf16x3": {"budget": 1e-3, "config2_max_abs": 2.9e-5, "meets": True, "arithmetic": "split-operand bf16, 3 MFMAs per product, fp32 accumulate"},
+    "f16": {"budget": 1e-2, "config2_max_abs": 1.91e-3, "config2_eps_mse": 1.50e-7, "meets": True,
+            "arithmetic": "IEEE-half MFMA operands (v_mfma_f32_16x16x32_f16: the bf16 rate, 11 significand bits), fp32 accumulate; every golden "
+                          "asserted at 1e-2 flat (tests/test_hip_engine.py, test_hip_fullsize.py, test_hip_refine.py), no overflow at t in {3, 500, 999} "
+                          "(profiles/r04_f16_model_distances.txt), results beyond 65504 saturate"},
     "bf16": {"budget": 1e-2, "config2_max_abs": 1.41e-2, "config2_eps_mse": 1.08e-5, "meets": "eps-MSE yes (config 2's stated criterion); max-abs misses by 1.4x at t = 500",
              "arithmetic": "bf16 MFMA operands, fp32 accumulate"},
-    "note": "value (the headline) is quoted in --dtype; bf16x3_steps_per_s is the rate of the fastest mode that meets the fp32-column budget on every golden",
+    "note": "value (the headline) is quoted in --dtype (default f16: inside the 2-byte budget); bf16_steps_per_s is the same chain on bf16 operands, "
+            "bf16x3_steps_per_s the rate of the fastest mode that meets the fp32-column budget (1e-3) on every golden",
 }
 
 
@@ -484,7 +514,8 @@ def run_sampling(args, ctx):
         achieved = kflops / ksec / 1e12
         result = {
             "metric": "denoising-steps/sec (BxT latents)", "value": world * K / dt, "unit": "denoising-steps/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "n_gpus": world, "backend": ctx["backend"], "rccl_ranks": rccl_ranks, "process_group_ranks": ctx["group_ranks"], "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[2]: DDIM/DDPM-schedule reverse chain, eps-predictor Model(512, z=128) on "
                                    f"[B={B},T={T}] latents per GPU, {args.timesteps}-step cosine schedule, random-init weights",
@@ -494,7 +525,7 @@ def run_sampling(args, ctx):
             "chain_setup_ms": chain_setup_ms,  # conditioning table of a whole chain, built once per chain (not per step)
             "step_tflops_per_gpu": step_flops * K / dt / 1e12,
             "step_mfma_frac": step_flops * K / dt / 1e12 / peak,
-            "roofline": {"bound": "mfma", "kernel": f"{'conv_gemm_fat_kernel' if args.dtype == 'bf16' else 'conv_gemm_big_kernel'}<{args.dtype}, BIAS> FFN causal conv k=3 "
+            "roofline": {"bound": "mfma", "kernel": f"{'conv_gemm_fat_kernel' if args.dtype in ('bf16', 'f16') else 'conv_gemm_big_kernel'}<{args.dtype}, BIAS> FFN causal conv k=3 "
                                                     f"[{B * T} x 4095] x [4095 x 1365]",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flops_per_launch": kflops, "avg_launch_ms": ksec * 1e3, "launches_timed": n_l.value,
@@ -505,7 +536,7 @@ def run_sampling(args, ctx):
         # profiles/; an upper bound on HBM bytes, Infinity-Cache hits included) x the measured step rate.  Only for the shape and
         # dtype the passes were collected on.
         sb, sb_ok = step_traffic_from_profiles(args.dtype)
-        if sb is not None and (B, T) == (32, 512) and args.dtype in ("bf16", "bf16x3"):
+        if sb is not None and (B, T) == (32, 512) and args.dtype in ("f16", "bf16", "bf16x3"):
             result["hbm_bytes_per_step"] = sb
             result["hbm_gbps_per_gpu"] = sb * K / dt / 1e9
             result["hbm_profile_matches_build"] = sb_ok
@@ -523,7 +554,8 @@ def run_sampling(args, ctx):
                 result["ddpm_steps_per_s"] = 20 / (time.perf_counter() - t1)
                 assert torch.isfinite(xd).all().item()
         result["tolerance"] = TOLERANCE
-        if world == 1 and not args.no_x3 and args.dtype == "bf16":
+        if world == 1 and not args.no_x3 and args.dtype in ("bf16", "f16"):
+            result.update(other_mode_leg(args, "bf16" if args.dtype == "f16" else "f16", sd, cfg, dev, stream, B, T, coef, lengths))
             result.update(x3_legs(args, sd, cfg, dev, stream, B, T, coef, lengths))
         if world == 1 and not args.no_full_chain:
             result.update(full_chain_legs(args, eng, sd, cfg, dev, stream, B, T, coef, sched))
@@ -709,8 +741,9 @@ def train_legs(args, ctx, stream):
     --max-tokens 12000 (scripts/vae/train.sh:8, scripts/diffusion/train.sh:5-9), so the driver's run observes them."""
     out = {}
     for kind, mt, K in (("vae", 15000, 10), ("diffusion", 12000, 5)):
-        m = measure_training(kind, args.dtype if args.dtype != "bf16x3" else "bf16", mt, K, 2, ctx, stream)
-        out[kind] = train_summary(kind, args.dtype if args.dtype != "bf16x3" else "bf16", mt, K, m, 1)
+        tdt = args.dtype if args.dtype in ("bf16", "f32") else "bf16"  # the training engines run bf16 / f32 (the reference trains in fp32)
+        m = measure_training(kind, tdt, mt, K, 2, ctx, stream)
+        out[kind] = train_summary(kind, tdt, mt, K, m, 1)
         import gc
 
         import torch
@@ -728,6 +761,8 @@ def run_training(args, ctx):
     rank, world, dev, rccl_ranks, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["rccl_ranks"], ctx["dist"]
     K, W = args.steps, args.warmup
     stream = torch.cuda.Stream(device=dev)
+    if args.dtype not in ("bf16", "f32"):
+        args.dtype = "bf16"  # the training engines run bf16 / f32 (the reference trains in fp32); the line's dtype says which ran
     m = measure_training(args.train_loss, args.dtype, args.max_tokens, K, W, ctx, stream)
     keys = ["dt", "sent", "toks", "frames", "flops", "ar_ms"]
     vals = torch.tensor([m[k] for k in keys], dtype=torch.float64, device=dev if world > 1 and dist.get_backend() == "nccl" else "cpu")
@@ -743,10 +778,11 @@ def run_training(args, ctx):
         result = {
             "metric": f"training samples/sec ({'speech_vae_decoder_loss' if args.train_loss == 'vae' else 'ddpm_discrete_loss'})",
             "value": t["samples_per_s"], "unit": "samples/s", "n_gpus": world,
-            "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": t["ms_per_update"], "higher_is_better": True, "scaling": "weak",
+            "backend": ctx["backend"], "rccl_ranks": rccl_ranks, "process_group_ranks": ctx["group_ranks"], "steps": K, "warmup": W,
+            "ms_per_step": t["ms_per_update"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("configs[3]: " if args.train_loss == "vae" else "") + t["workload"], "max_tokens_per_gpu": args.max_tokens,
-                       "parallelism": f"dp{world} (RCCL gradient all-reduce, {t['buckets']} buckets)"},
+                       "parallelism": f"dp{world} ({'RCCL' if ctx['backend'] == 'rccl' else ctx['backend']} gradient all-reduce, {t['buckets']} buckets)"},
             "tokens_per_s": t["tokens_per_s"], "padded_frames_per_s": m["frames"] / m["dt"], "all_reduce_ms_per_update": t["all_reduce_ms_per_update"],
             "gradient_bytes": t["gradient_bytes"], "step_tflops_per_gpu": t["step_tflops_per_gpu"], "step_mfma_frac": t["step_mfma_frac"],
             "loss": t["final_loss"], "grad_norm": t["grad_norm"], "roofline": t["roofline"],
@@ -783,15 +819,20 @@ def main():
             dist.init_process_group(backend=backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    rccl_ranks = 1
+    # `backend`: what carried the collectives of this run ("none" for one rank).  `rccl_ranks` is a statement about RCCL and is
+    # null under any other backend: a gloo rehearsal on one GPU must not read as an RCCL run.
+    backend_name, group_ranks = "none", 1
     if world > 1:  # the ranks the collective backend actually connected: must be the N that was asked for
-        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        backend_name = dist.get_backend()
+        ones = torch.ones(1, device=dev if backend_name == "nccl" else "cpu")
         dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        if rccl_ranks != args.gpus:
-            sys.exit(f"bench.py: {rccl_ranks} ranks joined the process group, --gpus {args.gpus} expected")
+        group_ranks = int(ones.item())
+        if group_ranks != args.gpus:
+            sys.exit(f"bench.py: {group_ranks} ranks joined the process group, --gpus {args.gpus} expected")
+    rccl_ranks = group_ranks if (world == 1 or backend_name == "nccl") else None
 
-    ctx = dict(rank=rank, world=world, dev=dev, rccl_ranks=rccl_ranks, dist=dist if world > 1 else None)
+    ctx = dict(rank=rank, world=world, dev=dev, rccl_ranks=rccl_ranks, dist=dist if world > 1 else None,
+               backend="rccl" if backend_name == "nccl" else backend_name, group_ranks=group_ranks)
     if args.mode == "train":
         run_training(args, ctx)
     else:

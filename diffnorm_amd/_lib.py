@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffnorm_hip.so")
 
-DN_F32, DN_BF16, DN_BF16X3 = 0, 1, 2
+DN_F32, DN_BF16, DN_BF16X3, DN_F16 = 0, 1, 2, 3
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_FILM_GATE, EPI_RESADD, EPI_POSEMB, EPI_RELU = range(7)
 DN_MAX_TERMS = 8
 TAG_FFN_CONV, TAG_WN_DILATED, TAG_FFN_CONV_WGRAD = 1, 2, 3

@@ -24,6 +24,7 @@ namespace dn {
 template <typename E> struct AttnGeom;
 template <> struct AttnGeom<BF16> { static constexpr int ROWB = 256; };
 template <> struct AttnGeom<F32> { static constexpr int ROWB = 512; };
+template <> struct AttnGeom<F16> { static constexpr int ROWB = 256; };
 
 // byte offset of byte `byte` (16-B aligned pieces stay contiguous) of row `row` in a K/V tile
 template <typename E>
@@ -32,6 +33,8 @@ template <>
 __device__ __forceinline__ int lds_off<BF16>(int row, int byte) {
   return row * 256 + ((((byte >> 5) ^ (row & 7))) << 5) + (byte & 31);
 }
+template <>
+__device__ __forceinline__ int lds_off<F16>(int row, int byte) { return lds_off<BF16>(row, byte); }
 template <>
 __device__ __forceinline__ int lds_off<F32>(int row, int byte) {
   return row * 512 + (((byte >> 4) ^ (row & 15)) << 4) + (byte & 15);
@@ -43,6 +46,7 @@ constexpr float NEG_BIG = -3.0e38f;
 template <typename E, int DHP, bool DROP>
 __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();
   constexpr int ES = Elem<E>::bytes;
   constexpr int ROWB = AttnGeom<E>::ROWB;
   constexpr int KS_D = DHP * ES / 64;    // 64-byte k-steps along the head dim (QK^T)
@@ -87,7 +91,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   // acc_l[qt][r] = sum_k P[k][query] (the same bf16-rounded P the numerator uses), replacing 32 v_add + 2 cross-lane
   // reductions per key tile by 4 MFMAs on a pipe that has slack here (the loop is VALU-bound on the exponentials).
   f32x4 acc_l[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const uint4 ones_frag = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  constexpr bool H16 = std::is_same<E, F16>::value;  // IEEE-half operands: same tiles and swizzles as bf16, P in [0, 1] rounds to 11 bits
+  constexpr uint32_t ONE2 = H16 ? 0x3c003c00u : 0x3f803f80u;  // (1.0, 1.0) in the operand type
+  const uint4 ones_frag = make_uint4(ONE2, ONE2, ONE2, ONE2);
 
   int len = p.lengths ? p.lengths[b] : Tk;
   len = len < Tk ? len : Tk;
@@ -213,7 +219,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            // a fully masked sequence runs with sc = 0 (uniform softmax over the Tk keys): the tile rows beyond Tk must still drop out
+            if constexpr (MASKED) pv = (kv0 + kt * 16 + fg * 4 + r) < len ? pv : 0.f;
             acc_s[kt][qt][r] = pv;
             if constexpr (ES != 2) rs += pv;
           }
@@ -243,17 +251,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
         uint4 pf[2], pfd[2];  // pf: the probabilities (denominator); pfd: after dropout (numerator)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          pf[qt].x = pack_bf16x2(acc_s[2 * kk][qt][0], acc_s[2 * kk][qt][1]);
-          pf[qt].y = pack_bf16x2(acc_s[2 * kk][qt][2], acc_s[2 * kk][qt][3]);
-          pf[qt].z = pack_bf16x2(acc_s[2 * kk + 1][qt][0], acc_s[2 * kk + 1][qt][1]);
-          pf[qt].w = pack_bf16x2(acc_s[2 * kk + 1][qt][2], acc_s[2 * kk + 1][qt][3]);
+          pf[qt].x = pack_h2<H16>(acc_s[2 * kk][qt][0], acc_s[2 * kk][qt][1]);
+          pf[qt].y = pack_h2<H16>(acc_s[2 * kk][qt][2], acc_s[2 * kk][qt][3]);
+          pf[qt].z = pack_h2<H16>(acc_s[2 * kk + 1][qt][0], acc_s[2 * kk + 1][qt][1]);
+          pf[qt].w = pack_h2<H16>(acc_s[2 * kk + 1][qt][2], acc_s[2 * kk + 1][qt][3]);
           pfd[qt] = pf[qt];
           if constexpr (DROP) {
             const int ka = kv0 + (2 * kk) * 16 + fg * 4, kb = ka + 16;
-            pfd[qt].x = pack_bf16x2(dropped(acc_s[2 * kk][qt][0], qt, ka), dropped(acc_s[2 * kk][qt][1], qt, ka + 1));
-            pfd[qt].y = pack_bf16x2(dropped(acc_s[2 * kk][qt][2], qt, ka + 2), dropped(acc_s[2 * kk][qt][3], qt, ka + 3));
-            pfd[qt].z = pack_bf16x2(dropped(acc_s[2 * kk + 1][qt][0], qt, kb), dropped(acc_s[2 * kk + 1][qt][1], qt, kb + 1));
-            pfd[qt].w = pack_bf16x2(dropped(acc_s[2 * kk + 1][qt][2], qt, kb + 2), dropped(acc_s[2 * kk + 1][qt][3], qt, kb + 3));
+            pfd[qt].x = pack_h2<H16>(dropped(acc_s[2 * kk][qt][0], qt, ka), dropped(acc_s[2 * kk][qt][1], qt, ka + 1));
+            pfd[qt].y = pack_h2<H16>(dropped(acc_s[2 * kk][qt][2], qt, ka + 2), dropped(acc_s[2 * kk][qt][3], qt, ka + 3));
+            pfd[qt].z = pack_h2<H16>(dropped(acc_s[2 * kk + 1][qt][0], qt, kb), dropped(acc_s[2 * kk + 1][qt][1], qt, kb + 1));
+            pfd[qt].w = pack_h2<H16>(dropped(acc_s[2 * kk + 1][qt][2], qt, kb + 2), dropped(acc_s[2 * kk + 1][qt][3], qt, kb + 3));
           }
         }
         // transposed read: lane i of a 16-lane group supplies row (i>>2) cols 4*(i&3).., receives column i
@@ -509,7 +517,9 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            float pv = __builtin_amdgcn_exp2f(fmaf(acc_s[kt][qt][r], sc, neg_ms));
+            // a fully masked sequence runs with sc = 0 (uniform softmax over the Tk keys): the tile rows beyond Tk must still drop out
+            if constexpr (MASKED) pv = (kv0 + kt * 16 + fg * 4 + r) < len ? pv : 0.f;
             acc_s[kt][qt][r] = pv;
             rs += pv;
           }
@@ -631,10 +641,10 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
   // DN_BF16X3: q / k / v are plain fp32 (the engine keeps them out of the split layout); the products run as three bf16 MFMAs on
   // halves split on the fly (attn_x3_kernel; heads over 64 dims: exact fp32 MFMA) and only the output -- the operand of the to_out
   // contraction -- is written as split rows (store4 on p.dtype)
-  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16 || p.dtype == DN_BF16X3, "dn_attention: bad dtype");
+  DN_CHECK_ARG(p.dtype == DN_F32 || p.dtype == DN_BF16 || p.dtype == DN_BF16X3 || p.dtype == DN_F16, "dn_attention: bad dtype");
   if (p.dtype == DN_BF16X3) DN_CHECK_ARG(p.ldo % 32 == 0 && (p.heads * p.dim_head) % 4 == 0 && ((uintptr_t)p.out & 127) == 0, "dn_attention: split-row output needs ldo %% 32 == 0");
   DN_CHECK_ARG(p.dropout_p >= 0.f && p.dropout_p < 1.f, "dn_attention: dropout_p %g", (double)p.dropout_p);
-  const int es = p.dtype == DN_BF16 ? 2 : 4;
+  const int es = dn::dn_is16(p.dtype) ? 2 : 4;
   DN_CHECK_ARG((p.dim_head * es) % 16 == 0, "dn_attention: dim_head*elem must be a multiple of 16 bytes (dim_head=%d)", p.dim_head);
   DN_CHECK_ARG((p.ldq * es) % 16 == 0 && (p.ldk * es) % 16 == 0 && (p.ldv * es) % 16 == 0 && p.ldo % 4 == 0,
                "dn_attention: row strides must keep 16-byte alignment");
@@ -652,6 +662,12 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
     if (dh <= 64) return dn::launch_attn<dn::BF16, 64>(p, s);
     if (dh <= 96) return dn::launch_attn<dn::BF16, 96>(p, s);
     if (dh <= 128) return dn::launch_attn<dn::BF16, 128>(p, s);
+  } else if (p.dtype == DN_F16) {
+    DN_CHECK_ARG(p.dropout_p == 0.f && !p.lse, "dn_attention: DN_F16 is an inference mode (no dropout, no saved log-sum-exp)");
+    if (dh <= 32) return dn::launch_attn_v<dn::F16, 32, false>(p, s);
+    if (dh <= 64) return dn::launch_attn_v<dn::F16, 64, false>(p, s);
+    if (dh <= 96) return dn::launch_attn_v<dn::F16, 96, false>(p, s);
+    if (dh <= 128) return dn::launch_attn_v<dn::F16, 128, false>(p, s);
   } else {
     if (dh <= 16) return dn::launch_attn<dn::F32, 16>(p, s);
     if (dh <= 32) return dn::launch_attn<dn::F32, 32>(p, s);

@@ -14,11 +14,18 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct BF16 {};  // tag types selecting the contraction arithmetic
 struct F32 {};
 struct BF16X3 {};  // split operands: (hi, lo) bf16 pairs in "split rows" (include/diffnorm_hip.h), three bf16 MFMAs per product
+struct F16 {};     // IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 rate, 11 significand bits, |x| <= 65504); same layouts as BF16
 
 template <typename E> struct Elem;
 template <> struct Elem<BF16> { static constexpr int bytes = 2; static constexpr int kDtype = DN_BF16; };
 template <> struct Elem<F32> { static constexpr int bytes = 4; static constexpr int kDtype = DN_F32; };
 template <> struct Elem<BF16X3> { static constexpr int bytes = 4; static constexpr int kDtype = DN_BF16X3; };
+template <> struct Elem<F16> { static constexpr int bytes = 2; static constexpr int kDtype = DN_F16; };
+// the two 2-byte operand types share every layout, tile and schedule; they differ in the MFMA opcode and the conversions
+template <typename E> struct IsHalf { static constexpr bool value = false; };
+template <> struct IsHalf<BF16> { static constexpr bool value = true; };
+template <> struct IsHalf<F16> { static constexpr bool value = true; };
+__host__ __device__ inline bool dn_is16(int dtype) { return dtype == DN_BF16 || dtype == DN_F16; }
 
 // One "k-step" = 64 bytes of K per row; a fragment is the 16 bytes a lane holds of it:
 // lane l -> row (l & 15), 16-byte chunk (l >> 4) of the 64-byte k-step.
@@ -36,6 +43,12 @@ __device__ __forceinline__ void mma_kstep<BF16>(f32x4& acc, const uint4& a, cons
 }
 
 template <>
+__device__ __forceinline__ void mma_kstep<F16>(f32x4& acc, const uint4& a, const uint4& b) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+
+template <>
 __device__ __forceinline__ void mma_kstep<F32>(f32x4& acc, const uint4& a, const uint4& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
@@ -50,6 +63,36 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// IEEE half: v_cvt_pk_f16_f32 (round-to-nearest-even).  A value beyond 65504 becomes inf unless the wave runs with the MODE
+// register's FP16_OVFL bit set (f16_saturate(): overflowed fp16 results clamp to +-65504, true infinities stay) -- the DN_F16
+// kernels set it at entry, so an operand that leaves the format's range saturates instead of poisoning a contraction with inf - inf.
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  f16x2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ void f16_saturate() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+// 16-bit storage by kind: H16 false = bf16, true = IEEE half
+template <bool H16>
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { if constexpr (H16) return pack_f16x2(lo, hi); else return pack_bf16x2(lo, hi); }
+template <bool H16>
+__device__ __forceinline__ float2 unpack_h2(uint32_t v) {
+  if constexpr (H16) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    const f16x2 h = __builtin_bit_cast(f16x2, v);
+    return make_float2((float)h.x, (float)h.y);
+  } else {
+    return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u));
+  }
+}
+// the same with the clamp spelled out (v_med3_f32), for kernels that do not switch the mode bit: the element-wise ones and the
+// run-time-dtype store4 below (a handful of stores per thread: the two extra VALU instructions do not show)
+__device__ __forceinline__ float f16_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float lo, float hi) { return pack_f16x2(f16_clamp(lo), f16_clamp(hi)); }
+__device__ __forceinline__ uint16_t to_h16(int dtype, float v) { return (uint16_t)((dtype == DN_F16 ? pack_f16x2_sat(v, 0.f) : pack_bf16x2(v, 0.f)) & 0xffff); }
+__device__ __forceinline__ float from_h16(int dtype, uint16_t h) { return dtype == DN_F16 ? f16_to_f32(h) : bf16_to_f32(h); }
 
 // DN_BF16X3 split rows: element `off` of a tensor (row strides multiples of 32) lives as hi at byte (off / 32) * 128 +
 // (off % 32) * 2 and lo 64 bytes further on; hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32).
@@ -86,6 +129,9 @@ __device__ __forceinline__ void store4(void* base, int64_t elem_off, int out_dty
   } else if (out_dtype == DN_BF16) {
     uint2 v = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem_off) = v;
+  } else if (out_dtype == DN_F16) {
+    uint2 v = make_uint2(pack_f16x2_sat(a, b), pack_f16x2_sat(c, d));
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem_off) = v;
   } else {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem_off) = make_float4(a, b, c, d);
   }
@@ -96,6 +142,11 @@ __device__ __forceinline__ float4 load4(const void* base, int64_t elem_off, int 
     uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
     return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                        __uint_as_float(v.y & 0xffff0000u));
+  }
+  if (dtype == DN_F16) {
+    uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
+    const float2 a = unpack_h2<true>(v.x), b = unpack_h2<true>(v.y);
+    return make_float4(a.x, a.y, b.x, b.y);
   }
   return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
 }

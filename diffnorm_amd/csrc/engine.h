@@ -16,7 +16,7 @@ inline int padn(int c) { return round_up(c, 128); }   // packed weight rows
 
 inline const void* eoff(const void* p, size_t elems, int es) { return static_cast<const char*>(p) + elems * es; }
 inline void* eoff(void* p, size_t elems, int es) { return static_cast<char*>(p) + elems * es; }
-inline int esize(int dtype) { return dtype == DN_BF16 ? 2 : 4; }
+inline int esize(int dtype) { return dtype == DN_BF16 || dtype == DN_F16 ? 2 : 4; }
 
 #define DN_TRY(expr)          \
   do {                        \

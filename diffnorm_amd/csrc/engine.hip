@@ -70,7 +70,7 @@ int run_wavenet(const WavenetW& w, int dtype, const void* in, int M, int T, cons
   // their consumers run on the 256 x 256 tile (large M): its 16-row staging pieces are then whole cache lines (-10 % on the
   // dilated conv, -11 % on the res conv at [32,512]).  The last stack's outputs stay row-major for the skip contraction.
   bool kb = false;
-  if (kblock_mode() != 0 && dtype == DN_BF16 && w.conv_Wkb && w.res_Wkb) {
+  if (kblock_mode() != 0 && dn::dn_is16(dtype) && w.conv_Wkb && w.res_Wkb) {
     DnGemmParams q = gemm_base(dtype, M, cp, cp, T);
     q.groups = L;
     const int t_res = dn_conv_gemm_tile(&q);
@@ -212,7 +212,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
   // projection then stages whole cache lines from it and from a K-blocked copy of its weights.
   bool geglu_kb = false;
   static const bool geglu_kb_off = getenv("DN_GEGLU_KB") && atoi(getenv("DN_GEGLU_KB")) == 0;  // A/B timing
-  if (!geglu_kb_off && split && !fuse && kblock_mode() != 0 && dtype == DN_BF16 && w.ffin_Wkb && Dp % 32 == 0) {
+  if (!geglu_kb_off && split && !fuse && kblock_mode() != 0 && dn::dn_is16(dtype) && w.ffin_Wkb && Dp % 32 == 0) {
     DnGemmParams q = gemm_base(dtype, M, ip, Dp, T);
     q.epilogue = DN_EPI_GEGLU;
     geglu_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
@@ -221,7 +221,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
   // attention norm's row * gamma, written by the previous layer's feed-forward-out contraction and read by nothing else.
   bool qkv_kb = false;
   static const bool qkv_kb_off = getenv("DN_QKV_KB") && atoi(getenv("DN_QKV_KB")) == 0;  // A/B timing
-  if (!qkv_kb_off && split && !fuse && kblock_mode() != 0 && dtype == DN_BF16 && w.qkv_Wkb && Dp % 32 == 0) {
+  if (!qkv_kb_off && split && !fuse && kblock_mode() != 0 && dn::dn_is16(dtype) && w.qkv_Wkb && Dp % 32 == 0) {
     DnGemmParams q = gemm_base(dtype, M, 3 * hd, Dp, T);
     qkv_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
   }
@@ -270,7 +270,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     pc.bias = w.ffconv_b + (size_t)l * ip; pc.out = tb.fc; pc.ldo = ip;
     pc.pad_ = (DN_TAG_FFN_CONV << 8) | (g_twin_launches ? 128 : 0);  // (bit 7: an identical half-batch launch runs beside this one)
     const int conv_tile = dn_conv_gemm_tile(&pc);  // 4 = 256 x 352 (the eps-predictor's width), 3 = 256 x 256 (the VAE's)
-    const bool kblocked = kblock_mode() != 0 && dtype == DN_BF16 && w.ffconv_Wkb && (kblock_mode() == 1 || conv_tile == 4 || conv_tile == 3);
+    const bool kblocked = kblock_mode() != 0 && dn::dn_is16(dtype) && w.ffconv_Wkb && (kblock_mode() == 1 || conv_tile == 4 || conv_tile == 3);
     if (kblocked)
       for (int j = 0; j < 3; ++j) {
         pc.terms[j].W = eoff(w.ffconv_Wkb, ((size_t)l * 3 + j) * in_n * ip, es);
@@ -329,7 +329,7 @@ const void* const* take_transformer(TransformerW& w, const void* const* t) {
 }
 
 int check_dims(const char* who, int dtype, int dim, int heads, int dim_head, int layers) {
-  DN_CHECK_ARG(dtype == DN_F32 || dtype == DN_BF16 || dtype == DN_BF16X3, "%s: bad dtype %d", who, dtype);
+  DN_CHECK_ARG(dtype == DN_F32 || dtype == DN_BF16 || dtype == DN_BF16X3 || dtype == DN_F16, "%s: bad dtype %d", who, dtype);
   DN_CHECK_ARG(dim > 0 && dim % 4 == 0, "%s: dim=%d must be a positive multiple of 4", who, dim);
   DN_CHECK_ARG((heads * dim_head) % 64 == 0, "%s: heads*dim_head=%d must be a multiple of 64", who, heads * dim_head);
   DN_CHECK_ARG(layers >= 1 && layers <= DN_MAX_TERMS, "%s: wavenet layers=%d must be in 1..%d", who, layers, DN_MAX_TERMS);
@@ -752,12 +752,12 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const void* __restrict_
     const void* sp = use_alt ? alt : src;
     const int64_t so = (use_alt ? 0 : (int64_t)b * src_bstride) + (int64_t)j * ld + c;
     const float v = src_dtype == DN_BF16X3 ? load1_split(sp, so)
-                    : src_dtype == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(sp)[so]) : reinterpret_cast<const float*>(sp)[so];
+                    : dn_is16(src_dtype) ? from_h16(src_dtype, reinterpret_cast<const uint16_t*>(sp)[so]) : reinterpret_cast<const float*>(sp)[so];
     const int64_t o = ((int64_t)b * rows_total + row0 + j) * ld + c;
     if (dst_dtype == DN_BF16X3)
       store1_split(dst, o, v);
-    else if (dst_dtype == DN_BF16)
-      reinterpret_cast<uint16_t*>(dst)[o] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+    else if (dn_is16(dst_dtype))
+      reinterpret_cast<uint16_t*>(dst)[o] = to_h16(dst_dtype, v);
     else
       reinterpret_cast<float*>(dst)[o] = v;
   }

@@ -139,22 +139,22 @@ __device__ __forceinline__ void tile_coords(int logical, int n_tiles_n, int m_ti
   mt = b * band + (r - nt * rows);
 }
 
-// KIND: 0 = fp32, 1 = bf16, 2 = DN_BF16X3 split rows (hi / lo bf16 halves of a 32-element group, common.h)
+// KIND: 0 = fp32, 1 = bf16, 2 = DN_BF16X3 split rows (hi / lo bf16 halves of a 32-element group, common.h), 3 = IEEE half
 template <int KIND>
 __device__ __forceinline__ void store4t(void* base, int64_t off, float a, float b, float c, float d) {
   if constexpr (KIND == 2)
     store4_split(base, off, a, b, c, d);
-  else if constexpr (KIND == 1)
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  else if constexpr (KIND == 1 || KIND == 3)
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_h2<KIND == 3>(a, b), pack_h2<KIND == 3>(c, d));
   else
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = make_float4(a, b, c, d);
 }
-template <bool BF>
+template <int KIND>  // 0 = fp32, 1 = bf16, 3 = IEEE half
 __device__ __forceinline__ float4 load4t(const void* base, int64_t off) {
-  if constexpr (BF) {
+  if constexpr (KIND != 0) {
     const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
-    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                       __uint_as_float(v.y & 0xffff0000u));
+    const float2 a = unpack_h2<KIND == 3>(v.x), b = unpack_h2<KIND == 3>(v.y);
+    return make_float4(a.x, a.y, b.x, b.y);
   } else {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
   }
@@ -242,13 +242,14 @@ __device__ __forceinline__ int64_t out_off(const DnGemmParams& p, int m, int n) 
   return p.out_layout ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.ldo + n;
 }
 
-__device__ __forceinline__ void store8_bf16(void* base, int64_t off, const float (&v)[8]) {
+template <bool H16>
+__device__ __forceinline__ void store8_h16(void* base, int64_t off, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
-      make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      make_uint4(pack_h2<H16>(v[0], v[1]), pack_h2<H16>(v[2], v[3]), pack_h2<H16>(v[4], v[5]), pack_h2<H16>(v[6], v[7]));
 }
 
 // WIDE (bf16 output, rows 16-byte aligned, BIAS / SILU / GEGLU): a lane owns 8 output columns instead of 4.
-template <int EPI, bool FULL>
+template <int EPI, bool FULL, bool H16>
 __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
                                                    int ncols, bool prescaled) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
       // K-blocked output ([N/32][M][32]): the 8 columns stay inside one 32-column block
-      store8_bf16(out, out_off(p, m, n), o);
+      store8_h16<H16>(out, out_off(p, m, n), o);
     }
   } else {
     const int c8 = (lane & 7) * 8;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
         v[i] += bv[i];
         if constexpr (EPI == DN_EPI_SILU) v[i] = (p.pad_ & 64) ? fmaxf(v[i], 0.f) : silu(v[i]);  // pad_ bit 6: DN_EPI_RELU rides on this epilogue
       }
-      store8_bf16(out, out_off(p, m, n), v);
+      store8_h16<H16>(out, out_off(p, m, n), v);
     }
   }
 }
@@ -358,7 +359,7 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
 // function's own (row batch, lane) pattern -- v[r] = res[m_base + 4 r + (lane >> 4)][n_base + 4 (lane & 15) ..+3]; `on` false:
 // not requested (A/B timing), load here.
 struct ResPre { float4 v[16]; bool on = false; };
-template <int EPI, int OUT_BF, bool RES_BF, bool FULL, bool HAS_PRE = false, bool SPLIT = false>  // OUT_BF: store4t's KIND
+template <int EPI, int OUT_BF, bool RES_BF, bool FULL, bool HAS_PRE = false, bool SPLIT = false, bool H16 = false>  // OUT_BF: store4t's KIND (1 = the kernel's 2-byte type: bf16 or, H16, IEEE half)
 __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
                                                    int ncols, bool prescaled, const ResPre pre_res = ResPre()) {
   const float* bias = p.bias ? p.bias + p.bias_gstride * g : nullptr;
@@ -399,7 +400,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         gt = make_float4(__fadd_rn(__fmul_rn(gt.x, sm), rg.x), __fadd_rn(__fmul_rn(gt.y, sm), rg.y), __fadd_rn(__fmul_rn(gt.z, sm), rg.z),
                          __fadd_rn(__fmul_rn(gt.w, sm), rg.w));
       }
-      store4t<OUT_BF>(out, out_off(p, m, n),
+      store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(out, out_off(p, m, n),
                       gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
                       gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
     }
@@ -457,9 +458,9 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         if constexpr (HAS_RES) {
           if constexpr (HAS_PRE) {
             if (pre_res.on) rv[i] = pre_res.v[jb + i];
-            else rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
+            else rv[i] = load4t<RES_BF ? (H16 ? 3 : 1) : 0>(resb, (int64_t)m * p.ldr + n);
           } else {
-            rv[i] = load4t<RES_BF>(resb, (int64_t)m * p.ldr + n);
+            rv[i] = load4t<RES_BF ? (H16 ? 3 : 1) : 0>(resb, (int64_t)m * p.ldr + n);
           }
         }
         if constexpr (EPI == DN_EPI_FILM_GATE) {
@@ -514,14 +515,14 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         } else if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           v0 += rv[i].x; v1 += rv[i].y; v2 += rv[i].z; v3 += rv[i].w;
         }
-        store4t<OUT_BF>(out, out_off(p, m, n), v0, v1, v2, v3);
+        store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(out, out_off(p, m, n), v0, v1, v2, v3);
         if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
           if (p.norm_split) {  // split norm, producer side: row * gamma for the consuming contraction + this slab's sum of squares
             float4 ga = split_gamma;
             if (p.norm_gb && p.norm_gb_ld) ga = *reinterpret_cast<const float4*>(p.norm_gb + (int64_t)(m / p.T) * p.norm_gb_ld + n);
             // norm_split == 2: K-blocked [norm_ld/32][M][32] for a consumer that stages whole cache lines (a lane's 4 columns stay in one block)
             const int64_t noff = p.norm_split == 2 ? ((int64_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (int64_t)m * p.norm_ld + n;
-            if (p.norm_dtype == (SPLIT ? DN_BF16X3 : DN_BF16)) store4t<SPLIT ? 2 : 1>(p.norm_out, noff, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
+            if (p.norm_dtype == (SPLIT ? DN_BF16X3 : H16 ? DN_F16 : DN_BF16)) store4t<SPLIT ? 2 : H16 ? 3 : 1>(p.norm_out, noff, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             else store4t<0>(p.norm_out, noff, v0 * ga.x, v1 * ga.y, v2 * ga.z, v3 * ga.w);
             float q = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;  // the row's 16 lanes are lanes (lane & ~15) .. +15
             q = row16_sum(q);
@@ -536,15 +537,15 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
 // SPLIT: the kernel runs split operands (DN_BF16X3): its outputs are split rows or fp32, never plain bf16 -- and a kernel of the
 // other arithmetics never writes split rows -- so each kernel carries the epilogue for two storage kinds only (a third set of
 // inlined epilogues made the FiLM kernels large enough for the compiler to keep the parameter block in scratch).
-template <int EPI, bool SPLIT = false>
+template <int EPI, bool SPLIT = false, bool H16 = false>
 __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float* ep, int m_base, int n_base, int g, int lane,
                                               int ncols = 64, float row_scale = -1.f, const ResPre pre_res = ResPre()) {
   if constexpr ((DN_GEMM_ABL & 16) != 0) return;  // diagnostic build: no epilogue (LDS reads, math and stores skipped)
   const bool full = m_base + 64 <= p.M;          // wave-uniform: slab entirely inside M
-  const bool obf = !SPLIT && p.out_dtype == DN_BF16;   // kernel arguments: uniform
+  const bool obf = !SPLIT && p.out_dtype == (H16 ? DN_F16 : DN_BF16);   // kernel arguments: uniform (the kernel's own 2-byte type)
   const bool osp = SPLIT && p.out_dtype == DN_BF16X3;  // split rows (the residual stream and dense fp32 outputs never are)
   constexpr bool RESADD = EPI == DN_EPI_RESADD;  // the residual stream is always fp32 (in and out)
-  const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == DN_BF16;
+  const bool rbf = EPI == DN_EPI_FILM_GATE && p.res_dtype == (H16 ? DN_F16 : DN_BF16);
   const bool prescaled = row_scale == ROW_PRESCALED;  // the slab already holds acc * sqrt(D)/|row|
   if constexpr (EPI == DN_EPI_BIAS || EPI == DN_EPI_SILU || EPI == DN_EPI_GEGLU) {
     if (p.row_ssq && row_scale != ROW_PRESCALED) {
@@ -552,10 +553,10 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
       else park_row_scales(p, const_cast<float*>(ep), m_base, lane);
     }
   }
-#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F, false, SPLIT>(p, ep, m_base, n_base, g, lane, ncols, prescaled)
+#define DN_EP(O, R, F) wave_epilogue_impl<EPI, O, R, F, false, SPLIT, H16>(p, ep, m_base, n_base, g, lane, ncols, prescaled)
   if constexpr (RESADD) {
-    if (full) wave_epilogue_impl<EPI, 0, false, true, true, SPLIT>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
-    else wave_epilogue_impl<EPI, 0, false, false, true, SPLIT>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
+    if (full) wave_epilogue_impl<EPI, 0, false, true, true, SPLIT, H16>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
+    else wave_epilogue_impl<EPI, 0, false, false, true, SPLIT, H16>(p, ep, m_base, n_base, g, lane, ncols, prescaled, pre_res);
   } else if constexpr (EPI == DN_EPI_FILM_GATE) {
     if constexpr (SPLIT) {  // (split mode keeps the residual branch fp32)
       if (osp) { if (full) DN_EP(2, false, true); else DN_EP(2, false, false); }
@@ -572,8 +573,8 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
       const bool wide = !SPLIT && !(p.pad_ & 16) && obf && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (ncols & 7) == 0 && (p.out_gstride & 7) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
       if (wide) {
-        if (full) wave_epilogue_wide<EPI, true>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
-        else wave_epilogue_wide<EPI, false>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
+        if (full) wave_epilogue_wide<EPI, true, H16>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
+        else wave_epilogue_wide<EPI, false, H16>(p, ep, m_base, n_base, g, lane, ncols, prescaled);
         return;
       }
     }
@@ -596,6 +597,7 @@ __device__ __forceinline__ void wave_epilogue(const DnGemmParams& p, const float
 template <typename E, int EPI, int BM, int STAGES>
 __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();  // stores of a value beyond 65504 clamp instead of becoming inf
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB / ES;                     // K elements per K-tile
   constexpr int NWAVES = BM / 32;
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
     for (int r = 0; r < 16; ++r) {
       const int m_ = m0 + wm * 64 + r * 4 + (lane >> 4);
       pre_res.v[r] = make_float4(0, 0, 0, 0);
-      if (pre_res.on && m_ < p.M && n_ < p.N) pre_res.v[r] = load4t<false>(resb, (int64_t)m_ * p.ldr + n_);
+      if (pre_res.on && m_ < p.M && n_ < p.N) pre_res.v[r] = load4t<0>(resb, (int64_t)m_ * p.ldr + n_);
     }
   }
 
@@ -817,9 +819,9 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_kernel(const DnGemmParams
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in-order: writes precede the reads below
 
   if constexpr (EPI == DN_EPI_RESADD)
-    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale, pre_res);
+    wave_epilogue<EPI, std::is_same<E, BF16X3>::value, std::is_same<E, F16>::value>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale, pre_res);
   else
-    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
+    wave_epilogue<EPI, std::is_same<E, BF16X3>::value, std::is_same<E, F16>::value>(p, ep, m0 + wm * 64, n0 + wn * 64, g, lane, 64, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
 }
 
 // ------------------------------------------------------------------------------------------ 256 x 256 tile
@@ -849,6 +851,7 @@ template <typename E, int EPI, bool TAPS, int BNB = 256, bool HALO = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParams p) {
   static_assert(!HALO || (TAPS && BNB == 256 && !std::is_same<E, BF16X3>::value), "shared staging: tap-inner order on the 256 x 256 tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();  // stores of a value beyond 65504 clamp instead of becoming inf
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
   static_assert(BNB == 256 || BNB == 192, "tile width");
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
       for (int nt = 0; nt < NTS; ++nt)
         *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = scaled(acc[H * 4 + nt][mt], sc4[mt]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m0 + wm * 64, n0 + wn * (BNB / 2) + H * 64, g, lane, NTS * 16, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
+    wave_epilogue<EPI, std::is_same<E, BF16X3>::value, std::is_same<E, F16>::value>(p, ep, m0 + wm * 64, n0 + wn * (BNB / 2) + H * 64, g, lane, NTS * 16, row_scale >= 0.f ? ROW_PRESCALED : row_scale);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the second half overwrites it
   };
   half(std::integral_constant<int, 0>{});
@@ -1245,6 +1248,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
 template <typename E, int EPI>
 __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();  // stores of a value beyond 65504 clamp instead of becoming inf
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB / ES;
   constexpr int A_TILE = 64 * ROWB, W_TILE = 512 * ROWB, STAGE_BYTES = W_TILE + A_TILE;
@@ -1415,7 +1419,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
   const float scale = sqrtf((float)p.norm_D);
   const bool in_d = n < p.norm_D;
   const float4 gam = (p.norm_gamma && in_d) ? *reinterpret_cast<const float4*>(p.norm_gamma + n) : make_float4(1, 1, 1, 1);
-  const bool nbf = p.norm_dtype == DN_BF16;
+  const bool nbf = dn_is16(p.norm_dtype);  // (the kernel's own 2-byte type)
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int row = j * 4 + (lane >> 4);
@@ -1433,7 +1437,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
       y = make_float4(y.x * ga.x + be.x, y.y * ga.y + be.y, y.z * ga.z + be.z, y.w * ga.w + be.w);
     }
     if (!in_d) y = make_float4(0, 0, 0, 0);
-    if (nbf) store4t<1>(p.norm_out, (int64_t)m * p.norm_ld + n, y.x, y.y, y.z, y.w);
+    if (nbf) store4t<std::is_same<E, F16>::value ? 3 : 1>(p.norm_out, (int64_t)m * p.norm_ld + n, y.x, y.y, y.z, y.w);
     else store4t<0>(p.norm_out, (int64_t)m * p.norm_ld + n, y.x, y.y, y.z, y.w);
   }
 }
@@ -1467,10 +1471,15 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_row_kernel(const DnGemmParam
 #endif
 typedef __attribute__((ext_vector_type(2))) unsigned long u32x4;  // a 128-bit fragment as two 64-bit halves (4 VGPRs)
 
-template <bool IN_AGPR>
+template <bool IN_AGPR, bool H16>  // H16: IEEE-half operands (same shape, same rate)
 __device__ __forceinline__ void mma_pinned_bf16(f32x4& acc, const u32x4& w, const u32x4& a) {
-  if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
-  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+  if constexpr (H16) {
+    if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+  } else {
+    if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+  }
 }
 
 template <int OFFSET>
@@ -1537,7 +1546,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // pieces per chunk.  Same K order as TAPS_INNER (chunk-major, tap-minor), so the same bits.
 template <typename E, int EPI, bool TAPS_INNER, int NTW, int WAVES, bool HALO = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGemmParams p) {
-  static_assert(std::is_same<E, BF16>::value, "the hand-scheduled tiles are built for bf16 operands only");
+  static_assert(IsHalf<E>::value, "the hand-scheduled tiles are built for 2-byte operands only");
+  constexpr bool H16 = std::is_same<E, F16>::value;
   static_assert(!HALO || (TAPS_INNER && NTW == 11 && WAVES == 4), "the halo staging is built for the 256 x 352 tile in tap-inner order");
   static_assert(NTW == 11 || NTW == 8, "n-tiles per wave");
   static_assert(WAVES == 4 || (WAVES == 8 && NTW == 8), "4 waves (one per SIMD) or, on the 256 x 256 tile, 8");
@@ -1545,6 +1555,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
                 "the 352-wide tile carries the BIAS and GEGLU epilogues (its waves start at multiples of 176 columns: fine for "
                 "GEGLU's self-contained 16-column tiles, not for the others' assumptions)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();  // stores of a value beyond 65504 clamp instead of becoming inf
   constexpr int ES = Elem<E>::bytes;
   constexpr int KT = ROWB2 / ES;
   constexpr int BMF = 256, BNF = 32 * NTW, STAGES = 4;
@@ -1792,8 +1803,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
       static_for<MT>([&](auto mt_c) {
         constexpr int mt = decltype(mt_c)::value;
         if constexpr (!(DN_FAT_ABL & 2) || mt == 0) {
-          if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
-          else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
+          if constexpr (nt < 8) mma_pinned_bf16<true, H16>(acc[nt][mt], w, cur[mt]);
+          else mma_pinned_bf16<false, H16>(acc[nt][mt], w, cur[mt]);
         }
         // the gap behind MFMA mt
         if constexpr (nt < NT - 1) {
@@ -1893,8 +1904,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
       using std::integral_constant;
       static_for<MT>([&](auto mt_c) {
         constexpr int mt = decltype(mt_c)::value;
-        if constexpr (nt < 8) mma_pinned_bf16<true>(acc[nt][mt], w, cur[mt]);
-        else mma_pinned_bf16<false>(acc[nt][mt], w, cur[mt]);
+        if constexpr (nt < 8) mma_pinned_bf16<true, H16>(acc[nt][mt], w, cur[mt]);
+        else mma_pinned_bf16<false, H16>(acc[nt][mt], w, cur[mt]);
         if constexpr (nt < NT - 1) {
           if constexpr (mt == 0) {
             if constexpr (nt + 2 < NT) lds_request<(nt + 2) * 1024>(wr[nt % 3], w_cur);
@@ -2072,7 +2083,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_gemm_fat_kernel(const DnGe
     int m_slab = m0 + wm * RPW + mh * 64, n_slab = n0 + wn * (16 * NTW) + nh * 64;
     if constexpr (WAVES == 8)  // opaque: keeps the per-row address arithmetic inside the loop (hoisted, it overflows the 128 VGPRs)
       asm volatile("" : "+s"(m_slab), "+s"(n_slab));
-    wave_epilogue<EPI, std::is_same<E, BF16X3>::value>(p, ep, m_slab, n_slab, g, lane, nts * 16, -1.f);
+    wave_epilogue<EPI, std::is_same<E, BF16X3>::value, std::is_same<E, F16>::value>(p, ep, m_slab, n_slab, g, lane, nts * 16, -1.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next slab overwrites it
   }
 }
@@ -2246,7 +2257,7 @@ static inline int forced_tile(const DnGemmParams& p) {
 // contractions; on the GEGLU projection (K = 512: 16 K-tiles) it measured level with the 256 x 256 tile (67.6 vs 66.1
 // us), so there it runs only when forced.
 static inline bool routes_to_352(const DnGemmParams& p) {
-  if (p.dtype != DN_BF16 || (p.epilogue != DN_EPI_BIAS && p.epilogue != DN_EPI_GEGLU)) return false;
+  if (!dn_is16(p.dtype) || (p.epilogue != DN_EPI_BIAS && p.epilogue != DN_EPI_GEGLU)) return false;
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split) return false;
   const int force = forced_tile(p);
   const int npk = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
@@ -2270,7 +2281,7 @@ static inline bool routes_to_352(const DnGemmParams& p) {
 // The tile variant a contraction runs on: 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256, 4 = 256 x 352, 5 = whole-row (fused norm),
 // 6 / 7 = the forced-only hand-scheduled 256 x 256 forms; -1 = K-blocked operands with a tile forced that does not take them.
 static inline int choose_tile(const DnGemmParams& p) {
-  const bool bf = p.dtype == DN_BF16;
+  const bool bf = dn_is16(p.dtype);
   if ((p.epilogue == DN_EPI_RESADD || p.epilogue == DN_EPI_POSEMB) && p.norm_out && !p.norm_split && p.dtype != DN_BF16X3) return 5;
   const int force = forced_tile(p);
   bool has_ldw = false;
@@ -2313,7 +2324,7 @@ static inline int choose_tile(const DnGemmParams& p) {
   bool kblocked = false;
   for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
   if (kblocked) return bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them
-  if (bf && (force == 6 || force == 7)) return force;
+  if (p.dtype == DN_BF16 && (force == 6 || force == 7)) return force;
   if (force >= 1 && force <= 3) return force;
 
   const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
@@ -2356,7 +2367,7 @@ static inline int choose_tile(const DnGemmParams& p) {
 static inline int choose_band(const DnGemmParams& p, int tile) {
   static const int env_band = getenv("DN_GEMM_BAND") ? atoi(getenv("DN_GEMM_BAND")) : -1;
   if (env_band >= 0) return env_band < 255 ? env_band : 255;
-  const int es = p.dtype == DN_BF16 ? 2 : 4;
+  const int es = dn_is16(p.dtype) ? 2 : 4;
   const int bm = tile == 1 ? 128 : 256, bn = tile == 3 ? 256 : 128, conc = 32 * (tile == 1 ? 2 : 1);
   const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
   const double w_total = (double)np * p.K * p.n_terms * es;
@@ -2391,10 +2402,10 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   if constexpr (EPI == DN_EPI_RESADD || EPI == DN_EPI_POSEMB) {
     if (tile == 5) return launch_row<E, EPI>(p, s);
   }
-  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && std::is_same<E, BF16>::value) {
+  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && IsHalf<E>::value) {
     if (tile == 4) return launch_fat<E, EPI, 11>(p, s);
   }
-  if constexpr (std::is_same<E, BF16>::value) {
+  if constexpr (std::is_same<E, BF16>::value) {  // (the forced-only hand-scheduled 256 x 256 forms: kept for bf16)
     if (tile == 6) return launch_fat<E, EPI, 8>(p, s);
     if (tile == 7) return launch_fat<E, EPI, 8, 8>(p, s);
   }
@@ -2428,5 +2439,6 @@ static int dispatch_epi(const DnGemmParams& p, hipStream_t s) {
 int gemm_dispatch_bf16(const DnGemmParams& p, hipStream_t s);
 int gemm_dispatch_f32(const DnGemmParams& p, hipStream_t s);
 int gemm_dispatch_x3(const DnGemmParams& p, hipStream_t s);
+int gemm_dispatch_f16(const DnGemmParams& p, hipStream_t s);
 
 }  // namespace dn

@@ -123,7 +123,7 @@ static const int kNarTensors = 22;
 extern "C" int dn_nar_create(const DnNarConfig* cfg, const void* const* w, int32_t n, DnNar** out) {
   DN_CHECK_ARG(cfg && w && out, "dn_nar_create: null argument");
   DN_CHECK_ARG(n == kNarTensors, "dn_nar_create: expected %d packed tensors, got %d", kNarTensors, n);
-  DN_CHECK_ARG(cfg->dtype == DN_F32 || cfg->dtype == DN_BF16 || cfg->dtype == DN_BF16X3, "dn_nar_create: bad dtype");
+  DN_CHECK_ARG(cfg->dtype == DN_F32 || cfg->dtype == DN_BF16 || cfg->dtype == DN_BF16X3 || cfg->dtype == DN_F16, "dn_nar_create: bad dtype");
   DN_CHECK_ARG(cfg->dim > 0 && cfg->dim % 64 == 0 && cfg->dim <= 1024 && cfg->dim % cfg->heads == 0 && (cfg->dim / cfg->heads) % 4 == 0,
                "dn_nar_create: embed dim %d must be a multiple of 64 (<= 1024) and of the head count", cfg->dim);
   DN_CHECK_ARG(cfg->ffn % 64 == 0 && cfg->vocab % 4 == 0 && cfg->layers >= 1 && cfg->layers <= DN_MAX_TERMS, "dn_nar_create: ffn %% 64, vocab %% 4, 1..%d layers", DN_MAX_TERMS);

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const int32_t* __restric
       if (out_act) {
         if (act_dtype == DN_BF16X3)
           store1_split(out_act, (int64_t)b * ldo + c, v);
-        else if (act_dtype == DN_BF16)
-          reinterpret_cast<uint16_t*>(out_act)[(int64_t)b * ldo + c] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+        else if (dn_is16(act_dtype))
+          reinterpret_cast<uint16_t*>(out_act)[(int64_t)b * ldo + c] = to_h16(act_dtype, v);
         else
           reinterpret_cast<float*>(out_act)[(int64_t)b * ldo + c] = v;
       }
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const int32_t* __restric
 __device__ __forceinline__ void store_act1(void* p, int64_t off, int dtype, float v) {
   if (dtype == DN_BF16X3)
     store1_split(p, off, v);
-  else if (dtype == DN_BF16)
-    reinterpret_cast<uint16_t*>(p)[off] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffff);
+  else if (dn_is16(dtype))
+    reinterpret_cast<uint16_t*>(p)[off] = to_h16(dtype, v);
   else
     reinterpret_cast<float*>(p)[off] = v;
 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const void* __restric
     float v = 0.f;
     if (c < C) {
       const int64_t so = (int64_t)m * lds + c;
-      v = sdt == DN_BF16X3 ? load1_split(src, so) : sdt == DN_BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(src)[so]) : reinterpret_cast<const float*>(src)[so];
+      v = sdt == DN_BF16X3 ? load1_split(src, so) : dn_is16(sdt) ? from_h16(sdt, reinterpret_cast<const uint16_t*>(src)[so]) : reinterpret_cast<const float*>(src)[so];
     }
     store_act1(dst, i, ddt, v);
   }

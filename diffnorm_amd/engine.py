@@ -15,16 +15,18 @@ from . import _lib, packing
 
 def _dtype_code(dtype) -> int:
     if isinstance(dtype, str):
-        names = {"bf16": _lib.DN_BF16, "f32": _lib.DN_F32, "fp32": _lib.DN_F32, "bf16x3": _lib.DN_BF16X3}
+        names = {"bf16": _lib.DN_BF16, "f32": _lib.DN_F32, "fp32": _lib.DN_F32, "bf16x3": _lib.DN_BF16X3, "f16": _lib.DN_F16, "fp16": _lib.DN_F16}
         if dtype in names:
             return names[dtype]
     elif dtype is torch.bfloat16:
         return _lib.DN_BF16
     elif dtype is torch.float32:
         return _lib.DN_F32
-    elif isinstance(dtype, int) and dtype in (_lib.DN_F32, _lib.DN_BF16, _lib.DN_BF16X3):
+    elif dtype is torch.float16:
+        return _lib.DN_F16
+    elif isinstance(dtype, int) and dtype in (_lib.DN_F32, _lib.DN_BF16, _lib.DN_BF16X3, _lib.DN_F16):
         return dtype
-    raise ValueError(f"unsupported arithmetic dtype {dtype!r} (use 'bf16', 'bf16x3' or 'f32')")
+    raise ValueError(f"unsupported arithmetic dtype {dtype!r} (use 'bf16', 'f16', 'bf16x3' or 'f32')")
 
 
 def _require_cuda(device) -> torch.device:

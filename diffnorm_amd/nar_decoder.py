@@ -83,10 +83,10 @@ class NarDecoderEngine(_Engine):
         """enc_out fp32 [B, S, D] -> the layers' encoder-attention keys / values [layers, B, S, 2 D] (engine dtype; fp32 for bf16x3)."""
         B, S, D = enc_out.shape
         assert D == self.dim and enc_out.is_contiguous() and enc_out.dtype == torch.float32 and enc_out.device == self.device
-        tdt = torch.bfloat16 if self.dtype == _lib.DN_BF16 else torch.float32
+        tdt = torch.bfloat16 if self.dtype == _lib.DN_BF16 else torch.float16 if self.dtype == _lib.DN_F16 else torch.float32
         raw = torch.empty(int(self.lib.dn_nar_cross_kv_bytes(self.handle, B, S)) + 256, dtype=torch.uint8, device=self.device)
         off = (-raw.data_ptr()) % 256
-        ckv = raw[off: off + self.layers * B * S * 2 * D * (2 if tdt == torch.bfloat16 else 4)].view(tdt).view(self.layers, B, S, 2 * D)
+        ckv = raw[off: off + self.layers * B * S * 2 * D * tdt.itemsize].view(tdt).view(self.layers, B, S, 2 * D)
         wp, wn = self._ws_for(B, 1, S)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dn_nar_cross_kv(self.handle, enc_out.data_ptr(), B, S, ckv.data_ptr(), wp, wn, _lib.current_stream()), "dn_nar_cross_kv")

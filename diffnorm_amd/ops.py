@@ -18,6 +18,8 @@ def _code(t: torch.Tensor) -> int:
         return DN_BF16
     if t.dtype == torch.float32:
         return DN_F32
+    if t.dtype == torch.float16:
+        return _lib.DN_F16
     raise TypeError(f"unsupported tensor dtype {t.dtype}")
 
 

@@ -32,7 +32,12 @@ def padn(c: int) -> int:
 
 
 def _act_dtype(dtype: int):
-    return torch.bfloat16 if dtype == _lib.DN_BF16 else torch.float32
+    return torch.bfloat16 if dtype == _lib.DN_BF16 else torch.float16 if dtype == _lib.DN_F16 else torch.float32
+
+
+def _is16(dtype: int) -> bool:
+    """the two 2-byte arithmetic modes share every packed layout (K-blocked copies included)"""
+    return dtype in (_lib.DN_BF16, _lib.DN_F16)
 
 
 def split_rows(t: torch.Tensor, weight: bool = False) -> torch.Tensor:
@@ -60,6 +65,8 @@ def _arith(t: torch.Tensor, dtype: int, weight: bool = True) -> torch.Tensor:
     """fp32 tensor (last dim = K, padded) -> the arithmetic dtype's storage (weight: a packed weight matrix, else activation rows)."""
     if dtype == _lib.DN_BF16X3:
         return split_rows(t, weight=weight)
+    if dtype == _lib.DN_F16:  # the format ends at 65504: saturate, as the kernels do (FP16_OVFL), instead of inf
+        return t.float().clamp(-65504.0, 65504.0).to(torch.float16)
     return t.to(_act_dtype(dtype))
 
 
@@ -116,8 +123,8 @@ def pack_wavenet(sd: SD, prefix: str, cin: int, cout: int, stacks: int, layers: 
         skip_W, skip_b,
         _mat(g("final_conv.weight")[:, :, 0], dtype), _vec(g("final_conv.bias"), cp),
         # conv_W and res_W once more, K-blocked, for the 256 x 256 tile (bf16 only; placeholders in f32 mode)
-        kblock(torch.stack(conv_W)) if dtype == _lib.DN_BF16 else torch.zeros(4),
-        kblock(torch.stack(res_W)) if dtype == _lib.DN_BF16 else torch.zeros(4),
+        kblock(torch.stack(conv_W)) if _is16(dtype) else torch.zeros(4),
+        kblock(torch.stack(res_W)) if _is16(dtype) else torch.zeros(4),
     ]
 
 
@@ -166,11 +173,11 @@ def pack_transformer(sd: SD, prefix: str, dim: int, depth: int, heads: int, dim_
         torch.stack(g1) if g1 else dummy, torch.stack(g2) if g2 else dummy.clone(),
         g("to_pred.0.gamma").float().clone(), _mat(g("to_pred.1.weight"), dtype),
         # the FFN conv weights once more, K-blocked, for the 256 x 352 tile (bf16 only; a placeholder in f32 mode)
-        kblock(torch.stack(ffc)) if dtype == _lib.DN_BF16 else dummy.clone(),
+        kblock(torch.stack(ffc)) if _is16(dtype) else dummy.clone(),
         # the GEGLU projection's packed weights K-blocked (its activations arrive K-blocked from the split norm's producer)
-        kblock(torch.stack(ffin)) if dtype == _lib.DN_BF16 else dummy.clone(),
+        kblock(torch.stack(ffin)) if _is16(dtype) else dummy.clone(),
         # and the q/kv projection's (layers >= 1 read the attention norm's output K-blocked from the previous layer's last contraction)
-        kblock(torch.stack(qkv)) if dtype == _lib.DN_BF16 else dummy.clone(),
+        kblock(torch.stack(qkv)) if _is16(dtype) else dummy.clone(),
     ]
 
 

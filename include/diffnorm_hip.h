@@ -21,6 +21,10 @@
  *     accumulator, a_hi b_hi + a_lo b_hi + a_hi b_lo (the dropped a_lo b_lo term is 2^-18 relative), i.e. fp32-class
  *     results (1e-3 budget of north_star's fp32 column) at a third of the bf16 MFMA rate instead of a sixteenth.
  *     Everything that is not a contraction operand is fp32 exactly as in DN_F32 mode.
+ *     DN_F16 = IEEE-half MFMA operands (v_mfma_f32_16x16x32_f16: the bf16 issue rate on gfx950) with fp32 accumulation --
+ *     DN_BF16 with three more significand bits: the same 2-byte layouts, tiles and schedules, every tensor DN_BF16 stores as
+ *     bf16 is stored as half, everything DN_BF16 keeps fp32 stays fp32.  The format ends at 65504: a value beyond it saturates
+ *     (the kernels run with the MODE register's FP16_OVFL bit set) instead of becoming inf.  Inference engines only.
  *   - DN_BF16X3 storage ("split rows"): an element takes 4 bytes like fp32 and ld / K / column offsets count elements, but
  *     every group of 32 consecutive elements of a row is laid out as two 64-byte halves of 32 bf16 each: ACTIVATIONS
  *     (everything a kernel of this library writes, and every A operand) store [hi | lo], packed WEIGHTS (W operands)
@@ -38,7 +42,7 @@
 extern "C" {
 #endif
 
-enum { DN_F32 = 0, DN_BF16 = 1, DN_BF16X3 = 2 };
+enum { DN_F32 = 0, DN_BF16 = 1, DN_BF16X3 = 2, DN_F16 = 3 };
 
 enum {
   DN_OK = 0,
@@ -94,7 +98,7 @@ enum { DN_LAYOUT_A_KBLOCKED = 1, DN_LAYOUT_W_KBLOCKED = 2, DN_LAYOUT_OUT_KBLOCKE
 typedef struct {
   DnGemmTerm terms[DN_MAX_TERMS];
   int32_t n_terms;
-  int32_t dtype;       /* DN_F32 | DN_BF16 | DN_BF16X3: element type of A and W                     */
+  int32_t dtype;       /* DN_F32 | DN_BF16 | DN_F16 | DN_BF16X3: element type of A and W            */
   int32_t M, N, K;     /* rows (B*T), stored output columns (multiple of 4), K per term (multiple of
                           64 for bf16 / 32 for f32)                                                 */
   int32_t T;           /* frames per sequence: row m -> (b = m / T, t = m % T)                      */
@@ -104,7 +108,7 @@ typedef struct {
   int64_t bias_gstride;
   void* out;           /* [M, ldo]                                                                  */
   int32_t ldo;
-  int32_t out_dtype;   /* DN_F32 | DN_BF16 | DN_BF16X3 (split rows: ldo, N offsets multiples of 32)  */
+  int32_t out_dtype;   /* DN_F32 | dtype's 2-byte type | DN_BF16X3 (split rows: ldo, N offsets multiples of 32) */
   int64_t out_gstride;
   const void* res;     /* FILM_GATE: [M, ldr] in res_dtype; RESADD: fp32 [M, ldr] (may alias out)   */
   int32_t ldr;

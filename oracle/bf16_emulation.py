@@ -29,11 +29,31 @@ Tensor = torch.Tensor
 
 
 class Rounder:
-    def __init__(self, skip: Optional[Set[str]] = None):
-        self.skip = set(skip or ())
+    """kind "bf16" (8 mantissa bits, fp32's exponent range) or "f16" (11 mantissa bits, |x| <= 65504, subnormals below 2^-14:
+    the operand format of v_mfma_f32_16x16x32_f16, which issues at the bf16 rate on gfx950).  For "f16" the rounder counts,
+    per rounding point, the values that overflow to inf and the non-zero values that fall into the subnormal range (they keep
+    fewer than 11 bits) or flush to zero -- the two ways the narrower exponent can hurt where bf16 cannot."""
+
+    F16_MAX, F16_MIN_NORMAL, F16_MIN_SUB = 65504.0, 2.0 ** -14, 2.0 ** -24
+
+    def __init__(self, skip: Optional[Set[str]] = None, kind: str = "bf16"):
+        assert kind in ("bf16", "f16")
+        self.skip, self.kind = set(skip or ()), kind
+        self.stats = {}  # point -> [elements, overflow, subnormal, flushed to zero, max |x|]
 
     def __call__(self, t: Tensor, point: str) -> Tensor:
-        return t if point in self.skip else t.to(torch.bfloat16).float()
+        if point in self.skip:
+            return t
+        if self.kind == "bf16":
+            return t.to(torch.bfloat16).float()
+        a = t.detach().abs()
+        s = self.stats.setdefault(point, [0, 0, 0, 0, 0.0])
+        s[0] += a.numel()
+        s[1] += int((a > self.F16_MAX).sum())
+        s[2] += int(((a < self.F16_MIN_NORMAL) & (a >= self.F16_MIN_SUB)).sum())
+        s[3] += int(((a < self.F16_MIN_SUB / 2) & (a > 0)).sum())
+        s[4] = max(s[4], float(a.max()) if a.numel() else 0.0)
+        return t.to(torch.float16).float()
 
 
 def _conv(x: Tensor, w: Tensor, b: Optional[Tensor], dil: int, R: Rounder) -> Tensor:
@@ -125,9 +145,9 @@ def transformer(sd, x: Tensor, depth: int, heads: int, mask: Optional[Tensor], t
     return R(out, "tp") if pred_round else out
 
 
-def eps_forward(sd, cfg, x: Tensor, times: Tensor, mask: Tensor, skip: Optional[Set[str]] = None) -> Tensor:
-    """dn_eps_forward in DN_BF16 mode (Model.forward latent_module.py:828-876)."""
-    R = Rounder(skip)
+def eps_forward(sd, cfg, x: Tensor, times: Tensor, mask: Tensor, skip: Optional[Set[str]] = None, R: Optional[Rounder] = None) -> Tensor:
+    """dn_eps_forward in DN_BF16 / DN_F16 mode (Model.forward latent_module.py:828-876)."""
+    R = R or Rounder(skip)
     t = O.time_cond(sd, times)  # conditioning path: fp32 throughout
     h = R(_conv(R(x, "in"), sd["init_conv.weight"], sd["init_conv.bias"], 1, R), "wn")
     h = wavenet(sub(sd, "wavenet."), h, cfg.wavenet_stacks, cfg.wavenet_layers, t, R)
@@ -136,9 +156,9 @@ def eps_forward(sd, cfg, x: Tensor, times: Tensor, mask: Tensor, skip: Optional[
     return F.linear(h, R(sd["final_proj.weight"], "w"), sd["final_proj.bias"])
 
 
-def vae_encode_params(sd, cfg, feat: Tensor, skip: Optional[Set[str]] = None) -> Tensor:
+def vae_encode_params(sd, cfg, feat: Tensor, skip: Optional[Set[str]] = None, R: Optional[Rounder] = None) -> Tensor:
     """dn_vae_encode_params (:1099-1106): posterior parameters, fp32 out of the last WaveNet."""
-    R = Rounder(skip)
+    R = R or Rounder(skip)
     x = R(feat, "in")
     n = len(cfg.chan_mults())
     for i in range(n):
@@ -147,9 +167,9 @@ def vae_encode_params(sd, cfg, feat: Tensor, skip: Optional[Set[str]] = None) ->
     return x
 
 
-def vae_decode(sd, cfg, latent: Tensor, mask: Tensor, skip: Optional[Set[str]] = None):
+def vae_decode(sd, cfg, latent: Tensor, mask: Tensor, skip: Optional[Set[str]] = None, R: Optional[Rounder] = None):
     """dn_vae_decode (:1109-1116) -> (recon fp32, logits fp32)."""
-    R = Rounder(skip)
+    R = R or Rounder(skip)
     x = R(latent, "in")
     n = len(cfg.chan_mults())
     for i in range(n):

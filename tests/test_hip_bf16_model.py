@@ -48,92 +48,97 @@ def eng():
     return engine, scheduler
 
 
-def test_eps_tiny_bf16_vs_emulation(eng, golden):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_eps_tiny_bf16_vs_emulation(eng, golden, kind):
     engine, _ = eng
     g = golden("eps_tiny")
     sd = O.make_eps_state_dict(TINY_EPS, "tiny")
     x, t, lens = T_(g["x"]), T_(g["t"]), T_(g["lens"])
     mask = O.lengths_to_mask(lens, x.shape[1])
-    got = engine.EpsEngine(sd, TINY_EPS, dtype="bf16", device=DEV).forward(x.to(DEV), t, lens, shared_t=False).cpu()
+    got = engine.EpsEngine(sd, TINY_EPS, dtype=kind, device=DEV).forward(x.to(DEV), t, lens, shared_t=False).cpu()
     with torch.no_grad():
-        emu = E.eps_forward(sd, TINY_EPS, x, t, mask)
+        emu = E.eps_forward(sd, TINY_EPS, x, t, mask, R=E.Rounder(kind=kind))
     ref = T_(g["eps"])
     for b in range(x.shape[0]):
         m = mask[b]
-        equivalent(f"tiny t={int(t[b])}", got[b][m], emu[b][m], ref[b][m])
+        equivalent(f"{kind} tiny t={int(t[b])}", got[b][m], emu[b][m], ref[b][m])
     assert maxerr(got[0][mask[0]], emu[0][mask[0]]) <= 2e-3  # t = 3: FiLM / adaptive-norm gains O(1), two layers: tight
 
 
-def test_eps_full_cfg2_bf16_vs_emulation(eng, golden):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_eps_full_cfg2_bf16_vs_emulation(eng, golden, kind):
     engine, _ = eng
     g = golden("eps_full_cfg2")
     sd = O.make_eps_state_dict(FULL_EPS, "full")
     x = seeded((8, 256, 128), 0)
     lens, t = T_(g["lens"]), T_(g["t"])
     mask = O.lengths_to_mask(lens, 256)
-    got = engine.EpsEngine(sd, FULL_EPS, dtype="bf16", device=DEV).forward(x.to(DEV), t, lens, shared_t=True).cpu()
+    got = engine.EpsEngine(sd, FULL_EPS, dtype=kind, device=DEV).forward(x.to(DEV), t, lens, shared_t=True).cpu()
     with torch.no_grad():
-        emu = E.eps_forward(sd, FULL_EPS, x, t, mask)
+        emu = E.eps_forward(sd, FULL_EPS, x, t, mask, R=E.Rounder(kind=kind))
     ref = T_(g["eps"])
-    equivalent("cfg2 [8,256] t=500", got[mask], emu[mask], ref[mask])
+    equivalent(f"{kind} cfg2 [8,256] t=500", got[mask], emu[mask], ref[mask])
 
 
-def test_vae_bf16_vs_emulation(eng, golden):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_vae_bf16_vs_emulation(eng, golden, kind):
     engine, _ = eng
     vsd = O.make_vae_state_dict(CHAIN_VAE, "chain")
-    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="bf16", device=DEV)
+    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype=kind, device=DEV)
     feat = seeded((3, 48, CHAIN_VAE.dim), 31)
     lens = torch.tensor([48, 29, 40])
     mask = O.lengths_to_mask(lens, 48)
     params = ve.encode_params(feat.to(DEV))
     with torch.no_grad():
-        p_emu = E.vae_encode_params(vsd, CHAIN_VAE, feat)
+        p_emu = E.vae_encode_params(vsd, CHAIN_VAE, feat, R=E.Rounder(kind=kind))
     p_ref = O.vae_encode_params(vsd, CHAIN_VAE, feat)
-    equivalent("small VAE posterior parameters", params.cpu(), p_emu, p_ref)
+    equivalent(f"{kind} small VAE posterior parameters", params.cpu(), p_emu, p_ref)
     assert maxerr(params.cpu(), p_emu) <= 2e-3  # two WaveNets, no norm, no gains: tight
     z = O.posterior_sample(p_emu, seeded((3, 48, CHAIN_VAE.z), 5))
     recon, logits, _ = ve.decode(z.to(DEV), lens)
     with torch.no_grad():
-        r_emu, l_emu = E.vae_decode(vsd, CHAIN_VAE, z, mask)
+        r_emu, l_emu = E.vae_decode(vsd, CHAIN_VAE, z, mask, R=E.Rounder(kind=kind))
         r_ref, l_ref = O.vae_decode(vsd, CHAIN_VAE, z, mask)
-    equivalent("small VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
-    equivalent("small VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
+    equivalent(f"{kind} small VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    equivalent(f"{kind} small VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
 
 
-def test_vae_full_cfg1_bf16_vs_emulation(eng, golden):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_vae_full_cfg1_bf16_vs_emulation(eng, golden, kind):
     """BASELINE config 1 shapes (a 4-utterance slice of the 64: the CPU model of the full batch takes minutes)."""
     engine, _ = eng
     g = golden("vae_full_cfg1")
     sd = O.make_vae_state_dict(FULL_VAE, "full")
-    ve = engine.VaeEngine(sd, dtype="bf16", device=DEV)
+    ve = engine.VaeEngine(sd, dtype=kind, device=DEV)
     feat = seeded((64, 128, 768), 0)[:4]
     lens = T_(g["lens"])[:4]
     mask = O.lengths_to_mask(lens, 128)
     params = ve.encode_params(feat.to(DEV)).cpu()
     with torch.no_grad():
-        p_emu = E.vae_encode_params(sd, FULL_VAE, feat)
+        p_emu = E.vae_encode_params(sd, FULL_VAE, feat, R=E.Rounder(kind=kind))
     z = O.posterior_sample(p_emu, seeded((64, 128, 128), 3)[:4])
     recon, logits, _ = ve.decode(z.to(DEV), lens)
     with torch.no_grad():
-        r_emu, l_emu = E.vae_decode(sd, FULL_VAE, z, mask)
+        r_emu, l_emu = E.vae_decode(sd, FULL_VAE, z, mask, R=E.Rounder(kind=kind))
         p_ref = O.vae_encode_params(sd, FULL_VAE, feat)
         r_ref, l_ref = O.vae_decode(sd, FULL_VAE, z, mask)
-    equivalent("cfg1 VAE posterior parameters", params, p_emu, p_ref)
+    equivalent(f"{kind} cfg1 VAE posterior parameters", params, p_emu, p_ref)
     assert maxerr(params, p_emu) <= 2e-3
-    equivalent("cfg1 VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
-    equivalent("cfg1 VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
+    equivalent(f"{kind} cfg1 VAE recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    equivalent(f"{kind} cfg1 VAE logits", logits.cpu()[mask], l_emu[mask], l_ref[mask])
     assert maxerr(params[:2], T_(g["params_head"])) <= 1e-2  # the reference's own posterior parameters (fp32 golden)
 
 
-def test_short_chain_bf16_vs_emulation(eng, golden):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_short_chain_bf16_vs_emulation(eng, golden, kind):
     """DDIM chain, start_step 5 (4 evaluations): every step's eps-predictor call and both VAE ends against the CPU model."""
     engine, scheduler = eng
     from diffnorm_amd import ops
 
     g = golden("chain_small")
     esd, vsd = O.make_eps_state_dict(CHAIN_EPS, "chain"), O.make_vae_state_dict(CHAIN_VAE, "chain")
-    ee = engine.EpsEngine(esd, CHAIN_EPS, dtype="bf16", device=DEV)
-    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype="bf16", device=DEV)
+    ee = engine.EpsEngine(esd, CHAIN_EPS, dtype=kind, device=DEV)
+    ve = engine.VaeEngine(vsd, dim=CHAIN_VAE.dim, latent_dim=CHAIN_VAE.latent_dim, dtype=kind, device=DEV)
     B, Tn, start = 3, 48, 5
     feat = seeded((B, Tn, CHAIN_VAE.dim), 31)
     lens = T_(g["lens"])
@@ -152,9 +157,9 @@ def test_short_chain_bf16_vs_emulation(eng, golden):
     with torch.no_grad():
         for tt in range(start - 1, 0, -1):
             t = torch.full((B,), tt, dtype=torch.long)
-            xe = O.ddim_update(tab, xe, E.eps_forward(esd, CHAIN_EPS, xe, t, mask), t)
-        r_emu, _ = E.vae_decode(vsd, CHAIN_VAE, xe, mask)
+            xe = O.ddim_update(tab, xe, E.eps_forward(esd, CHAIN_EPS, xe, t, mask, R=E.Rounder(kind=kind)), t)
+        r_emu, _ = E.vae_decode(vsd, CHAIN_VAE, xe, mask, R=E.Rounder(kind=kind))
         r_ref, _ = O.vae_decode(vsd, CHAIN_VAE, xe, mask)
     assert maxerr(xs.cpu()[mask], xe[mask]) <= 2e-3  # the latent after 4 evaluations (eps is damped by the small-t DDIM update): tight
-    equivalent("chain start=5 recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
+    equivalent(f"{kind} chain start=5 recon", recon.cpu()[mask], r_emu[mask], r_ref[mask])
     assert maxerr(recon.cpu()[mask], T_(g["s5_recon"])[mask]) <= 1.5e-2

@@ -672,7 +672,7 @@ def test_split_rmsnorm_producer_and_consumers(ops, dtype, tile, mode, D, K, N2, 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("heads,dh,B,T,lens", [(8, 64, 2, 200, [200, 77]), (8, 96, 1, 130, [101]), (4, 16, 3, 40, [40, 1, 23]),
-                                               (2, 32, 2, 64, [64, 0])])
+                                               (2, 32, 2, 64, [64, 0]), (4, 64, 3, 150, [150, 0, 31])])
 def test_attention(ops, dtype, heads, dh, B, T, lens):
     """Attend.forward non-flash branch with key-padding mask (reference latent_module.py:299-343),
     incl. a 1-key and an all-masked (length 0 -> uniform) sequence."""
