@@ -11,6 +11,7 @@ import zlib
 import torch
 
 from ...data import ReprToReprUnitDataset, UnitDictionary
+from ...latent_module import wrapped_by_torch_ddp
 from ...profiling import profile_range
 from ..registry import MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY, CRITERION_REGISTRY, FairseqTask, register_task
 
@@ -140,6 +141,13 @@ class _SpeechTaskBase(FairseqTask):
         if hasattr(enc, "enable_training"):
             enc.enable_training()  # (a training run's model did this when it was moved to the GPU: models/common_args.is_training_run)
             _check_optimizer_holds_flat_params(enc, optimizer)
+            # fairseq's default `--ddp-backend pytorch_ddp` hands the task the model inside torch's DistributedDataParallel, whose
+            # reducer only sees gradients that come out of the autograd graph: the bridge then returns them instead of writing the
+            # engine's buffer in place (latent_module._finish_backward).  legacy_ddp / one rank: the in-place form.
+            through = wrapped_by_torch_ddp(model)
+            if through and not getattr(enc, "_grads_through_autograd", False):
+                enc._train_engine.work_current = False  # DDP's constructor broadcast rank 0's parameters into the master buffer
+            enc._grads_through_autograd = through
         with profile_range("forward"):  # the reference's range names (speech_decoder_task.py:215-220)
             loss, sample_size, logging_output = criterion(model, sample)
         if ignore_grad:

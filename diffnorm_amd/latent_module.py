@@ -196,14 +196,19 @@ def _set_dropout(engine, p: float):
 
 
 def _prepare_step(flat, eng, holder) -> bool:
-    """Before a training forward.  (1) The master buffer may have been updated by an optimizer that is not the HIP one (fairseq's
-    Adam on `flat_params`, an in-place update: the tensor's version counter moves): the engine's bf16 working copy and its
-    transposed weights are refreshed from it.  (2) fairseq's FairseqOptimizer.zero_grad sets `p.grad = None`
+    """Before a training forward.  (1) The master buffer may have been updated by an optimizer that is not the HIP one: the engine's
+    bf16 working copy and its transposed weights are then refreshed from it.  Nothing observable tells that such an update
+    happened -- fairseq's Adam writes through `p.data` (fairseq/optim/adam.py:185-236: `p_data_fp32 = p.data; ...addcdiv_`), which
+    does NOT move the parameter's version counter (round 3 relied on it and trained nothing under `--optimizer adam`) -- so the
+    engine keeps a flag instead: `work_current` is set by the two calls that bring the copies up to date (`refresh` after the
+    HIP-backed FlatOptimizer's step, `sync_work`) and cleared by every backward of this bridge, after which any optimizer may
+    move the master buffer.  Under FlatOptimizer the flag is set again before the next forward and nothing extra runs; under an
+    external optimizer every forward that follows a backward pays one sync (fp32 -> bf16 + the transposes: what an update
+    needs anyway).  (2) fairseq's FairseqOptimizer.zero_grad sets `p.grad = None`
     (fairseq/optim/fairseq_optimizer.py:129-133), which drops the alias `flat_params.grad is engine.grads`: that IS the zeroing,
     so the engine's gradient buffer is cleared here and the alias is restored by the backward.  -> whether the alias was dropped."""
-    if flat._version != getattr(holder, "_seen_version", flat._version):
+    if not getattr(eng, "work_current", False):
         eng.sync_work()
-    holder._seen_version = flat._version
     dropped = flat.grad is None
     if dropped:
         eng.zero_grad()
@@ -221,6 +226,50 @@ def _scaled_backward(eng, c: float, fresh: bool, run):
         eng.grads.div_(c)
     run()
     eng.grads.mul_(c)
+
+
+def _finish_backward(flat, eng, holder, run, c: float, fresh: bool):
+    """What the bridge's backward hands back for `flat_params`, after `run` has ADDED d loss / d theta into the engine's buffer.
+
+    Default: nothing -- `flat_params.grad` IS the engine's gradient buffer (the alias is restored when a zero_grad had dropped
+    it), so any elementwise optimizer and an explicit flat all-reduce (fairseq's legacy_ddp) work on it in place.
+
+    `holder._grads_through_autograd` (set by the plugin's train_step when the model arrives wrapped in
+    torch.nn.parallel.DistributedDataParallel, fairseq's DEFAULT `--ddp-backend pytorch_ddp`: fairseq/dataclass/configs.py:301-309,
+    fairseq/models/distributed_fairseq_model.py:59-84): torch-DDP's reducer hangs on the parameter's gradient ACCUMULATOR, which
+    only fires when a gradient for the parameter comes out of the autograd graph.  So this micro-batch's gradient is computed into
+    the (zeroed) engine buffer and returned as the Function's gradient for `flat_params`: autograd accumulates it into
+    `flat_params.grad` (one copy of the buffer), the reducer's hook fires and all-reduces it like any other parameter's.  A
+    zero upstream gradient (fairseq's ignore_grad dummy batches) returns zeros rather than nothing: every rank must feed the
+    reducer in every step."""
+    if not getattr(holder, "_grads_through_autograd", False):
+        if c != 0.0:
+            _scaled_backward(eng, c, fresh, run)
+        if flat.grad is None:
+            flat.grad = eng.grads
+        eng.work_current = False  # an optimizer step may follow: see _prepare_step
+        return None
+    if flat.grad is eng.grads:  # an alias left from steps taken before the wrapper appeared: detach the accumulated gradient from it
+        flat.grad = eng.grads.clone()
+    eng.grads.zero_()
+    if c != 0.0:
+        run()
+    out = eng.grads.clone()
+    if c not in (0.0, 1.0):
+        out.mul_(c)
+    eng.work_current = False
+    return out
+
+
+def wrapped_by_torch_ddp(model) -> bool:
+    """Is `model` (or something it wraps: fairseq's ModuleProxyWrapper keeps the DDP module under `.module`) a torch
+    DistributedDataParallel?"""
+    m, seen = model, 0
+    while m is not None and seen < 8:
+        if isinstance(m, torch.nn.parallel.DistributedDataParallel):
+            return True
+        m, seen = getattr(m, "module", None), seen + 1
+    return False
 
 
 class _VaeStepFn(torch.autograd.Function):
@@ -247,13 +296,13 @@ class _VaeStepFn(torch.autograd.Function):
         if gs[0] != 0.0:
             if any(v != 0.0 for v in gs[1:]):
                 raise NotImplementedError("differentiate the HIP VAE either through its fused criterion loss (stats[0]) or through (mse, logits, kl), not both")
-            _scaled_backward(eng, gs[0], ctx.fresh, eng.backward)
+            g_flat = _finish_backward(ctx.flat, eng, ctx.module, eng.backward, gs[0], ctx.fresh)
         elif gs[2] != 0.0 or gs[3] != 0.0 or (g_logits is not None and bool(g_logits.ne(0).any())):  # zero: fairseq's ignore_grad
             ext = g_logits if g_logits is not None else torch.zeros_like(eng._keep[5])
-            eng.backward(ext_dlogits=ext, d_mse=gs[2], d_kl=gs[3])
-        if ctx.flat.grad is None:
-            ctx.flat.grad = eng.grads
-        return None, None, None, None, None, None, None
+            g_flat = _finish_backward(ctx.flat, eng, ctx.module, lambda: eng.backward(ext_dlogits=ext, d_mse=gs[2], d_kl=gs[3]), 1.0, True)
+        else:
+            g_flat = _finish_backward(ctx.flat, eng, ctx.module, eng.backward, 0.0, ctx.fresh)
+        return g_flat, None, None, None, None, None, None
 
 
 class _EpsStepFn(torch.autograd.Function):
@@ -274,11 +323,7 @@ class _EpsStepFn(torch.autograd.Function):
         if any(v != 0.0 for v in gs[1:]):
             raise NotImplementedError("the HIP diffusion loss is differentiated through total_loss")
         eng = ctx.owner._train_engine
-        if gs[0] != 0.0:
-            _scaled_backward(eng, gs[0], ctx.fresh, eng.backward)
-        if ctx.flat.grad is None:
-            ctx.flat.grad = eng.grads
-        return (None,) * 9
+        return (_finish_backward(ctx.flat, eng, ctx.owner, eng.backward, gs[0], ctx.fresh),) + (None,) * 8
 
 
 class SpeechVAEEncoderDecoder(_ParamTree):
@@ -334,7 +379,6 @@ class SpeechVAEEncoderDecoder(_ParamTree):
             del self._modules[name]
         self.flat_params = nn.Parameter(eng.master)
         self.flat_params.grad = eng.grads
-        self._seen_version = self.flat_params._version
         self._train_engine = eng
         self._engine = None
         return eng
@@ -474,7 +518,6 @@ class LatentDiscreteModel(nn.Module):
         eng = training.EpsTrainEngine(esd, self.model.cfg, self._frozen_vae, timesteps=self.timesteps, dtype=self.model.arith, device=dev,
                                       multitask=self.multitask)
         self.model._adopt_flat(eng)
-        self._seen_version = self.model.flat_params._version
         self._train_engine = eng
         return eng
 

@@ -112,6 +112,7 @@ class VaeTrainEngine:
         self.update_count = getattr(self, "update_count", 0) + 1
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dn_vae_train_refresh(self.handle, _lib.current_stream()), "dn_vae_train_refresh")
+        self.work_current = True  # (latent_module._prepare_step: cleared by the autograd bridge's backward)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return packing.unpack_flat(self.master, self.entries, self.offsets)
@@ -294,6 +295,7 @@ class EpsTrainEngine(_FlatEngine):
         self.update_count = getattr(self, "update_count", 0) + 1
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dn_eps_train_refresh(self.handle, _lib.current_stream()), "dn_eps_train_refresh")
+        self.work_current = True
 
     @property
     def n_stages(self) -> int:

@@ -2,6 +2,8 @@
 (oracle/gen_golden_train.py -> tests/golden/vae_train.npz: autograd gradients of every parameter + a 5-update trajectory driven
 like fairseq's trainer with the reference's own Adam / clip_grad_norm_ / inverse_sqrt classes).  Exact-fp32 mode carries the
 north_star budget (1e-3); bf16 mode is held to the oracle's gradients by direction and norm."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -207,6 +209,90 @@ class _FairseqStyleOptimizer:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+
+
+class _FairseqAdamThroughData(_FairseqStyleOptimizer):
+    """The update of fairseq's own Adam restated (fairseq/optim/adam.py:185-236): it works on `p.data` -- `p_data_fp32 = p.data;
+    exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1); ...; p_data_fp32.addcdiv_(exp_avg, denom, value=-step_size)` -- and in-place
+    operations on `.data` do NOT move the parameter's version counter, which is what round 3's bridge watched."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.98), eps=1e-8):
+        self._params = [p for p in model.parameters() if p.requires_grad]
+        self.lr, self.betas, self.eps, self.state = lr, betas, eps, {}
+
+    @property
+    def params(self):
+        yield from self._params
+
+    def step(self):
+        for p in self._params:
+            if p.grad is None:
+                continue
+            grad, p_data = p.grad.data.float(), p.data
+            st = self.state.setdefault(p, {"step": 0, "exp_avg": torch.zeros_like(p_data), "exp_avg_sq": torch.zeros_like(p_data)})
+            st["step"] += 1
+            b1, b2 = self.betas
+            st["exp_avg"].mul_(b1).add_(grad, alpha=1 - b1)
+            st["exp_avg_sq"].mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            denom = st["exp_avg_sq"].sqrt().add_(self.eps)
+            step_size = self.lr * math.sqrt(1 - b2 ** st["step"]) / (1 - b1 ** st["step"])
+            p_data.addcdiv_(st["exp_avg"], denom, value=-step_size)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_level1_with_an_optimizer_that_updates_through_p_data(golden, dtype):
+    """under `--optimizer adam` the reference's optimizer updates `flat_params` through `p.data`, the version
+    counter stays put, and round 3's bridge never refreshed the bf16 working copy / the transposed weights -- bf16 training did
+    nothing, f32 back-propagated through stale weights.  The bridge now keeps its own flag (latent_module._prepare_step): three
+    updates by such an optimizer equal the HIP-backed FlatOptimizer's (same kernel contract, eps inside sqrt(v)), the version
+    counter provably does not move, and the loss moves."""
+    import types
+
+    from diffnorm_amd import fairseq_plugin, optim  # noqa: F401
+    from diffnorm_amd.fairseq_plugin import registry
+
+    g = golden("vae_train")
+
+    def build():
+        args = types.SimpleNamespace(arch="speech_vae_decoder", criterion="speech_vae_decoder_loss", latent_dim=CFG.latent_dim,
+                                     feature_dim=CFG.dim, hip_dtype=dtype, target_code_size=1000, data="", optimizer="adam", lr=[1e-3])
+        task = registry.TASK_REGISTRY["speech_decoder"].setup_task(args)
+        model = task.build_model(args)
+        model.load_state_dict({"encoder." + k: v for k, v in O.make_vae_state_dict(CFG, "train").items()}, strict=True)
+        model.to(DEV)
+        model.encoder.attn_dropout = 0.0
+        return task, model, task.build_criterion(args)
+
+    task, model, criterion = build()
+    ext = _FairseqAdamThroughData(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    task2, model2, criterion2 = build()
+    ref = optim.FlatOptimizer(model2.encoder._train_engine, lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    v0 = model.encoder.flat_params._version
+    losses = []
+    for it in range(3):
+        sample = _sample(g, torch.from_numpy(g[f"traj_noise{it % 3}"]))
+        ext.zero_grad()
+        loss, n, _ = task.train_step(sample, model, criterion, ext, it)
+        ref.zero_grad()
+        loss2, _, _ = task2.train_step(sample, model2, criterion2, ref, it)
+        losses.append(float(loss.detach()))
+        tol = 1e-5 if dtype == "f32" else 2e-3
+        assert abs(float(loss.detach()) - float(loss2.detach())) <= tol * abs(float(loss2.detach())), (it, float(loss.detach()), float(loss2.detach()))
+        ext.multiply_grads(1.0 / n)
+        ref.multiply_grads(1.0 / n)
+        ext.step()
+        ref.step()
+        pa, pb = model.encoder._train_engine.master, model2.encoder._train_engine.master
+        assert float((pa - pb).norm() / pb.norm()) < (1e-6 if dtype == "f32" else 1e-4), (it, float((pa - pb).norm() / pb.norm()))
+    assert model.encoder.flat_params._version == v0, "the premise: an update through p.data is invisible to the version counter"
+    # the engine really computes with the updated weights: the same batch again gives a different loss than before the updates
+    sample = _sample(g, torch.from_numpy(g["traj_noise0"]))
+    ext.zero_grad()
+    loss_after, _, _ = task.train_step(sample, model, criterion, ext, 3)
+    assert abs(float(loss_after.detach()) - losses[0]) > 1e-3 * abs(losses[0])
+    eng = model.encoder._train_engine
+    if eng.work is not eng.master:  # bf16: the working copy is the rounding of the master buffer as of the last forward
+        assert torch.equal(eng.work, eng.master.to(torch.bfloat16))
 
 
 def test_level1_reference_trainer_order_with_an_external_optimizer(golden):
