@@ -371,27 +371,36 @@ def refine_leg(args, dev, stream):
            "src_tokens": [], "src_lengths": []}
     lengths = torch.full((B,), T, dtype=torch.long, device=dev)
 
-    def chain():
+    def chain(host_stepped=False):
         state = model.initialize_output_tokens(enc, None, true_length=lengths)
-        for step in range(iters):
+        if not host_stepped:  # one captured iteration (decoder pass + dn_cmlm_step_dev + counter) replayed: no host work between iterations
+            return model.refine(state._replace(step=0, max_step=iters), enc, iters)
+        for step in range(iters):  # the generator's own stepping: forward_decoder per iteration (each one graph launch + its copies)
             state = model.forward_decoder(state._replace(step=step, max_step=iters), enc)
         return state
 
-    with torch.cuda.stream(stream):
-        chain()
+    def timed(host_stepped):
+        chain(host_stepped)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            st = chain()
+            st = chain(host_stepped)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        return (time.perf_counter() - t0) / reps, st
+
+    with torch.cuda.stream(stream):
+        dt_host, st_host = timed(True)
+        dt, st = timed(False)
+    assert torch.equal(st.output_tokens, st_host.output_tokens)  # the replayed iterations are the host-stepped ones
     assert int(st.output_tokens.ne(3).sum()) == B * T  # every position decided after the last iteration
     flops = B * T * 2.0 * 6 * (4 * 512 * 512 + 2 * 512 * 512 + 2 * 512 * 2048 + 2 * 512 * (T + S)) + B * T * 2.0 * 512 * 1004
-    return {"refine": {"iterations_per_s": iters / dt, "ms_per_iteration": dt / iters * 1e3, "hypothesis_frames_per_s": B * T * iters / dt,
+    return {"refine": {"iterations_per_s": iters / dt, "ms_per_iteration": dt / iters * 1e3, "ms_per_iteration_host_stepped": dt_host / iters * 1e3,
+                       "hypothesis_frames_per_s": B * T * iters / dt,
                        "dtype": args.dtype, "tflops": flops * iters / dt / 1e12,
                        "what": f"NAR S2UT decoder (512 / 2048 / 6 layers / 8 heads / 1004 units) inside mask-predict refinement: B = {B}, T = {T}, "
-                               f"S = {S} encoder frames, {iters} iterations (decoder pass + dn_cmlm_step each), host-stepped like the reference's generator"}}
+                               f"S = {S} encoder frames, {iters} iterations (decoder pass + dn_cmlm_step each): one iteration captured into a hipGraph "
+                               f"with the iteration index on the device and replayed; host_stepped = forward_decoder per iteration as the reference's generator calls it"}}
 
 
 def cond_leg(args, dev, stream, B, T):
@@ -680,15 +689,12 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
         # the dominant backward kernel, timed where it runs: HIP events around the FFN causal conv's weight-gradient contraction
         # (one per transformer layer of the trained model) inside two more updates of the first batch shape
         # Twice: as the updates above ran it (on the second stream beside the data-gradient chain -- train_engine.hip: WgSide -- so
-        # the events also span the launches it shares the GPU with), and alone on the caller's stream (DN_WGRAD_STREAM=0): the
+        # the events also span the launches it shares the GPU with), and alone on the caller's stream (option wgrad_stream = 0): the
         # kernel's own rate, which is what the roofline object quotes.
         lib = _lib.load()
         timed = {}
         for mode in ("overlapped", "alone"):
-            prev = os.environ.get("DN_WGRAD_STREAM")
-            if mode == "alone":
-                os.environ["DN_WGRAD_STREAM"] = "0"
-            try:
+            with _lib.option("wgrad_stream", 0 if mode == "alone" else _lib.get_option("wgrad_stream")):
                 _lib.check(lib.dn_profile_start(_lib.TAG_FFN_CONV_WGRAD, 24), "dn_profile_start")
                 for _ in range(2):
                     if kind == "vae":
@@ -698,9 +704,6 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
                 k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
                 _lib.check(lib.dn_profile_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "dn_profile_stop")
                 timed[mode] = k_ms.value
-            finally:
-                if mode == "alone":
-                    os.environ.pop("DN_WGRAD_STREAM") if prev is None else os.environ.__setitem__("DN_WGRAD_STREAM", prev)
         ar_ms = 0.0
         if world > 1:  # all-reduce time of one update (buckets timed with events on the side stream)
             tr.reducer.measure = True
@@ -731,7 +734,7 @@ def train_summary(kind, dtype, max_tokens, K, m, world):
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flops_per_launch": m["k_flops"],
                          "avg_launch_ms": m["k_ms"], "launches_timed": m["k_n"],
                          "avg_launch_ms_beside_the_data_gradient_chain": m.get("k_ms_overlapped"),
-                         "timed": "alone on the caller's stream (DN_WGRAD_STREAM=0); in the measured updates it runs on a second stream beside the "
+                         "timed": "alone on the caller's stream (option wgrad_stream = 0); in the measured updates it runs on a second stream beside the "
                                   "data-gradient chain and its events span the launches it shares the GPU with",
                          "traffic": train_traffic_from_profiles() if kind == "vae" else None}}
 

@@ -189,6 +189,9 @@ SYMBOLS = {
     "dn_eps_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_eps_cond_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "dn_eps_forward_cond": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_eps_forward_cond_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _i32, _vp, _i32, _i32, _vp]),
+    "dn_eps_cond_time_table_workspace_bytes": (_sz, [_vp, _i32]),
+    "dn_eps_cond_time_table": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_vae_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "dn_vae_destroy": (None, [_vp]),
     "dn_vae_workspace_bytes": (_sz, [_vp, _i32, _i32]),
@@ -207,7 +210,40 @@ SYMBOLS = {
     "dn_nar_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_last_error": (C.c_char_p, []),
     "dn_version": (C.c_int, []),
+    "dn_cmlm_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "dn_set_option": (C.c_int, [C.c_char_p, _i32]),
+    "dn_get_option": (C.c_int, [C.c_char_p, _vp, _vp]),
 }
+
+OPTION_DEFAULT = -2147483648
+
+
+def set_option(name: str, value) -> None:
+    """dn_set_option: a process-wide run-time option of the library (include/diffnorm_hip.h); value None = back to its start value."""
+    check(load().dn_set_option(name.encode(), OPTION_DEFAULT if value is None else int(value)), "dn_set_option")
+
+
+def get_option(name: str):
+    """Current value of a run-time option, or None when it is neither set nor in the environment."""
+    v, on = C.c_int32(), C.c_int32()
+    check(load().dn_get_option(name.encode(), C.addressof(v), C.addressof(on)), "dn_get_option")
+    return v.value if on.value else None
+
+
+class option:
+    """with _lib.option("taps_inner", 2): ...  -- sets a run-time option and restores what was there before."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
 
 _lib = None
 

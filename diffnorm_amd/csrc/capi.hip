@@ -14,4 +14,63 @@ void dn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dn_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ run-time options
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+namespace {
+struct OptDef { const char* name; const char* env; const char* env_old; };
+// name (dn_set_option) <- environment variable that seeds it at first use
+const OptDef kOpts[dn::OPT_COUNT] = {
+    {"taps_inner", "DN_TAPS_INNER", "DN_FAT_TAPS_INNER"},  // K order of a causal conv's taps: 0 term-outer everywhere, 1 tap-inner on the 256-row tiles (default), 2 routed by shape
+    {"fuse_norm", "DN_FUSE_NORM", nullptr},                // 1: residual-closing contractions on the whole-row tile that also emits the next RMSNorm
+    {"no_split_norm", "DN_NO_SPLIT_NORM", nullptr},        // 1: stand-alone RMSNorm kernels instead of the split norm
+    {"kblock", "DN_KBLOCK", nullptr},                      // 0 never / 1 always K-blocked operands (unset: where the consuming tile gains)
+    {"wgrad_stream", "DN_WGRAD_STREAM", nullptr},          // 0: weight gradients on the caller's stream
+    {"wgrad_tn", "DN_WGRAD_TN", nullptr},                  // 0: weight gradients from transposed operand copies
+    {"wgrad_groups", "DN_WGRAD_GROUPS", nullptr},          // 0: one weight-gradient launch per WaveNet block
+};
+std::atomic<int> g_opt[dn::OPT_COUNT];
+std::once_flag g_opt_once;
+int env_value(const OptDef& d) {
+  const char* e = getenv(d.env);
+  if (!e && d.env_old) e = getenv(d.env_old);
+  return e ? atoi(e) : dn::DN_OPT_UNSET;
+}
+void init_options() {
+  for (int i = 0; i < dn::OPT_COUNT; ++i) g_opt[i].store(env_value(kOpts[i]), std::memory_order_relaxed);
+}
+int find_option(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < dn::OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+int dn::option(dn::Opt o) {
+  std::call_once(g_opt_once, init_options);
+  return g_opt[o].load(std::memory_order_relaxed);
+}
+
+extern "C" int dn_set_option(const char* name, int32_t value) {
+  const int i = find_option(name);
+  DN_CHECK_ARG(i >= 0, "dn_set_option: unknown option '%s'", name ? name : "(null)");
+  std::call_once(g_opt_once, init_options);
+  g_opt[i].store(value == DN_OPTION_DEFAULT ? env_value(kOpts[i]) : value, std::memory_order_relaxed);
+  return DN_OK;
+}
+
+extern "C" int dn_get_option(const char* name, int32_t* value, int32_t* is_set) {
+  const int i = find_option(name);
+  DN_CHECK_ARG(i >= 0 && value, "dn_get_option: unknown option '%s'", name ? name : "(null)");
+  const int v = dn::option(static_cast<dn::Opt>(i));
+  *value = v == dn::DN_OPT_UNSET ? 0 : v;
+  if (is_set) *is_set = v != dn::DN_OPT_UNSET;
+  return DN_OK;
+}
 extern "C" int dn_version(void) { return 100; }

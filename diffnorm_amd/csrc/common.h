@@ -231,6 +231,16 @@ extern LaunchProfile g_prof;  // defined in gemm.hip
 
 // host-side error plumbing (defined in capi.hip)
 void dn_set_error(const char* fmt, ...);
+
+// Run-time options of the library (dn_set_option / dn_get_option, include/diffnorm_hip.h).  Each starts from the environment
+// variable of the same meaning, read ONCE when the library first looks (a process-wide default), and is switched afterwards through
+// the C ABI only -- no per-launch getenv, no environment mutation by callers.  DN_OPT_UNSET: neither set nor in the environment.
+namespace dn {
+enum Opt { OPT_TAPS_INNER = 0, OPT_FUSE_NORM, OPT_NO_SPLIT_NORM, OPT_KBLOCK, OPT_WGRAD_STREAM, OPT_WGRAD_TN, OPT_WGRAD_GROUPS, OPT_COUNT };
+constexpr int DN_OPT_UNSET = -2147483647 - 1;
+int option(Opt o);                       // current value or DN_OPT_UNSET
+inline int option_or(Opt o, int dflt) { const int v = option(o); return v == DN_OPT_UNSET ? dflt : v; }
+}  // namespace dn
 #define DN_CHECK_ARG(cond, ...)  \
   do {                           \
     if (!(cond)) {               \

@@ -18,8 +18,7 @@ namespace {
 // norm_out).  Measured on [32,512] x dim 512 it loses to 256 x 128 tiles + a standalone norm kernel (one workgroup
 // re-reads the whole weight for 64 rows): 6.85 vs 6.63 ms per denoising step.  Off unless DN_FUSE_NORM=1.
 inline bool fuse_norm_enabled(int Dp, int dtype) {
-  const char* e = getenv("DN_FUSE_NORM");  // read per call: tests toggle it
-  const bool on = e && atoi(e) != 0;
+  const bool on = option_or(OPT_FUSE_NORM, 0) != 0;  // dn_set_option("fuse_norm", 1)
   return on && Dp <= 512 && dtype != DN_BF16X3;  // (the whole-row tile is not built for split operands)
 }
 
@@ -31,8 +30,7 @@ static thread_local bool g_twin_launches = false;
 // over the residual stream disappear (measured: -6 % per denoising step at [32,512] x dim 512).  DN_NO_SPLIT_NORM=1 runs
 // the standalone norm kernel instead (A/B timing, and the reference point of the parity tests).
 inline bool split_norm_enabled(int Dp, int dtype) {
-  const char* e = getenv("DN_NO_SPLIT_NORM");  // read per call: tests toggle it
-  return !(e && atoi(e) != 0) && Dp % 64 == 0 && !fuse_norm_enabled(Dp, dtype);
+  return option_or(OPT_NO_SPLIT_NORM, 0) == 0 && Dp % 64 == 0 && !fuse_norm_enabled(Dp, dtype);
 }
 // DN_BF16X3: tensors that are read by an epilogue or by the attention kernel rather than staged as a contraction operand stay
 // plain fp32 (the WaveNet block's residual branch, q / k / v)
@@ -41,8 +39,8 @@ inline int side_dtype(int dtype) { return dtype == DN_BF16X3 ? DN_F32 : dtype; }
 // DN_KBLOCK: unset = K-blocked buffers where the consuming contraction lands on a tile that gains from them, 0 = never,
 // 1 = always (the contraction then runs on a tile that takes them; tests).  Read per call (host side, once per capture).
 int kblock_mode() {
-  const char* e = getenv("DN_KBLOCK");
-  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  const int v = option(OPT_KBLOCK);  // dn_set_option("kblock", 0 / 1); DN_OPTION_DEFAULT = by tile
+  return v == DN_OPT_UNSET ? -1 : (v != 0 ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------ WaveNet
@@ -738,6 +736,19 @@ __global__ __launch_bounds__(256) void assemble_cond2_kernel(const float* __rest
     out[i] = c < C ? tc[(int64_t)b * C + c] : (drop[b] ? null_pc[c - C] : pc[(int64_t)b * C + c - C]);
   }
 }
+// gb[b] = table[t[b] - t0] + gbp[b]: the conditioning rows of a step from the chain's time table and the prompt half
+__global__ __launch_bounds__(256) void cond_rows_from_table_kernel(const float* __restrict__ table, const int32_t* __restrict__ t, int t0, int n_t,
+                                                                   const float* __restrict__ gbp, int B, int n, float* __restrict__ gb) {
+  const int64_t tot = (int64_t)B * (n / 4);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / (n / 4)), c = (int)(i - (int64_t)b * (n / 4)) * 4;
+    int r = t[b] - t0;
+    r = r < 0 ? 0 : (r >= n_t ? n_t - 1 : r);
+    const float4 a = *reinterpret_cast<const float4*>(table + (int64_t)r * n + c);
+    const float4 p = *reinterpret_cast<const float4*>(gbp + (int64_t)b * n + c);
+    *reinterpret_cast<float4*>(gb + (int64_t)b * n + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
 // dst rows [b, row0 + j] (row stride of a sample: rows_total) <- src rows: sample-indexed [b, j] (src_bstride = rows * ld) or shared
 // (src_bstride = 0); optional per-sample override by `alt` (shared rows) where flag[b] != 0.  fp32 or bf16 sources -> dst dtype.
 __global__ __launch_bounds__(256) void place_rows_kernel(const void* __restrict__ src, int src_dtype, int64_t src_bstride, const void* __restrict__ alt,
@@ -762,6 +773,10 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const void* __restrict_
       reinterpret_cast<float*>(dst)[o] = v;
   }
 }
+__global__ void iota_i32_kernel(int32_t first, int32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = first + i;
+}
 __global__ void add_const_i32_kernel(const int32_t* __restrict__ a, int32_t c, int32_t cap, int32_t* __restrict__ out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (a[i] < cap ? a[i] : cap) + c;
@@ -771,7 +786,7 @@ __global__ void add_const_i32_kernel(const int32_t* __restrict__ a, int32_t c, i
 namespace {
 
 struct CondBufs {
-  float *cond, *pooled, *pc, *cond2, *gb, *lat, *xres;
+  float *cond, *pooled, *pc, *cond2, *gb, *gbp, *lat, *xres;
   void *prompt_act, *ctx, *kvsrc, *lat_act, *rq, *rkv, *rao, *rgg, *c_act, *ckv, *xin, *h0, *xn, *qkv, *ao, *cq, *gg, *fc, *tp;
   int32_t* klen;
   WaveBufs wv;
@@ -786,6 +801,7 @@ CondBufs plan_eps_cond(const DnEps* m, int B, int T, int Tp, Arena& ar) {
   memset(&b, 0, sizeof(b));
   b.cond = (float*)ar.take(B * C * 4); b.pooled = (float*)ar.take(B * Pp * 4); b.pc = (float*)ar.take(B * C * 4);
   b.cond2 = (float*)ar.take(B * 2 * C * 4); b.gb = (float*)ar.take((size_t)B * m->n_cond * 4);
+  b.gbp = (float*)ar.take((size_t)B * m->n_cond * 4);  // the prompt half of the conditioning rows (+ bias): prompt-only, kept across steps
   b.prompt_act = ar.take((size_t)B * Tp * Pp * es); b.ctx = ar.take((size_t)B * Tp * Dp * es);
   b.kvsrc = ar.take(B * Lk * Dp * es); b.lat = (float*)ar.take(B * ml * Dp * 4); b.lat_act = ar.take(B * ml * Dp * es);
   b.rq = ar.take(B * ml * hd * es); b.rkv = ar.take(B * Lk * 2 * hd * es); b.rao = ar.take(B * ml * hd * es);
@@ -823,7 +839,40 @@ extern "C" size_t dn_eps_cond_workspace_bytes(const DnEps* m, int32_t B, int32_t
 extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
                                    const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return dn_eps_forward_cond_ex(m, x, t, lengths, prompt, prompt_lengths, drop, B, T, Tp, eps_out, workspace, workspace_bytes, 0, nullptr, 0, 0, stream);
+}
+
+// The time half of the conditioning rows for timesteps t0 .. t0 + n_t - 1 of a chain: table[i] = W_c[:, :C] . time_cond(t0 + i)
+// (no bias: it rides on the prompt half).  fp32 [n_t, n_cond].  workspace: n_t * (C + 1) * 4 bytes (+ 256).
+extern "C" size_t dn_eps_cond_time_table_workspace_bytes(const DnEps* m, int32_t n_t) {
+  if (!m || n_t <= 0) return 0;
+  return (size_t)n_t * ((size_t)m->cfg.dim * m->cfg.cond_mult + 1) * 4 + 512;
+}
+extern "C" int dn_eps_cond_time_table(DnEps* m, int32_t t0, int32_t n_t, float* table, void* workspace, size_t workspace_bytes, void* stream) {
+  DN_CHECK_ARG(m && table && workspace && n_t > 0 && t0 >= 0, "dn_eps_cond_time_table: bad argument");
+  DN_CHECK_ARG(m->cfg.dim_prompt > 0, "dn_eps_cond_time_table: the model was created without a prompt branch");
+  DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && workspace_bytes >= dn_eps_cond_time_table_workspace_bytes(m, n_t) - 256, "dn_eps_cond_time_table: workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->cfg.dim, C = D * m->cfg.cond_mult;
+  int32_t* times = (int32_t*)workspace;
+  float* cond = (float*)((char*)workspace + (((size_t)n_t * 4 + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(dn::iota_i32_kernel, dim3((n_t + 255) / 256), dim3(256), 0, s, t0, times, n_t);
+  DN_TRY(dn_time_cond(times, n_t, m->w_freq, D / 2, m->tc_W, m->tc_b, C, cond, nullptr, DN_F32, C, s));
+  DnGemmParams p = gemm_base(DN_F32, n_t, m->n_cond, C, 1);
+  p.terms[0].A = cond; p.terms[0].lda = C; p.terms[0].W = m->cond_W; p.terms[0].ldw = 2 * C;
+  p.out = table; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+  DN_TRY(dn_conv_gemm(&p, s));
+  DN_CHECK_LAUNCH("dn_eps_cond_time_table");
+  return DN_OK;
+}
+
+extern "C" int dn_eps_forward_cond_ex(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
+                                      const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
+                                      void* workspace, size_t workspace_bytes, int32_t flags, const float* time_table, int32_t table_t0,
+                                      int32_t table_n, void* stream) {
+  const bool reuse_prompt = (flags & DN_COND_REUSE_PROMPT) != 0;
   DN_CHECK_ARG(m && x && t && lengths && prompt && prompt_lengths && drop && eps_out && workspace, "dn_eps_forward_cond: null argument");
+  DN_CHECK_ARG(!time_table || table_n > 0, "dn_eps_forward_cond: a time table needs its row count");
   DN_CHECK_ARG(m->cfg.dim_prompt > 0, "dn_eps_forward_cond: the model was created without a prompt branch (cfg.dim_prompt == 0)");
   DN_CHECK_ARG(B > 0 && T > 0 && Tp > 0 && T <= m->cfg.max_pos, "dn_eps_forward_cond: B=%d T=%d Tp=%d", B, T, Tp);
   DN_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "dn_eps_forward_cond: workspace must be 256-byte aligned");
@@ -838,8 +887,13 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
   const int dtype = c.dtype, es = esize(dtype), M = B * T;
   const int D = c.dim, Dp = padk(D), Dn = padn(D), z = c.latent, zp = padk(z), C = D * c.cond_mult, P = c.dim_prompt, Pp = padk(P);
   const int hd = c.heads * c.dim_head, ip = padk(m->tf.inner), in_n = padn(m->tf.inner), ml = c.num_latents, Lk = ml + Tp, R = c.resampler_depth;
-  // ---- conditioning rows: [time cond | pooled-prompt cond] -> FiLM / adaptive-norm [gamma ; beta] (:841-852), fp32
-  DN_TRY(dn_time_cond(t, B, m->w_freq, D / 2, m->tc_W, m->tc_b, C, b.cond, nullptr, DN_F32, C, s));
+  // ---- conditioning rows: [time cond | pooled-prompt cond] -> FiLM / adaptive-norm [gamma ; beta] (:841-852), fp32.  The
+  // projection is linear in its two halves, so the rows are formed as (time half) + (prompt half + bias): the prompt half and
+  // everything else that depends on the prompt only -- the resampler and every layer's cross-attention keys / values -- is computed
+  // once and kept in the workspace (DN_COND_REUSE_PROMPT: a later call on the same workspace and shapes skips it), and the time
+  // half of a whole chain can come from dn_eps_cond_time_table (the 1.1 GB projection is then never streamed inside the loop).
+  if (!time_table) DN_TRY(dn_time_cond(t, B, m->w_freq, D / 2, m->tc_W, m->tc_b, C, b.cond, nullptr, DN_F32, C, s));
+  if (!reuse_prompt) {
   hipLaunchKernelGGL(dn::prompt_pool_kernel, dim3(B), dim3(256), 0, s, prompt, prompt_lengths, B, Tp, P, Pp, b.pooled);
   {  // to_prompt_cond: Linear(P -> C) + SiLU (:760-764)
     DnGemmParams p = gemm_base(DN_F32, B, C, Pp, 1);
@@ -847,11 +901,11 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     p.bias = m->tpc_b; p.epilogue = DN_EPI_SILU; p.out = b.pc; p.ldo = C; p.out_dtype = DN_F32;
     DN_TRY(dn_conv_gemm(&p, s));
   }
-  hipLaunchKernelGGL(dn::assemble_cond2_kernel, dim3(ew((int64_t)B * 2 * C)), dim3(256), 0, s, b.cond, b.pc, m->null_pc, drop, B, C, b.cond2);
-  {
-    DnGemmParams p = gemm_base(DN_F32, B, m->n_cond, 2 * C, 1);
-    p.terms[0].A = b.cond2; p.terms[0].lda = 2 * C; p.terms[0].W = m->cond_W;
-    p.bias = m->cond_b; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
+  hipLaunchKernelGGL(dn::assemble_cond2_kernel, dim3(ew((int64_t)B * 2 * C)), dim3(256), 0, s, b.pc, b.pc, m->null_pc, drop, B, C, b.cond2);  // (second half: pc or null_pc by drop)
+  {  // prompt half + bias
+    DnGemmParams p = gemm_base(DN_F32, B, m->n_cond, C, 1);
+    p.terms[0].A = b.cond2 + C; p.terms[0].lda = 2 * C; p.terms[0].W = reinterpret_cast<const float*>(m->cond_W) + C; p.terms[0].ldw = 2 * C;
+    p.bias = m->cond_b; p.out = b.gbp; p.ldo = m->n_cond; p.out_dtype = DN_F32;
     DN_TRY(dn_conv_gemm(&p, s));
   }
   // ---- PerceiverResampler (:416-471): prompt -> ml latents per sample
@@ -916,6 +970,17 @@ extern "C" int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, c
     p.terms[0].A = b.c_act; p.terms[0].lda = Dp; p.terms[0].a_gstride = 0;
     p.terms[0].W = m->ckv_W; p.terms[0].w_gstride = (int64_t)padn(2 * hd) * Dp;
     p.out = b.ckv; p.ldo = 2 * hd; p.out_gstride = (int64_t)B * ml * 2 * hd; p.out_dtype = side_dtype(dtype);
+    DN_TRY(dn_conv_gemm(&p, s));
+  }
+  }  // !reuse_prompt
+  // ---- the step's conditioning rows: time half (from the chain's table, or contracted here) + prompt half
+  if (time_table) {
+    hipLaunchKernelGGL(dn::cond_rows_from_table_kernel, dim3(ew((int64_t)B * m->n_cond / 4)), dim3(256), 0, s, time_table, t, table_t0, table_n, b.gbp, B,
+                       m->n_cond, b.gb);
+  } else {
+    DnGemmParams p = gemm_base(DN_F32, B, m->n_cond, C, 1);
+    p.terms[0].A = b.cond; p.terms[0].lda = C; p.terms[0].W = m->cond_W; p.terms[0].ldw = 2 * C;
+    p.epilogue = DN_EPI_RESADD; p.res = b.gbp; p.ldr = m->n_cond; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
     DN_TRY(dn_conv_gemm(&p, s));
   }
   // ---- the eps-predictor proper (:861-876)

@@ -2118,14 +2118,9 @@ static int launch_tile(const DnGemmParams& p, hipStream_t s) {
 // with it the last bits, relative to the 128-byte-K-tile variants (term-outer): a batch large enough to route to these tiles and
 // a smaller one do not agree to the last bit; equal-size shards do.  DN_TAPS_INNER=0 (or DN_FAT_TAPS_INNER=0, the older name)
 // or bit 23 of pad_ restores term-outer everywhere (bit 22 forces tap-inner).
-static inline bool taps_route_by_shape() {
-  const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
-  return e && atoi(e) == 2;
-}
+static inline bool taps_route_by_shape() { return option_or(OPT_TAPS_INNER, 1) == 2; }  // dn_set_option("taps_inner", 2)
 static inline bool terms_are_taps(const DnGemmParams& p) {
-  const char* e = getenv("DN_TAPS_INNER");  // read per launch (host side): tests switch it
-  if (!e) e = getenv("DN_FAT_TAPS_INNER");
-  const bool env_taps = !(e && atoi(e) == 0);
+  const bool env_taps = option_or(OPT_TAPS_INNER, 1) != 0;
   bool taps = p.n_terms >= 2 && p.n_terms <= 4 && !((p.pad_ >> 23) & 1) && (env_taps || ((p.pad_ >> 22) & 1));
   for (int i = 0; i < p.n_terms; ++i) taps = taps && p.terms[i].layout == p.terms[0].layout && p.terms[i].shift >= 0;
   for (int i = 1; i < p.n_terms && taps; ++i) {

@@ -434,8 +434,16 @@ __global__ __launch_bounds__(256) void gaussian_moments_kernel(const DnGaussianM
 // One workgroup per sequence (T <= 2048).  Phase 1: every position holding `unk` (the mask symbol) takes argmax / max of
 // log_softmax(logits[b, t, :]) (one wave per position).  Phase 2 (not on the last iteration): the boundary lowest-scoring
 // positions -- boundary = trunc((n_nonpad - 2) * p), scores ascending, ties by position -- are re-masked (token = unk, score = 0).
+// step_dev != nullptr: the iteration index is read from the device (a captured refinement iteration is replayed while a device
+// counter advances: nothing of the iteration is baked into the graph) and p / remask are derived here exactly as the host derives them.
 __global__ __launch_bounds__(256) void cmlm_step_kernel(const float* __restrict__ logits, int32_t* __restrict__ tokens, float* __restrict__ scores,
-                                                        int32_t* __restrict__ predicted, int T, int V, float p, int remask, int unk, int pad) {
+                                                        int32_t* __restrict__ predicted, int T, int V, float p, int remask, int unk, int pad,
+                                                        const int32_t* __restrict__ step_dev, int max_step) {
+  if (step_dev) {
+    const int step = *step_dev;
+    remask = (step + 1) < max_step;
+    p = (float)(1.0 - (double)(step + 1) / (double)max_step);  // the Python float of the reference, cast to the scores' fp32
+  }
   __shared__ float s_sc[2048];
   __shared__ int32_t s_tok[2048];
   __shared__ int s_n;
@@ -626,7 +634,18 @@ extern "C" int dn_cmlm_step(const float* logits, int32_t* tokens, float* scores,
                "dn_cmlm_step: bad args (T=%d must be <= 2048)", T);
   const int remask = (step + 1) < max_step;
   const float p = (float)(1.0 - (double)(step + 1) / (double)max_step);  // the Python float of the reference, cast to the scores' fp32
-  hipLaunchKernelGGL(cmlm_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, tokens, scores, predicted, T, V, p, remask, unk, pad);
+  hipLaunchKernelGGL(cmlm_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, tokens, scores, predicted, T, V, p, remask, unk, pad,
+                     (const int32_t*)nullptr, max_step);
   DN_CHECK_LAUNCH("dn_cmlm_step");
+  return DN_OK;
+}
+
+extern "C" int dn_cmlm_step_dev(const float* logits, int32_t* tokens, float* scores, int32_t* predicted, int32_t B, int32_t T, int32_t V,
+                                const int32_t* step_dev, int32_t max_step, int32_t unk, int32_t pad, void* stream) {
+  DN_CHECK_ARG(logits && tokens && scores && predicted && step_dev && B > 0 && T > 0 && T <= 2048 && V > 1 && max_step > 0,
+               "dn_cmlm_step_dev: bad args (T=%d must be <= 2048)", T);
+  hipLaunchKernelGGL(cmlm_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, tokens, scores, predicted, T, V, 0.f, 0, unk, pad,
+                     step_dev, max_step);
+  DN_CHECK_LAUNCH("dn_cmlm_step_dev");
   return DN_OK;
 }

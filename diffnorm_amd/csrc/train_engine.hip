@@ -204,8 +204,7 @@ struct WgSide {
 WgSide* wg_side() {
   static WgSide side;
   static bool tried = false, ok = false;
-  const char* e = getenv("DN_WGRAD_STREAM");
-  if (e && atoi(e) == 0) return nullptr;
+  if (option_or(OPT_WGRAD_STREAM, 1) == 0) return nullptr;
   if (!tried) {
     tried = true;
     ok = hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
@@ -314,10 +313,9 @@ int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const voi
   // bf16: straight from the row-major operands (wgrad_tn.hip: transposing LDS reads, no channel-major copies).  Slices of the
   // frames until about 160 tile-slices (at least 256 frames each), partial sums in the scratch the transposed copies would use;
   // a contraction that has its tiles anyway accumulates straight into the gradient.  DN_WGRAD_TN=0: the transposed-copies form.
-  const char* tn_env = getenv("DN_WGRAD_TN");
-  const bool use_tn = c.es == 2 && !(tn_env && atoi(tn_env) == 0);
-  const char* grp_env = getenv("DN_WGRAD_GROUPS");  // 0: one launch per block also in the row-major form (A/B timing)
-  if (grp && grp->groups > 1 && (!use_tn || (grp_env && atoi(grp_env) == 0))) {  // the transposed-copies form has no groups: one call per group
+  const bool use_tn = c.es == 2 && option_or(OPT_WGRAD_TN, 1) != 0;
+  const bool grouped = option_or(OPT_WGRAD_GROUPS, 1) != 0;  // 0: one launch per block also in the row-major form (A/B timing)
+  if (grp && grp->groups > 1 && (!use_tn || !grouped)) {  // the transposed-copies form has no groups: one call per group
     for (int g = 0; g < grp->groups; ++g) {
       WgTap tg[DN_MAX_TERMS];
       for (int j = 0; j < n_taps; ++j)

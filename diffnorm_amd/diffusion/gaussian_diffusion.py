@@ -92,7 +92,21 @@ class GaussianDiffusion(ScheduleTables):
     def _start_x(self) -> int:
         return int(self.model_mean_type == ModelMeanType.START_X)
 
-    def _step(self, model, x, t, noise, clip_denoised, sampler, eta=0.0, model_kwargs=None, cond_fn=None):
+    def _through_denoised_fn(self, out, x, t, denoised_fn):
+        """`denoised_fn`: "a function which applies to the x_start prediction before it is used to sample; applies before
+        clip_denoised" (:263-265, process_xstart :309-314) -- a host callable between the two halves of the fused step.  Un-fused
+        fallback: the kernel first produces the UNCLIPPED x_0 prediction of the model output (whatever its mean type), the
+        callable maps it, and the result goes back in as a START_X model output (with the learned-variance channels it came
+        with), so the second kernel call clips it, forms the posterior mean and samples exactly as upstream does from the
+        processed prediction.  -> (model output to hand to the kernel, start_x flag)."""
+        x0 = self._moments(x, t, model_out=out, clip_denoised=False, want=("pred_xstart",))["pred_xstart"]
+        x0 = denoised_fn(x0).float().contiguous()
+        assert x0.shape == x.shape, "denoised_fn must keep the shape of the x_start prediction"
+        if self.model_var_type == ModelVarType.LEARNED_RANGE:
+            return torch.cat([x0, out[:, x.shape[1]:]], dim=1).contiguous(), 1
+        return x0, 1
+
+    def _step(self, model, x, t, noise, clip_denoised, sampler, eta=0.0, model_kwargs=None, cond_fn=None, denoised_fn=None):
         lib = _lib.load()
         x = x.float().contiguous()
         out = model(x, t, **(model_kwargs or {}))
@@ -102,6 +116,9 @@ class GaussianDiffusion(ScheduleTables):
         learned = self.model_var_type == ModelVarType.LEARNED_RANGE
         B, Cc = x.shape[:2]
         assert out.shape == ((B, Cc * 2, *x.shape[2:]) if learned else x.shape)
+        start_x = self._start_x
+        if denoised_fn is not None:
+            out, start_x = self._through_denoised_fn(out, x, t, denoised_fn)
         tab, _, _ = self._table(x.device)
         sample, x0 = torch.empty_like(x), torch.empty_like(x)
         nz = noise.float().contiguous() if noise is not None else None
@@ -111,23 +128,19 @@ class GaussianDiffusion(ScheduleTables):
         assert grad is None or grad.shape == x.shape
         p = _lib.GaussianStep(x.data_ptr(), out.data_ptr(), _lib.ptr(nz), sample.data_ptr(), x0.data_ptr(),
                               self._t32(t, x.device).data_ptr(), tab.data_ptr(), B, x[0].numel(), int(learned),
-                              int(clip_denoised), sampler, float(eta), self._start_x, _lib.ptr(grad))
+                              int(clip_denoised), sampler, float(eta), start_x, _lib.ptr(grad))
         _lib.check(lib.dn_gaussian_step(C.byref(p), _lib.current_stream()), "dn_gaussian_step")
         return {"sample": sample, "pred_xstart": x0}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
         """x_{t-1} ~ p(. | x_t) (:376-417).  `noise` may be injected; otherwise it is drawn like upstream (randn_like)."""
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn (a host callable in the middle of the fused step) is not built")
         noise = torch.randn_like(x) if noise is None else noise
-        return self._step(model, x, t, noise, clip_denoised, 0, model_kwargs=model_kwargs, cond_fn=cond_fn)
+        return self._step(model, x, t, noise, clip_denoised, 0, model_kwargs=model_kwargs, cond_fn=cond_fn, denoised_fn=denoised_fn)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0, noise=None):
         """(:513-560)."""
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn (a host callable in the middle of the fused step) is not built")
         noise = torch.randn_like(x) if noise is None else noise
-        return self._step(model, x, t, noise, clip_denoised, 1, eta=eta, model_kwargs=model_kwargs, cond_fn=cond_fn)
+        return self._step(model, x, t, noise, clip_denoised, 1, eta=eta, model_kwargs=model_kwargs, cond_fn=cond_fn, denoised_fn=denoised_fn)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False):
@@ -138,7 +151,7 @@ class GaussianDiffusion(ScheduleTables):
         for i in list(range(self.num_timesteps))[::-1]:
             t = torch.tensor([i] * shape[0], device=device)
             with torch.no_grad():
-                out = self.p_sample(model, img, t, clip_denoised=clip_denoised, cond_fn=cond_fn, model_kwargs=model_kwargs)
+                out = self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs)
                 yield out
                 img = out["sample"]
 
@@ -146,8 +159,8 @@ class GaussianDiffusion(ScheduleTables):
                       device=None, progress=False):
         """(:419-457)."""
         final = None
-        for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised, cond_fn=cond_fn,
-                                                     model_kwargs=model_kwargs, device=device):
+        for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                                     cond_fn=cond_fn, model_kwargs=model_kwargs, device=device):
             final = sample
         return final["sample"]
 
@@ -209,10 +222,12 @@ class GaussianDiffusion(ScheduleTables):
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """p(x_{t-1} | x_t) and the x_0 prediction (:254-332)."""
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not on the DiffNorm path")
         out, extra = self._model_out(model, x, t, model_kwargs)
-        o = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("mean", "variance", "log_variance", "pred_xstart"))
+        start_x = None
+        if denoised_fn is not None:
+            out, start_x = self._through_denoised_fn(out, x.float().contiguous(), t, denoised_fn)
+            start_x = bool(start_x)
+        o = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("mean", "variance", "log_variance", "pred_xstart"), start_x=start_x)
         o["extra"] = extra
         return o
 
@@ -287,9 +302,17 @@ class GaussianDiffusion(ScheduleTables):
     def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
         """x_{t+1} along the deterministic DDIM path (:562-598)."""
         assert eta == 0.0, "Reverse ODE only for deterministic path"
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn (a host callable in the middle of the fused step) is not built")
         out, _ = self._model_out(model, x, t, model_kwargs)
+        if denoised_fn is not None and cond_fn is None:
+            out, _ = self._through_denoised_fn(out, x.float().contiguous(), t, denoised_fn)
+            o = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("reverse_sample", "pred_xstart"), start_x=True)
+            return {"sample": o["reverse_sample"], "pred_xstart": o["pred_xstart"]}
+        if denoised_fn is not None:
+            out, sx = self._through_denoised_fn(out, x.float().contiguous(), t, denoised_fn)
+            pmv = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("mean", "variance", "log_variance", "pred_xstart"), start_x=True)
+            x0 = self.condition_score(cond_fn, pmv, x, t, model_kwargs=model_kwargs)["pred_xstart"]
+            o = self._moments(x, t, model_out=x0, clip_denoised=False, want=("reverse_sample", "pred_xstart"), learned=False, start_x=True)
+            return {"sample": o["reverse_sample"], "pred_xstart": o["pred_xstart"]}
         if cond_fn is not None:  # (:579-580): the conditioned x_0 prediction, then the reverse-ODE step from it (START_X form)
             pmv = self._moments(x, t, model_out=out, clip_denoised=clip_denoised, want=("mean", "variance", "log_variance", "pred_xstart"))
             x0 = self.condition_score(cond_fn, pmv, x, t, model_kwargs=model_kwargs)["pred_xstart"]

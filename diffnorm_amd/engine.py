@@ -107,10 +107,24 @@ class EpsEngine(_Engine):
                        "dn_eps_forward")
         return out
 
+    def cond_time_table(self, t0: int, n_t: int) -> torch.Tensor:
+        """The time half of the conditioning rows of timesteps t0 .. t0 + n_t - 1 (dn_eps_cond_time_table): fp32 [n_t, n_cond]."""
+        n_cond = (self.cfg.wavenet_stacks * self.cfg.wavenet_layers + 3 * self.cfg.depth) * 2 * packing.padk(self.cfg.dim)
+        table = torch.empty(n_t, n_cond, dtype=torch.float32, device=self.device)
+        ws = torch.empty(int(self.lib.dn_eps_cond_time_table_workspace_bytes(self.handle, n_t)) + 256, dtype=torch.uint8, device=self.device)
+        wp, wn = self._aligned(ws)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_eps_cond_time_table(self.handle, int(t0), int(n_t), table.data_ptr(), wp, wn, _lib.current_stream()),
+                       "dn_eps_cond_time_table")
+        return table
+
     def forward_cond(self, x: torch.Tensor, times: torch.Tensor, lengths: torch.Tensor, prompt: torch.Tensor, prompt_lengths: torch.Tensor,
-                     drop: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     drop: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, reuse_prompt: bool = False,
+                     time_table: Optional[torch.Tensor] = None, table_t0: int = 0) -> torch.Tensor:
         """Conditional variant (reference Model.forward with condition_on_prompt, latent_module.py:828-876): prompt [B,Tp,dim_prompt],
-        prompt_lengths [B]; drop [B] bool = the classifier-free-guidance drop mask (True: null condition)."""
+        prompt_lengths [B]; drop [B] bool = the classifier-free-guidance drop mask (True: null condition).  Inside a chain:
+        `reuse_prompt` skips the prompt-only work a previous call left in the workspace (same shapes, same prompt and drop mask),
+        `time_table` (cond_time_table) supplies the time half of the conditioning rows."""
         B, T, z = x.shape
         Tp = prompt.shape[1]
         x, prompt = _f32(x, self.device), _f32(prompt, self.device)
@@ -120,9 +134,10 @@ class EpsEngine(_Engine):
         ws = self._workspace(int(self.lib.dn_eps_cond_workspace_bytes(self.handle, B, T, Tp)))
         wp, wn = self._aligned(ws)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dn_eps_forward_cond(self.handle, x.data_ptr(), t32.data_ptr(), l32.data_ptr(), prompt.data_ptr(), p32.data_ptr(),
-                                                    d32.data_ptr(), B, T, Tp, out.data_ptr(), wp, wn, _lib.current_stream()),
-                       "dn_eps_forward_cond")
+            _lib.check(self.lib.dn_eps_forward_cond_ex(self.handle, x.data_ptr(), t32.data_ptr(), l32.data_ptr(), prompt.data_ptr(), p32.data_ptr(),
+                                                       d32.data_ptr(), B, T, Tp, out.data_ptr(), wp, wn, int(bool(reuse_prompt)),
+                                                       _lib.ptr(time_table), int(table_t0), 0 if time_table is None else time_table.shape[0],
+                                                       _lib.current_stream()), "dn_eps_forward_cond")
         return out
 
     def _guided_inputs(self, lengths, prompt, prompt_lengths):
@@ -148,7 +163,7 @@ class EpsEngine(_Engine):
         return out
 
     def guided_ddim_chain(self, x: torch.Tensor, lengths, prompt, prompt_lengths, start_step: int, coef: torch.Tensor, cond_scale: float = 1.0,
-                          use_graph: bool = True) -> int:
+                          use_graph: bool = True, hoist: bool = True) -> int:
         """The prompted chain of the conditional variant, in place on x [B,T,z]: for t = start_step-1 .. 1 (t = 0 only when start_step
         == 1, like the reference's loop :1411-1445) the guided prediction (one 2B-row pass, or B rows at scale 1) and the DDIM eta = 0
         update.  One step -- timestep fill from a device counter, the pass, the guidance combination, the update, the decrement -- is
@@ -170,11 +185,18 @@ class EpsEngine(_Engine):
         both = torch.empty(n, T, z, dtype=torch.float32, device=self.device)
         eps = torch.empty_like(x) if guided else both
 
+        # prompt-only work (pooled-prompt half of the conditioning projection, resampler, every layer's prompt keys / values) once per
+        # chain: the first step computes it into the workspace, every later step reuses it; the time half of the conditioning rows of
+        # all the chain's steps comes from one table
+        table = self.cond_time_table(0, start_step) if hoist else None
+        first = [True]
+
         def one_step():
             if guided:
                 xin[:B].copy_(x)
                 xin[B:].copy_(x)
-            self.forward_cond(xin, tvec, l2, p2, pl2, drop2, out=both)
+            self.forward_cond(xin, tvec, l2, p2, pl2, drop2, out=both, reuse_prompt=hoist and not first[0], time_table=table, table_t0=0)
+            first[0] = False
             if guided:
                 _lib.check(self.lib.dn_cfg_combine(both.data_ptr(), float(cond_scale), x.numel(), eps.data_ptr(), _lib.current_stream()), "dn_cfg_combine")
             ops.ddim_step(x, eps, coef, tvec[:B], T, out=x)

@@ -102,13 +102,14 @@ class NarDecoderEngine(_Engine):
                        "dn_nar_predict_lengths")
         return out
 
-    def forward(self, tokens: torch.Tensor, ckv: torch.Tensor, src_lengths: torch.Tensor) -> torch.Tensor:
+    def forward(self, tokens: torch.Tensor, ckv: torch.Tensor, src_lengths: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """tokens int32 [B, T] -> logits fp32 [B, T, vocab]."""
         B, T = tokens.shape
         S = ckv.shape[2]
         assert tokens.dtype == torch.int32 and tokens.is_contiguous() and ckv.is_contiguous() and ckv.shape[1] == B
         sl = src_lengths if (src_lengths.dtype == torch.int32 and src_lengths.device == self.device) else src_lengths.to(self.device, torch.int32)
-        logits = torch.empty(B, T, self.vocab, dtype=torch.float32, device=self.device)
+        logits = torch.empty(B, T, self.vocab, dtype=torch.float32, device=self.device) if out is None else out
+        assert logits.shape == (B, T, self.vocab) and logits.dtype == torch.float32 and logits.is_contiguous()
         wp, wn = self._ws_for(B, T, S)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dn_nar_decoder_forward(self.handle, tokens.data_ptr(), ckv.data_ptr(), sl.contiguous().data_ptr(), B, T, S, logits.data_ptr(),
@@ -135,14 +136,93 @@ class _GivenEncoder:
         return out
 
 
+class _RefineGraph:
+    """ONE refinement iteration of the mask-predict loop -- the decoder pass (about 70 launches) and the CMLM update with the
+    iteration index read from a device counter, then the counter's increment -- captured into a hipGraph (torch.cuda.CUDAGraph over
+    this library's launches on the capture stream) over static buffers and replayed: an iteration is one graph launch instead of
+    70 host launches.  Keyed by (B, T, S, max_step); the encoder-attention keys / values and source lengths are copied into the
+    static buffers when the caller's tensors change (once per utterance batch, or after the generator re-ordered a shrunken batch)."""
+
+    def __init__(self, model, B, T, S, max_step, ckv_like, slen_like):
+        eng, dev = model.engine, model.device
+        self.tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
+        self.scores = torch.empty(B, T, dtype=torch.float32, device=dev)
+        self.predicted = torch.empty(B, T, dtype=torch.int32, device=dev)
+        self.logits = torch.empty(B, T, eng.vocab, dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ckv, self.slen = torch.empty_like(ckv_like), torch.empty_like(slen_like)
+        self._src = (None, None)
+        self.max_step, self.model, self.graph = max_step, model, None
+
+    def bind(self, ckv, slen):
+        key = (ckv.data_ptr(), slen.data_ptr(), ckv._version, slen._version)
+        if key != self._src:
+            self.ckv.copy_(ckv)
+            self.slen.copy_(slen)
+            self._src = key
+
+    def _iteration(self):
+        m, eng = self.model, self.model.engine
+        eng.forward(self.tokens, self.ckv, self.slen, out=self.logits)
+        B, T, V = self.logits.shape
+        _lib.check(eng.lib.dn_cmlm_step_dev(self.logits.data_ptr(), self.tokens.data_ptr(), self.scores.data_ptr(), self.predicted.data_ptr(), B, T, V,
+                                            self.step.data_ptr(), int(self.max_step), int(m.unk), int(m.pad), _lib.current_stream()), "dn_cmlm_step_dev")
+        self.step.add_(1)
+
+    def run(self, n: int = 1):
+        """n iterations from the state in the static buffers (tokens, scores, step)."""
+        with torch.cuda.device(self.model.device):
+            if self.graph is None:
+                self._iteration()  # eager first: workspaces and kernel attributes settle outside capture
+                n -= 1
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream(device=self.model.device)
+                side.wait_stream(cur)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        self._iteration()
+                cur.wait_stream(side)
+                self.graph = g
+            for _ in range(n):
+                self.graph.replay()
+
+
 class NARS2UTDecoderModel:
-    """forward_decoder / initialize_output_tokens / regenerate_length_beam of NARS2UTTransformerModel (:791-912) over the HIP decoder."""
+    """forward_decoder / initialize_output_tokens / regenerate_length_beam of NARS2UTTransformerModel (:791-912) over the HIP decoder.
+    `use_graph` (default on): an iteration of `forward_decoder` runs as ONE captured hipGraph launch (_RefineGraph) instead of ~70
+    host launches -- same kernels on the same inputs, bit-identical results; `refine(state, enc, n)` runs n iterations back to back
+    with no host work in between (a generator without the adaptive early stop, and the benchmark)."""
     allow_length_beam = True
 
-    def __init__(self, decoder_state_dict, dim=512, ffn=2048, layers=6, heads=8, vocab=1004, pad=1, unk=3, dtype="bf16", device="cuda:0"):
+    def __init__(self, decoder_state_dict, dim=512, ffn=2048, layers=6, heads=8, vocab=1004, pad=1, unk=3, dtype="bf16", device="cuda:0",
+                 use_graph: bool = True):
         self.engine = NarDecoderEngine(decoder_state_dict, dim, ffn, layers, heads, vocab, pad=pad, dtype=dtype, device=device)
         self.encoder = _GivenEncoder()
         self.pad, self.unk, self.device = pad, unk, self.engine.device
+        self.use_graph, self._graphs = use_graph, {}
+
+    def _graph_for(self, B, T, ckv, slen, max_step) -> "_RefineGraph":
+        key = (B, T, ckv.shape[2], int(max_step))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 8:  # a generator whose batch keeps shrinking: keep the cache bounded
+                self._graphs.pop(next(iter(self._graphs)))
+            g = self._graphs[key] = _RefineGraph(self, B, T, ckv.shape[2], max_step, ckv, slen)
+        g.bind(ckv, slen)
+        return g
+
+    def refine(self, decoder_out, encoder_out, n_iters: int):
+        """n_iters mask-predict iterations from `decoder_out` (its `step` / `max_step` as the generator sets them) with no host work
+        in between: the captured iteration replayed while the device step counter advances.  -> the DecoderOut after them."""
+        ckv, slen = self._prepared(encoder_out)
+        B, T = decoder_out.output_tokens.shape
+        g = self._graph_for(B, T, ckv, slen, decoder_out.max_step)
+        g.tokens.copy_(decoder_out.output_tokens)
+        g.scores.copy_(decoder_out.output_scores)
+        g.step.fill_(int(decoder_out.step))
+        g.run(n_iters)
+        return decoder_out._replace(output_tokens=g.tokens.long(), output_scores=g.scores.clone(), attn=None, step=decoder_out.step + n_iters)
 
     def eval(self):
         return self
@@ -189,6 +269,18 @@ class NARS2UTDecoderModel:
         positions, then re-masking of the lowest-scoring ones unless this is the last iteration)."""
         ckv, slen = self._prepared(encoder_out)
         step, max_step, history = decoder_out.step, decoder_out.max_step, decoder_out.history
+        if self.use_graph:
+            B, T = decoder_out.output_tokens.shape
+            g = self._graph_for(B, T, ckv, slen, max_step)
+            g.tokens.copy_(decoder_out.output_tokens)
+            g.scores.copy_(decoder_out.output_scores)
+            g.step.fill_(int(step))
+            g.run(1)
+            if history is not None:
+                history.append(g.predicted.long())
+                if (step + 1) < max_step:
+                    history.append(g.tokens.long())
+            return decoder_out._replace(output_tokens=g.tokens.long(), output_scores=g.scores.clone(), attn=None, history=history)
         tokens = decoder_out.output_tokens.to(self.device, torch.int32).contiguous()
         scores = decoder_out.output_scores.to(self.device, torch.float32).contiguous().clone()
         logits = self.engine.forward(tokens, ckv, slen)

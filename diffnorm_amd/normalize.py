@@ -74,25 +74,27 @@ def normalize(ddim_sample: Callable, utterances: Sequence[Utterance], start_step
     """Runs `ddim_sample(feat, input_mask=..., ref_units=..., start_step=...)` (LatentDiscreteModel.ddim_sample) over this
     rank's batches and gathers the TSV lines of all ranks in utterance order (every rank returns the full list)."""
     rank, world = sharding.rank_world(group)
-    # Sharded runs must give the results of the unsharded run whatever sizes the shards' last batches have.  The bf16 / f32
+    # A run must give the same results on any number of ranks (and whatever sizes the last batches have).  The 2-byte / f32
     # contractions' fast K order (taps of a causal conv innermost, one staged copy of the rows, on the two 256-row tiles) sums in a
-    # different order than the small-batch tiles: a batch and its shards can differ in the last bit of an fp32 sum when they route
-    # to different tiles.  With more than one rank the tap contractions are therefore routed by SHAPE, not by batch size
-    # (DN_TAPS_INNER=2: always the 256-row tiles and their order) -- full speed on the large batches a sharded run has, 256-row
-    # tiles on a short last batch -- unless the caller has chosen (DN_TAPS_INNER set; 0 = term-outer everywhere, the older
-    # invariant setting, about 6 % per step slower).  The bf16x3 mode is invariant by construction.
-    import os
+    # different order than the small-batch tiles, so by default a large batch and a small one can differ in the last bit of an fp32
+    # sum.  normalize() therefore ALWAYS routes the tap contractions by SHAPE, not by batch size (option "taps_inner" = 2: the
+    # 256-row tiles and their order at every batch size) -- the same routing on 1 rank and on N, full speed on the 100-utterance
+    # batches this driver forms, 256-row tiles on a short last batch -- for the duration of the call, through the library's
+    # option entry (dn_set_option; restored on the way out, no environment mutation), unless the caller has chosen a K order
+    # (option set, or DN_TAPS_INNER in the environment at start-up; 0 = term-outer everywhere is the other invariant setting,
+    # about 6 % per step slower).  The bf16x3 mode is invariant by construction.
+    from . import _lib
 
-    if world > 1 and "DN_TAPS_INNER" not in os.environ:
-        os.environ["DN_TAPS_INNER"] = "2"
+    chosen = _lib.get_option("taps_inner")
     batches = sharding.batch_indices(len(utterances), batch_size)
     mine = sharding.my_batches(len(batches), rank, world)
     local = []
-    for b in mine:
-        items = [utterances[i] for i in batches[b]]
-        feat, ref_units, lens = assemble_batch(items, device)
-        mask = torch.arange(feat.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1)
-        pred, _, _, _ = ddim_sample(feat, input_mask=mask, cond_scale=1.0, ref_units=ref_units, start_step=start_step)
-        local.append([tsv_line(it, p.tolist()) for it, p in zip(items, pred)])
+    with _lib.option("taps_inner", 2 if chosen is None else chosen):
+        for b in mine:
+            items = [utterances[i] for i in batches[b]]
+            feat, ref_units, lens = assemble_batch(items, device)
+            mask = torch.arange(feat.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1)
+            pred, _, _, _ = ddim_sample(feat, input_mask=mask, cond_scale=1.0, ref_units=ref_units, start_step=start_step)
+            local.append([tsv_line(it, p.tolist()) for it, p in zip(items, pred)])
     per_batch = sharding.gather_in_order(local, mine, len(batches), group)
     return [line for lines in per_batch for line in lines]

@@ -523,15 +523,21 @@ class DiffusionTrainer(VaeTrainer):
         times = draws.get("times")
         if times is None:
             times = torch.randint(1, ldm.timesteps, (B,), device=eng.device)
+        # the three noise tensors come from the library's own Philox4x32-10 kernel (dn_randn), keyed by (seed + num_updates, micro-batch,
+        # which tensor): no torch RNG kernel in the step, an update is reproducible from the trainer's seed alone
+        from . import ops
+
+        self._draws = getattr(self, "_draws", 0) + 1
+        key = lambda i: ((self.seed + self.num_updates) << 20) + ((self._draws & 0xffff) << 4) + i
         post = draws.get("post_noise")
         if post is None and not self.reference_rng:
-            post = torch.randn(B, feat.shape[1], ldm.speech_decoder.engine().z, device=eng.device)
+            post = ops.randn((B, feat.shape[1], ldm.speech_decoder.engine().z), seed=key(0), device=eng.device)
         with torch.no_grad():
             z = ldm.speech_decoder.encode_feature(feat, noise=post).transpose(1, 2).contiguous()
         jn = draws.get("jitter_noise")
         tn = draws.get("true_noise")
-        jn = torch.randn(z.shape, device=eng.device) if jn is None else jn
-        tn = torch.randn(z.shape, device=eng.device) if tn is None else tn
+        jn = ops.randn(tuple(z.shape), seed=key(1), device=eng.device) if jn is None else jn
+        tn = ops.randn(tuple(z.shape), seed=key(2), device=eng.device) if tn is None else tn
         # host scalars of the loss normalisation without a device read-back: the sample dict carries ntokens (= the sum of the
         # lengths) and, from this build's collaters, n_units; an unknown batch is counted once and remembered
         if "n_units" not in sample:

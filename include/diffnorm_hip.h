@@ -480,6 +480,20 @@ size_t dn_eps_cond_workspace_bytes(const DnEps* m, int32_t B, int32_t T, int32_t
 int dn_eps_forward_cond(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
                         const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same pass inside a CHAIN of steps (the prompted, guided sampling loop): everything that depends on the prompt only -- the
+ * pooled-prompt half of the conditioning projection, the PerceiverResampler and every layer's cross-attention keys / values -- is
+ * kept in the workspace, and with DN_COND_REUSE_PROMPT a later call on the SAME workspace and shapes skips it (the caller
+ * guarantees nothing else wrote the workspace in between and that prompt / prompt_lengths / drop are unchanged).  time_table
+ * (optional, fp32 [table_n, n_cond] from dn_eps_cond_time_table, first row = timestep table_t0): the time half of the conditioning
+ * rows of every step of the chain, so the 2 C x n_cond projection is not streamed inside the loop.  flags = 0, time_table = NULL
+ * is dn_eps_forward_cond.                                                                                                     */
+#define DN_COND_REUSE_PROMPT 1
+int dn_eps_forward_cond_ex(DnEps* m, const float* x, const int32_t* t, const int32_t* lengths, const float* prompt,
+                           const int32_t* prompt_lengths, const int32_t* drop, int32_t B, int32_t T, int32_t Tp, float* eps_out,
+                           void* workspace, size_t workspace_bytes, int32_t flags, const float* time_table, int32_t table_t0,
+                           int32_t table_n, void* stream);
+size_t dn_eps_cond_time_table_workspace_bytes(const DnEps* m, int32_t n_t);
+int dn_eps_cond_time_table(DnEps* m, int32_t t0, int32_t n_t, float* table, void* workspace, size_t workspace_bytes, void* stream);
 
 int dn_vae_create(const DnVaeConfig* cfg, const void* const* weights, int32_t n_weights, DnVae** out);
 void dn_vae_destroy(DnVae* m);
@@ -583,6 +597,11 @@ int dn_vae_train_backward(DnVaeTrain* m, const DnVaeTrainBatch* batch, int32_t f
  * scores ordered by position).  logits fp32 [B, T, V]; tokens int32 [B, T] and scores fp32 [B, T] updated in place.  T <= 2048.  */
 int dn_cmlm_step(const float* logits, int32_t* tokens, float* scores, int32_t* predicted, int32_t B, int32_t T, int32_t V, int32_t step,
                  int32_t max_step, int32_t unk, int32_t pad, void* stream);
+/* The same update with the iteration index read from the DEVICE (int32 *step_dev): one refinement iteration of the loop of
+ * fairseq/iterative_refinement_generator.py:200-230 -- dn_nar_decoder_forward + this -- can then be captured into a hipGraph once and
+ * replayed while a device counter advances (diffnorm_amd/nar_decoder.py).                                                         */
+int dn_cmlm_step_dev(const float* logits, int32_t* tokens, float* scores, int32_t* predicted, int32_t B, int32_t T, int32_t V,
+                     const int32_t* step_dev, int32_t max_step, int32_t unk, int32_t pad, void* stream);
 
 /* ------------------------------------------------------------------ diffusion training step */
 /* LatentDiscreteModel.forward (latent_module.py:1514-1613; criterion fairseq/criterions/ddpm_discrete_loss.py:37-75) for the
@@ -636,6 +655,18 @@ int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEpsTrainBatch*
 
 const char* dn_last_error(void);
 int dn_version(void);
+
+/* Run-time options (process-wide; no reference counterpart: the reference has no such switches).  Each option starts from the
+ * environment variable named beside it, read once when the library first looks, and is changed afterwards only through this entry
+ * (the library never re-reads the environment per launch and callers never have to mutate it).  DN_OPTION_DEFAULT restores the
+ * start value.  Names: "taps_inner" (DN_TAPS_INNER: K order of a causal conv's taps -- 0 term-outer everywhere, 1 tap-inner on
+ * the 256-row tiles [default], 2 tap contractions routed to those tiles by SHAPE whatever the batch size: a batch and its shards
+ * then agree bit for bit), "fuse_norm" (DN_FUSE_NORM), "no_split_norm" (DN_NO_SPLIT_NORM), "kblock" (DN_KBLOCK: 0 never / 1 always
+ * K-blocked operands), "wgrad_stream", "wgrad_tn", "wgrad_groups" (DN_WGRAD_*: A/B switches of the weight-gradient path).
+ * dn_get_option: *is_set = 0 when the option is neither set nor in the environment (the library's built-in choice applies). */
+#define DN_OPTION_DEFAULT (-2147483647 - 1)
+int dn_set_option(const char* name, int32_t value);
+int dn_get_option(const char* name, int32_t* value, int32_t* is_set);
 
 /* Classifier-free guidance (Model.forward_with_cond_scale, latent_module.py:813-826) over ONE pass of twice the batch: `both` fp32
  * [2, n] = the conditioned predictions followed by the null-conditioned ones -> out[i] = null + (cond - null) * scale.           */

@@ -30,7 +30,12 @@ def cond_fn(x, t, **kw):  # grad log p(y | x) of a toy classifier
     return 0.3 * torch.cos(x) - 0.001 * tt
 
 
+def denoised_fn(x):  # "a function which applies to the x_start prediction before it is used to sample" (:263-265); before the clip
+    return 0.8 * torch.tanh(1.5 * x)
+
+
 def main():
+    torch.manual_seed(20261005)  # the recorded draws come off torch's global generator: a re-run regenerates the file byte for byte
     _, gd = ref_loader.load_reference()
     out = {}
     N, C, L = 3, 4, 10
@@ -54,6 +59,22 @@ def main():
             out[f"{tag}_dc_noise"], out[f"{tag}_dc_sample"], out[f"{tag}_dc_x0"] = rec.draws[0], o["sample"], o["pred_xstart"]
         pm = diff.p_mean_variance(model, x, t, clip_denoised=True)
         out[f"{name}_pmv_mean"], out[f"{name}_pmv_logvar"] = pm["mean"], pm["log_variance"]
+        # denoised_fn (:254-332 process_xstart; threaded through p_sample / ddim_sample / ddim_reverse_sample)
+        for clip in (False, True):
+            tag = f"{name}_dfn_clip{int(clip)}"
+            pm = diff.p_mean_variance(model, x, t, clip_denoised=clip, denoised_fn=denoised_fn)
+            out[f"{tag}_pmv_mean"], out[f"{tag}_pmv_x0"] = pm["mean"], pm["pred_xstart"]
+            with record_draws() as rec:
+                o = diff.p_sample(model, x, t, clip_denoised=clip, denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs={})
+            out[f"{tag}_p_noise"], out[f"{tag}_p_sample"], out[f"{tag}_p_x0"] = rec.draws[0], o["sample"], o["pred_xstart"]
+            with record_draws() as rec:
+                o = diff.ddim_sample(model, x, t, clip_denoised=clip, denoised_fn=denoised_fn, eta=0.5)
+            out[f"{tag}_d_noise"], out[f"{tag}_d_sample"], out[f"{tag}_d_x0"] = rec.draws[0], o["sample"], o["pred_xstart"]
+            o = diff.ddim_reverse_sample(model, x, t, clip_denoised=clip, denoised_fn=denoised_fn, eta=0.0)
+            out[f"{tag}_r_sample"], out[f"{tag}_r_x0"] = o["sample"], o["pred_xstart"]
+        with record_draws() as rec:
+            y = diff.ddim_sample_loop(model, (N, C, L), noise=seeded((N, C, L), 504), clip_denoised=True, denoised_fn=denoised_fn, eta=0.3, device="cpu")
+        out[f"{name}_dfn_dloop_noises"], out[f"{name}_dfn_dloop_out"] = torch.stack(rec.draws), y
         with record_draws() as rec:  # (training_losses unpacks `model_output, misc = model(...)`)
             tl = diff.training_losses(lambda *a, **k: (model(*a, **k), None), x, t)
         out[f"{name}_tl_noise"] = rec.draws[0]

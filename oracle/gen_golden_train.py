@@ -17,7 +17,15 @@ identity.  Random tensors the reference draws (posterior noise, t, jitter, targe
                   inner 2048; dim 512 / depth 12 / inner 1365 padded to 1408 / the 57 k-wide conditioning projection) at B = 2, T = 64:
                   checksums + strided samples only.
 
-Usage:  python oracle/gen_golden_train.py [--full]   ->  tests/golden/{vae_train,eps_train}[_full].npz
+  vae_train_batch.npz / eps_train_batch.npz (--full-batch): the RECIPE-sized models at the batch shapes bench.py's training
+                  legs actually time (scripts/vae/train.sh:5-9 --max-tokens 15000 -> B = 24 x T = 512; scripts/diffusion/train.sh
+                  --max-tokens 12000 -> B = 16 x T = 512; ragged lengths U[64, 512], longest first, zero-padded features): 8-12 k
+                  frames into every weight gradient, K-sliced partial sums, several slices -- checksums + strided samples only.
+                  The reference's random draws are not recorded here (a [24, 512, 128] noise tensor is 6 MB) but INJECTED: while
+                  the reference runs, torch.randn / randn_like / randint return portable seeded tensors (gen_golden_configs.seeded
+                  with the seeds stored in the fixture), which the test regenerates.
+
+Usage:  python oracle/gen_golden_train.py [--full | --full-batch]   ->  tests/golden/{vae_train,eps_train}[_full|_batch].npz
 """
 import os
 import sys
@@ -220,9 +228,104 @@ def gen_eps_train_full(lm):
     save("eps_train_full", **out)
 
 
+class inject_draws:
+    """While the reference runs, every torch.randn / randn_like / randint call returns a portable seeded tensor (seed base + call
+    index) instead of a draw off the global generator; `calls` lists (kind, shape, seed) in call order for the test to regenerate."""
+
+    def __init__(self, base):
+        self.base, self.calls = base, []
+
+    def __enter__(self):
+        self._orig = {n: getattr(torch, n) for n in ("randn", "randn_like", "randint")}
+
+        def randn(*shape, **k):
+            shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+            seed = self.base + len(self.calls)
+            self.calls.append(("randn", shape, seed))
+            return self._orig["randn"](*shape, generator=torch.Generator().manual_seed(seed))  # == gen_golden_configs.seeded(shape, seed)
+
+        def randn_like(x, **k):
+            return randn(*x.shape)
+
+        def randint(low, high, size, **k):
+            seed = self.base + len(self.calls)
+            self.calls.append(("randint", tuple(size), seed))
+            return self._orig["randint"](low, high, tuple(size), generator=torch.Generator().manual_seed(seed))
+
+        torch.randn, torch.randn_like, torch.randint = randn, randn_like, randint
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(torch, n, f)
+
+
+def bench_batch(B, T, dim, seed):
+    """One batch of bench.py's make_train_batches shape class: lengths U[64, 512] sorted longest first (the first one T), features
+    N(0, 1) zero-padded, units U{4..1003} with 0 on the pads."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(64, T + 1, (B,), generator=g).sort(descending=True).values
+    lens[0] = T
+    mask = O.lengths_to_mask(lens, T)
+    feat = seeded((B, T, dim), seed + 1) * mask.unsqueeze(-1)
+    units = torch.randint(4, 1004, (B, T), generator=g).masked_fill(~mask, 0)
+    return feat, lens, mask, units
+
+
+def gen_vae_train_batch(lm):
+    """speech_vae_decoder_loss on the recipe-sized VAE at B = 24, T = 512 (bench.py --max-tokens 15000)."""
+    from gen_golden_configs import FULL_VAE
+
+    vae = ref_vae(lm, FULL_VAE, O.make_vae_state_dict(FULL_VAE, "full"))
+    feat, lens, mask, units = bench_batch(24, 512, FULL_VAE.dim, 4300)
+    out = dict(lens=lens, units=units, batch_seed=np.array(4300))
+    with inject_draws(9100) as inj:
+        loss, parts, logits = vae_criterion_loss(lm, vae, feat, units, mask, lens)
+    assert [c[0] for c in inj.calls] == ["randn"] and inj.calls[0][1] == (24, FULL_VAE.z, 512), inj.calls
+    out["post_noise_seed"], out["post_noise_shape"] = np.array(inj.calls[0][2]), np.array(inj.calls[0][1])  # drawn [B, z, T] (distributions.py:38)
+    loss.backward()
+    out["loss"] = loss.detach()
+    out.update({k: v.detach() for k, v in parts.items()})
+    out["logits_head"] = logits.detach()[:, :4, :64]
+    grad_record("g/", [(n, p.grad) for n, p in vae.named_parameters()], out, small=2048, samples=256)
+    save("vae_train_batch", **out)
+
+
+def gen_eps_train_batch(lm):
+    """ddpm_discrete_loss on the recipe-sized eps-predictor through the frozen VAE at B = 16, T = 512 (bench.py --max-tokens 12000)."""
+    from gen_golden_configs import FULL_EPS, FULL_VAE
+
+    esd, vsd = O.make_eps_state_dict(FULL_EPS, "full"), O.make_vae_state_dict(FULL_VAE, "full")
+    vae = ref_vae(lm, FULL_VAE, vsd)
+    for p in vae.parameters():
+        p.requires_grad = False
+    ldm = lm.LatentDiscreteModel(types.SimpleNamespace(encoder=vae), FULL_EPS.dim, FULL_VAE.z, timesteps=200, multitask=True)
+    ldm.model.load_state_dict(dict(esd, **{"pos_embed._float_tensor": torch.zeros(1)}), strict=True)
+    ldm.eval()
+    feat, lens, mask, units = bench_batch(16, 512, FULL_VAE.dim, 4400)
+    out = dict(lens=lens, units=units, batch_seed=np.array(4400))
+    with inject_draws(9200) as inj:
+        ld = ldm(feat, units, tgt_mask=mask)
+    assert [c[0] for c in inj.calls] == ["randint", "randn", "randn", "randn"], inj.calls  # t, posterior noise [B,z,T], jitter, true noise
+    out["draw_seeds"] = np.array([c[2] for c in inj.calls])
+    out["draw_shapes"] = np.array([list(c[1]) + [0] * (3 - len(c[1])) for c in inj.calls])
+    out["times"] = torch.randint(1, 200, (16,), generator=torch.Generator().manual_seed(int(inj.calls[0][2])))  # (the draw itself: 16 integers)
+    out.update({"loss_" + k: v.detach() for k, v in ld.items()})
+    ld["total_loss"].backward()
+    grad_record("g/", [(n, p.grad) for n, p in ldm.model.named_parameters() if p.grad is not None], out, small=2048, samples=256)
+    out["no_grad_names"] = np.array([n for n, p in ldm.model.named_parameters() if p.grad is None])
+    save("eps_train_batch", **out)
+
+
 def main():
     torch.set_grad_enabled(True)
     lm, _ = ref_loader.load_reference()
+    if "--full-batch" in sys.argv:  # recipe-sized models at the benchmark's batch shapes: ~10 minutes and tens of GB on the CPU
+        if "eps" not in sys.argv:
+            gen_vae_train_batch(lm)
+        if "vae" not in sys.argv:
+            gen_eps_train_batch(lm)
+        return
     if "--full" in sys.argv:  # recipe-sized models: a few minutes of CPU
         gen_vae_train_full(lm)
         gen_eps_train_full(lm)

@@ -31,6 +31,23 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def hip_option():
+    """set(name, value): switches a run-time option of the library through its C ABI (dn_set_option; value None = its start
+    value) -- the library reads no environment variable per launch -- and puts every touched option back afterwards."""
+    from diffnorm_amd import _lib
+
+    before = {}
+
+    def set_(name, value):
+        before.setdefault(name, _lib.get_option(name))
+        _lib.set_option(name, value)
+
+    yield set_
+    for name, value in before.items():
+        _lib.set_option(name, value)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

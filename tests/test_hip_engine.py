@@ -61,8 +61,8 @@ def test_eps_tiny_vs_reference_golden(eng, golden, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("f16", 1e-2), ("bf16", 1e-2)])
-def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
-    """DN_FUSE_NORM=1 routes the residual-closing contractions through the whole-row tile that also emits the next
+def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, hip_option):
+    """option fuse_norm = 1 (DN_FUSE_NORM=1 at start-up) routes the residual-closing contractions through the whole-row tile that also emits the next
     block's RMSNorm (off by default: slower at dim 512): same golden, and the same numbers as the default path."""
     engine, _ = eng
     g = golden("eps_tiny")
@@ -70,9 +70,9 @@ def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
     e = engine.EpsEngine(sd, TINY_EPS, dtype=dtype, device=DEV)
     x, t, lens = T_(g["x"]), T_(g["t"]), T_(g["lens"])
     base = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
-    monkeypatch.setenv("DN_FUSE_NORM", "1")
+    hip_option("fuse_norm", 1)
     got = e.forward(x.to(DEV), t, lens, shared_t=False).cpu()
-    monkeypatch.delenv("DN_FUSE_NORM")
+    hip_option("fuse_norm", None)
     mask = O.lengths_to_mask(lens, x.shape[1])
     ref = T_(g["eps"])
     if dtype == "f16":
@@ -93,8 +93,8 @@ def test_eps_tiny_with_fused_norm_option(eng, golden, dtype, tol, monkeypatch):
         assert ((got - base)[mask] ** 2).mean().item() < 1e-3
 
 
-def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
-    """DN_KBLOCK=1 lays the WaveNet hidden states and the FFN conv's operands out K-blocked at every size (by default only
+def test_kblocked_buffers_are_bit_identical(eng, golden, hip_option):
+    """option kblock = 1 (DN_KBLOCK=1 at start-up) lays the WaveNet hidden states and the FFN conv's operands out K-blocked at every size (by default only
     where the consuming contraction lands on a tile that gains from whole-cache-line staging pieces, i.e. large batches)
     and runs those contractions on the tile that takes them: same K order, so the same bits as row-major buffers -- for
     the eps-predictor (tiny and BASELINE config 2 shapes) and for both VAE ends."""
@@ -102,9 +102,9 @@ def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
     outs = {}
     # term-outer K order on every tile: forcing the layout also forces the 256x256 tile, whose default order for a causal conv
     # (taps innermost) differs in the last bits from the small tiles these test sizes otherwise route to
-    monkeypatch.setenv("DN_TAPS_INNER", "0")
+    hip_option("taps_inner", 0)
     for mode in ("0", "1"):
-        monkeypatch.setenv("DN_KBLOCK", mode)
+        hip_option("kblock", int(mode))
         g = golden("eps_tiny")
         e = engine.EpsEngine(O.make_eps_state_dict(TINY_EPS, "tiny"), TINY_EPS, dtype="bf16", device=DEV)
         a = e.forward(T_(g["x"]).to(DEV), T_(g["t"]), T_(g["lens"]), shared_t=False).cpu()
@@ -119,7 +119,7 @@ def test_kblocked_buffers_are_bit_identical(eng, golden, monkeypatch):
         params = ve.encode_params(feat.to(DEV))
         recon, logits, _ = ve.decode(ve.sample_posterior(params, seeded((3, 48, CHAIN_VAE.z), 5)), lens)
         outs[mode] = (a, b, params.cpu(), recon.cpu(), logits.cpu())
-    monkeypatch.delenv("DN_KBLOCK")
+    hip_option("kblock", None)
     for x, y in zip(outs["0"], outs["1"]):
         assert torch.equal(x, y)
     g2 = golden("eps_full_cfg2")
@@ -214,11 +214,9 @@ def test_vae_and_chain_small_vs_reference_golden(eng, golden, dtype, tol):
             assert ee.ddim_loop(xc, lens.to(DEV).int(), start - 7, coef, keep_table=True) == start - 8
             assert torch.equal(xc, xs)
             xe = x.clone()  # and with the split RMSNorm off (standalone norm kernel): same chain within the budget
-            os.environ["DN_NO_SPLIT_NORM"] = "1"
-            try:
+            from diffnorm_amd import _lib
+            with _lib.option("no_split_norm", 1):
                 ee.ddim_loop(xe, lens.to(DEV).int(), start, coef, use_graph=False)
-            finally:
-                del os.environ["DN_NO_SPLIT_NORM"]
             assert maxerr(xe, xs) < tol * 5
 
 

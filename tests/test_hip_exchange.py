@@ -101,3 +101,44 @@ def test_level1_under_torch_ddp(tmp_path):
     assert rel(ranks[0]["grad0"], one["grad0"]) < 1e-5, rel(ranks[0]["grad0"], one["grad0"])
     assert rel(ranks[0]["master"], one["master"]) < 1e-5, rel(ranks[0]["master"], one["master"])
     assert abs(float(ranks[1]["loss2"]) - one["loss2"]) <= 1e-4 * abs(one["loss2"])  # rank 1's batch is the last micro-batch of the single process
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_normalize_is_the_same_on_one_rank_and_on_two(dtype, tmp_path):
+    """SURVEY 8e, sampling row: normalize() shards whole batches over the ranks with no data-path collective, so a run on two
+    ranks must produce the run on one -- identical TSV lines and BIT-identical reconstructions, batch by batch.  Round 3 switched
+    the K order of the tap contractions only when world > 1 (and through os.environ), which made the two differ in bits; now the
+    driver routes them by shape on any world size, through dn_set_option, and restores the option on the way out.  RECIPE-sized
+    engines, two batches that land on the 256-row tiles and a short last one; two FRESH ranks over gloo share cuda:0."""
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    worker = os.path.join(HERE, "normalize_worker.py")
+    r = subprocess.run([sys.executable, worker, str(one), dtype], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker, str(two), dtype]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    errs = "".join(open(os.path.join(two, f)).read() for f in sorted(os.listdir(two)) if f.startswith("error_rank"))
+    assert r.returncode == 0, errs or (r.stdout[-3000:] + r.stderr[-3000:])
+    lines1 = open(one / "lines_rank0.txt").read()
+    assert lines1.count("\n") == 35
+    for k in range(2):  # every rank returns the full list
+        assert open(two / f"lines_rank{k}.txt").read() == lines1
+    rec1 = np.load(one / "recon_rank0.npz")
+    rec2 = {}
+    for k in range(2):
+        with np.load(two / f"recon_rank{k}.npz") as z:
+            rec2.update({n: z[n] for n in z.files})
+    assert sorted(rec2) == sorted(rec1.files) and len(rec2) == 3
+    for n in rec1.files:
+        assert np.array_equal(rec1[n], rec2[n]), f"batch {n}: the two-rank run differs from the one-rank run in bits"
+    from diffnorm_amd import _lib
+
+    assert _lib.get_option("taps_inner") is None  # (this process never ran normalize; the workers restore it themselves)

@@ -45,7 +45,7 @@ def test_config3_chain_graph_and_split_are_bit_identical(models):
     assert not torch.equal(outs[0], x0)
 
 
-def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeypatch):
+def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, hip_option):
     """[B=16,T=1024] features: VAE encode -> noise at start_step -> DDIM -> VAE decode -> units.  (a) the 16-utterance
     batch and two 8-utterance shards (the multi-GPU sharding): with every contraction in term-outer K order
     (DN_TAPS_INNER=0) units and recon are identical bit for bit whatever tile variants the shard sizes route to; in the
@@ -79,22 +79,22 @@ def test_config5_end_to_end_sharding_invariance_and_oracle_slice(models, monkeyp
         recon, logits, units = vae.decode(x, l)
         return recon.cpu(), logits.cpu(), units.cpu()
 
-    monkeypatch.setenv("DN_TAPS_INNER", "0")
+    hip_option("taps_inner", 0)
     full = run(slice(0, 16))
     a, b = run(slice(0, 8)), run(slice(8, 16))
     assert torch.equal(torch.cat([a[2], b[2]]), full[2])
     assert torch.equal(torch.cat([a[0], b[0]]), full[0])
-    monkeypatch.delenv("DN_TAPS_INNER")
+    hip_option("taps_inner", None)
     strict = full
     full = run(slice(0, 16))
     # DN_TAPS_INNER=2 (the sharded driver's default): tap contractions routed by shape -> the fast order AND bit-for-bit invariance,
     # down to single-utterance shards (the big batch's narrow convs leave the 128-byte-K-tile kernels too, so it need not equal `full`)
-    monkeypatch.setenv("DN_TAPS_INNER", "2")
+    hip_option("taps_inner", 2)
     routed = run(slice(0, 16))
     parts = [run(slice(0, 8)), run(slice(8, 15)), run(slice(15, 16))]
     assert torch.equal(torch.cat([q[2] for q in parts]), routed[2])
     assert torch.equal(torch.cat([q[0] for q in parts]), routed[0])
-    monkeypatch.delenv("DN_TAPS_INNER")
+    hip_option("taps_inner", None)
     a, b = run(slice(0, 8)), run(slice(8, 16))
     valid = torch.arange(T)[None, :] < lens[:, None]
     for got in (torch.cat([a[2], b[2]]), strict[2]):  # shards vs batch, and the batch in the other K order

@@ -234,6 +234,28 @@ def test_gaussian_diffusion_tail_matches_reference_golden(golden):
         pm = d.p_mean_variance(model, x, t, clip_denoised=True)
         rel(pm["mean"], g[f"{name}_pmv_mean"], 1e-5)
         rel(pm["log_variance"], g[f"{name}_pmv_logvar"], 1e-5)
+        # denoised_fn (applies to the x_0 prediction before the clip, :263-265): the un-fused fallback of p_mean_variance / p_sample
+        # (with cond_fn) / ddim_sample (eta 0.5) / ddim_reverse_sample and the loop that threads it through
+        dfn = lambda z: 0.8 * torch.tanh(1.5 * z)
+        for clip in (False, True):
+            tag = f"{name}_dfn_clip{int(clip)}"
+            pm = d.p_mean_variance(model, x, t, clip_denoised=clip, denoised_fn=dfn)
+            rel(pm["mean"], g[f"{tag}_pmv_mean"], 1e-5)
+            rel(pm["pred_xstart"], g[f"{tag}_pmv_x0"], 1e-5)
+            o = d.p_sample(model, x, t, clip_denoised=clip, denoised_fn=dfn, cond_fn=cond_fn, model_kwargs={}, noise=T_(g[f"{tag}_p_noise"]).to(DEV))
+            rel(o["sample"], g[f"{tag}_p_sample"], 1e-5)
+            rel(o["pred_xstart"], g[f"{tag}_p_x0"], 1e-5)
+            o = d.ddim_sample(model, x, t, clip_denoised=clip, denoised_fn=dfn, eta=0.5, noise=T_(g[f"{tag}_d_noise"]).to(DEV))
+            rel(o["sample"], g[f"{tag}_d_sample"], 2e-5)
+            rel(o["pred_xstart"], g[f"{tag}_d_x0"], 2e-5)
+            o = d.ddim_reverse_sample(model, x, t, clip_denoised=clip, denoised_fn=dfn, eta=0.0)
+            rel(o["sample"], g[f"{tag}_r_sample"], 2e-5)
+            rel(o["pred_xstart"], g[f"{tag}_r_x0"], 2e-5)
+        dn = T_(g[f"{name}_dfn_dloop_noises"]).to(DEV)
+        img = dn[0]
+        for k, i in enumerate(range(99, -1, -1)):
+            img = d.ddim_sample(model, img, torch.tensor([i] * N, device=DEV), clip_denoised=True, denoised_fn=dfn, eta=0.3, noise=dn[k + 1])["sample"]
+        rel(img, g[f"{name}_dfn_dloop_out"], 1e-4)
         tl = d.training_losses(lambda *a, **k: (model(*a, **k), None), x, t, noise=T_(g[f"{name}_tl_noise"]).to(DEV))
         for k in ("loss", "mse", "vb"):
             if f"{name}_tl_{k}" in g:

@@ -362,7 +362,7 @@ def test_kblocked_operands_on_the_352_tile(ops, cin, cout, k, dil, B, T):
     assert maxerr(refs[True].cpu(), ref.cpu()) < 1e-5 * max(1.0, ref.abs().max().item())
     dflt = torch.empty((B * T, N), device=DEV)  # no order forced: taps innermost when there is more than one tap
     ops_.conv_gemm([(xb, Wb[j], (k - 1 - j) * dil) for j in range(k)], dflt, T, N, bias=bias, tile=4, a_kblocked=True, w_kblocked=True)
-    inner_default = os.environ.get("DN_TAPS_INNER", os.environ.get("DN_FAT_TAPS_INNER", "1")) != "0"  # the suite also runs with it off
+    inner_default = (_lib.get_option("taps_inner") if _lib.get_option("taps_inner") is not None else 1) != 0  # the suite also runs with it off
     assert torch.equal(dflt, refs[k > 1 and inner_default])
     for inner in (True, False):  # the 256x256 tile takes them too, in either K order: its tap-inner order is the 256x352 tile's
         for kb in (True, False):
