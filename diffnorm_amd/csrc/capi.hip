@@ -33,6 +33,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"wgrad_stream", "DN_WGRAD_STREAM", nullptr},          // 0: weight gradients on the caller's stream
     {"wgrad_tn", "DN_WGRAD_TN", nullptr},                  // 0: weight gradients from transposed operand copies
     {"wgrad_groups", "DN_WGRAD_GROUPS", nullptr},          // 0: one weight-gradient launch per WaveNet block
+    {"qkv_192", "DN_QKV_192", nullptr},                    // 1: the q/kv projection (N = 1536 = 8 x 192) on the 256 x 192 tile (A/B timing)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;

@@ -223,6 +223,9 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
     DnGemmParams q = gemm_base(dtype, M, 3 * hd, Dp, T);
     qkv_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
   }
+  // option qkv_192: the projection's 3 x 512 columns are 8 x 192 but 6 x 256 -- at [32,512] 512 tiles of 256 x 192 are two full rounds
+  // of the chip, 384 tiles of 256 x 256 one and a half
+  const bool qkv_192 = option_or(OPT_QKV_192, 0) != 0 && dn::dn_is16(dtype) && (3 * hd) % 192 == 0 && M >= 2048;
   for (int l = 0; l < w.depth; ++l) {
     {  // to_q ; to_kv in one contraction (:930-931,945)
       DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
@@ -232,6 +235,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
         p.terms[0].layout = DN_LAYOUT_A_KBLOCKED | DN_LAYOUT_W_KBLOCKED;
       }
       p.out = tb.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
+      if (qkv_192) p.pad_ |= 8 << 16;
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }

@@ -2281,6 +2281,11 @@ static inline int choose_tile(const DnGemmParams& p) {
   const int force = forced_tile(p);
   bool has_ldw = false;
   for (int i = 0; i < p.n_terms; ++i) has_ldw = has_ldw || p.terms[i].ldw != 0;
+  // A handful of rows against a huge fp32 weight (the conditioning projections: B rows x [2048 -> 57 k], 470 MB of weights): the
+  // launch is a weight stream, and what decides is how the rows of the weight are fetched -- the 128-byte K-tiles of the 128 x 128
+  // tile take whole cache lines per row (64-byte K-tiles: half lines from rows 8 KiB apart), two workgroups per CU keep twice
+  // the loads in flight.  Measured at B = 16 (tools/cond_gemm_bench.py): 282 us on that tile against 503-569 us on the others.
+  if (p.dtype == DN_F32 && p.M <= 128 && force == 0 && (long)p.N * p.K * p.groups >= (8L << 20)) return 1;
   if (has_ldw && p.dtype != DN_BF16X3) {  // a weight row stride other than K: the 128x128 / 256x128 / 256x256 tiles (row-major operands)
     const int npw = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
     const long tb = (long)((p.M + 255) / 256) * ((npw + 255) / 256) * p.groups, ts = (long)((p.M + 127) / 128) * ((npw + BN - 1) / BN) * p.groups;
@@ -2318,7 +2323,8 @@ static inline int choose_tile(const DnGemmParams& p) {
   if (force == 0 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && taps_route_by_shape() && terms_are_taps(p)) return 3;
   bool kblocked = false;
   for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
-  if (kblocked) return bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them
+  if (kblocked) return bf && force == 8 && p.epilogue == DN_EPI_BIAS ? 8 : bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them (8: its 192-column form)
+  if (bf && force == 8 && p.epilogue == DN_EPI_BIAS) return 8;
   if (p.dtype == DN_BF16 && (force == 6 || force == 7)) return force;
   if (force >= 1 && force <= 3) return force;
 
@@ -2399,6 +2405,9 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   }
   if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && IsHalf<E>::value) {
     if (tile == 4) return launch_fat<E, EPI, 11>(p, s);
+  }
+  if constexpr (EPI == DN_EPI_BIAS && IsHalf<E>::value) {
+    if (tile == 8) return launch_big<E, EPI, 192>(p, s);  // 256 x 192: widths that are whole multiples of 192 but ragged on 256 (forced-only)
   }
   if constexpr (std::is_same<E, BF16>::value) {  // (the forced-only hand-scheduled 256 x 256 forms: kept for bf16)
     if (tile == 6) return launch_fat<E, EPI, 8>(p, s);
