@@ -99,6 +99,10 @@ class NarConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "ffn", "layers", "heads", "vocab", "max_pos", "pad", "dtype")]
 
 
+class NarEncConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_dim", "conv_channels", "kernel", "dim", "ffn", "layers", "heads", "max_pos", "pad", "dtype")]
+
+
 class VaeTrainBatch(C.Structure):
     _fields_ = [("feat", C.c_void_p), ("units", C.c_void_p), ("lengths", C.c_void_p), ("noise", C.c_void_p), ("B", C.c_int32),
                 ("T", C.c_int32), ("ntokens", C.c_int32), ("w_lsce", C.c_float), ("w_mse", C.c_float), ("w_kl", C.c_float),
@@ -208,6 +212,11 @@ SYMBOLS = {
     "dn_nar_cross_kv": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_nar_predict_lengths": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_nar_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_nar_encoder_create": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "dn_nar_encoder_destroy": (None, [_vp]),
+    "dn_nar_encoder_out_frames": (_i32, [_i32]),
+    "dn_nar_encoder_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "dn_nar_encoder_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "dn_last_error": (C.c_char_p, []),
     "dn_version": (C.c_int, []),
     "dn_cmlm_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),

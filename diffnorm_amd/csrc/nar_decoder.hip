@@ -11,16 +11,11 @@
 
 #include "common.h"
 #include "engine.h"
+#include "nar_common.h"
 
 using namespace dn;
 
 namespace dn {
-
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // x[b, t, :] = sqrt(D) * E[tok] + P[pos], pos = padding_idx + (rank of t among the non-pad tokens of its row), pad -> padding_idx
 // (fairseq/utils.py:256-266; table row padding_idx is zero; transformer_decoder.py:254-275).  One workgroup per sequence; also
@@ -53,46 +48,6 @@ __global__ __launch_bounds__(256) void nar_embed_kernel(const int32_t* __restric
       v = make_float4(fmaf(scale, e.x, p.x), fmaf(scale, e.y, p.y), fmaf(scale, e.z, p.z), fmaf(scale, e.w, p.w));
     }
     *reinterpret_cast<float4*>(x + ((int64_t)b * T + t) * Dp + c) = v;
-  }
-}
-
-// LayerNorm (eps 1e-5, biased variance, affine): x fp32 [M, ldx] -> y [M, ldy] in out_dtype (pad columns zeroed).  One wave per
-// row, D <= 1024 in registers.
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, void* __restrict__ y, int ldy, int out_dtype, int M,
-                                                        int D, const float* __restrict__ gamma, const float* __restrict__ beta) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* xr = x + (int64_t)row * ldx;
-  float4 v[4];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
-    s += v[i].x + v[i].y + v[i].z + v[i].w;
-  }
-  const float mean = wave_sum64(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < D) {
-      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-      q += a * a + b * b + cc * cc + d * d;
-    }
-  }
-  const float rstd = rsqrtf(wave_sum64(q) / (float)D + 1e-5f);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c >= ldy) continue;
-    float o[4] = {0, 0, 0, 0};
-    if (c < D) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
-      o[0] = (v[i].x - mean) * rstd * g.x + be.x; o[1] = (v[i].y - mean) * rstd * g.y + be.y;
-      o[2] = (v[i].z - mean) * rstd * g.z + be.z; o[3] = (v[i].w - mean) * rstd * g.w + be.w;
-    }
-    store4(y, (int64_t)row * ldy + c, out_dtype, o[0], o[1], o[2], o[3]);
   }
 }
 

@@ -61,6 +61,88 @@ def pack_nar(sd: Dict[str, torch.Tensor], dim: int, ffn: int, layers: int, vocab
             g("layer_norm.bias").contiguous(), mat(g("output_projection.weight"))]
 
 
+def pack_nar_encoder(sd: Dict[str, torch.Tensor], input_dim: int, conv_channels: int, kernel: int, dim: int, ffn: int, layers: int, max_pos: int,
+                     pad: int, dtype: int) -> List[torch.Tensor]:
+    """Reference-named encoder state dict (S2TTransformerEncoder.state_dict()) -> the tensor table of dn_nar_encoder_create."""
+    g = lambda k: sd[k].float()
+    mat = lambda w: packing._mat(w, dtype, cols=w.shape[1])
+    stack = lambda items: torch.stack(items).contiguous()
+
+    def conv_mat(w, cols=None):  # Conv1d weight [out, in, k] -> [out, k * in], column j * in + c (the gathered rows' order)
+        w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)
+        return packing._mat(w2, dtype, cols=cols or w2.shape[1])
+
+    c0, c1 = g("subsample.conv_layers.0.weight"), g("subsample.conv_layers.1.weight")
+    assert c0.shape == (conv_channels, input_dim, kernel) and c1.shape == (2 * dim, conv_channels // 2, kernel), (c0.shape, c1.shape)
+    qkv_W, qkv_b, so_W, so_b, f1W, f1b, f2W, f2b, lng, lnb = ([] for _ in range(10))
+    for l in range(layers):
+        p = f"transformer_layers.{l}."
+        sa = p + "self_attn."
+        qkv_W.append(mat(torch.cat([g(sa + "q_proj.weight"), g(sa + "k_proj.weight"), g(sa + "v_proj.weight")])))
+        qkv_b.append(torch.cat([g(sa + "q_proj.bias"), g(sa + "k_proj.bias"), g(sa + "v_proj.bias")]))
+        so_W.append(mat(g(sa + "out_proj.weight"))); so_b.append(g(sa + "out_proj.bias"))
+        f1W.append(mat(g(p + "fc1.weight"))); f1b.append(g(p + "fc1.bias"))
+        f2W.append(mat(g(p + "fc2.weight"))); f2b.append(g(p + "fc2.bias"))
+        lng.append(torch.stack([g(p + "self_attn_layer_norm.weight"), g(p + "final_layer_norm.weight")]))
+        lnb.append(torch.stack([g(p + "self_attn_layer_norm.bias"), g(p + "final_layer_norm.bias")]))
+    return [conv_mat(c0, cols=packing.padk(kernel * input_dim)), g("subsample.conv_layers.0.bias").contiguous(), conv_mat(c1),
+            g("subsample.conv_layers.1.bias").contiguous(), sinusoidal_table(max_pos, dim, pad), stack(qkv_W), stack(qkv_b), stack(so_W), stack(so_b),
+            stack(f1W), stack(f1b), stack(f2W), stack(f2b), stack(lng), stack(lnb), g("layer_norm.weight").contiguous(), g("layer_norm.bias").contiguous()]
+
+
+class NarEncoderEngine(_Engine):
+    """dn_nar_encoder_* of libdiffnorm_hip.so: the speech encoder of the NAR S2UT model (S2STransformerEncoder,
+    research/TranSpeech/nar_transformer.py:40-76): one pass per utterance batch, in front of the refinement loop."""
+
+    def __init__(self, state_dict, input_dim=80, conv_channels=1024, kernel=5, dim=512, ffn=2048, layers=12, heads=8, max_pos=6002, pad=1,
+                 dtype="bf16", device="cuda:0"):
+        self.dim, self.input_dim = dim, input_dim
+        self.dtype = _dtype_code(dtype)
+        super().__init__(device, pack_nar_encoder(state_dict, input_dim, conv_channels, kernel, dim, ffn, layers, max_pos, pad, self.dtype))
+        cfg = _lib.NarEncConfig(input_dim, conv_channels, kernel, dim, ffn, layers, heads, max_pos, pad, self.dtype)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_nar_encoder_create(C.byref(cfg), self._table, len(self.tensors), C.byref(self.handle)), "dn_nar_encoder_create")
+
+    def __del__(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.dn_nar_encoder_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def forward(self, feats: torch.Tensor, src_lengths: torch.Tensor):
+        """feats [B, L, input_dim], src_lengths [B] -> (enc_out fp32 [B, S, dim] batch-major, lengths int32 [B])."""
+        B, L, Fd = feats.shape
+        assert Fd == self.input_dim
+        feats = feats.to(self.device, torch.float32).contiguous()
+        sl = src_lengths.to(self.device, torch.int32).contiguous()
+        S = int(self.lib.dn_nar_encoder_out_frames(L))
+        out = torch.empty(B, S, self.dim, dtype=torch.float32, device=self.device)
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        wp, wn = self._aligned(self._workspace(int(self.lib.dn_nar_encoder_workspace_bytes(self.handle, B, L))))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dn_nar_encoder_forward(self.handle, feats.data_ptr(), sl.data_ptr(), B, L, out.data_ptr(), lens.data_ptr(), wp, wn,
+                                                       _lib.current_stream()), "dn_nar_encoder_forward")
+        return out, lens
+
+
+class _HipEncoder:
+    """`model.encoder` of the NAR S2UT model on the HIP engine: __call__(src_tokens [B, L, 80], src_lengths) -> the reference's encoder
+    dict (encoder_out [S, B, D], encoder_padding_mask [B, S] -- an empty list when nothing is padded, s2t_transformer.py:364-373), with
+    the batch-major copy and the subsampled lengths the decoder engine wants riding along; reorder_encoder_out as upstream (:387-420)."""
+
+    def __init__(self, engine: "NarEncoderEngine"):
+        self.engine = engine
+
+    def __call__(self, src_tokens, src_lengths=None):
+        x, lens = self.engine.forward(src_tokens, src_lengths)
+        S = x.shape[1]
+        pad = torch.arange(S, device=x.device)[None, :] >= lens[:, None]
+        return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [pad] if bool(pad.any()) else [], "encoder_embedding": [],
+                "encoder_states": [], "src_tokens": [], "src_lengths": []}
+
+    def reorder_encoder_out(self, enc, order):
+        return _GivenEncoder.reorder_encoder_out(self, enc, order)
+
+
 class NarDecoderEngine(_Engine):
     """dn_nar_* of libdiffnorm_hip.so: cross-attention keys / values once per batch, length prediction, one decoder pass."""
 
@@ -196,9 +278,17 @@ class NARS2UTDecoderModel:
     allow_length_beam = True
 
     def __init__(self, decoder_state_dict, dim=512, ffn=2048, layers=6, heads=8, vocab=1004, pad=1, unk=3, dtype="bf16", device="cuda:0",
-                 use_graph: bool = True):
+                 use_graph: bool = True, encoder_state_dict=None, encoder_kw=None):
+        """encoder_state_dict (S2TTransformerEncoder.state_dict() names; encoder_kw = NarEncoderEngine's sizes): with it `forward_encoder`
+        runs the speech encoder on the HIP engine from [B, L, 80] features, as NARS2UTTransformerModel.forward_encoder does (:566-567);
+        without it the encoder output is a tensor the caller supplies."""
         self.engine = NarDecoderEngine(decoder_state_dict, dim, ffn, layers, heads, vocab, pad=pad, dtype=dtype, device=device)
-        self.encoder = _GivenEncoder()
+        if encoder_state_dict is not None:
+            kw = dict(dim=dim, heads=heads, dtype=dtype, device=device)
+            kw.update(encoder_kw or {})
+            self.encoder = _HipEncoder(NarEncoderEngine(encoder_state_dict, **kw))
+        else:
+            self.encoder = _GivenEncoder()
         self.pad, self.unk, self.device = pad, unk, self.engine.device
         self.use_graph, self._graphs = use_graph, {}
 

@@ -702,6 +702,30 @@ int dn_nar_predict_lengths(DnNar* m, const float* enc_out, const int32_t* src_le
 int dn_nar_decoder_forward(DnNar* m, const int32_t* tokens, const void* ckv, const int32_t* src_lengths, int32_t B, int32_t T, int32_t S,
                            float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ the speech encoder of the same model */
+/* S2STransformerEncoder (research/TranSpeech/nar_transformer.py:40-76; no speaker embedding) = S2TTransformerEncoder._forward
+ * (fairseq/models/speech_to_text/s2t_transformer.py:345-373): Conv1dSubsampler (two Conv1d(kernel, stride 2, padding kernel / 2) + GLU,
+ * fairseq/models/speech_to_text/modules/convolution.py:13-57) -> sqrt(dim) scaling + sinusoidal positions of the padding mask -> `layers`
+ * pre-norm TransformerEncoderLayers (fairseq/modules/transformer_layer.py:163-226) -> LayerNorm.  Packed tensors
+ * (diffnorm_amd/nar_decoder.py::pack_nar_encoder; matrices [rows -> 128][K] in cfg.dtype, biases / norms / positions fp32):
+ *   0 conv0_W [conv_channels][padk(kernel * input_dim)] (column j * input_dim + c = weight[o][c][j])   1 conv0_b
+ *   2 conv1_W [2 dim][kernel * conv_channels / 2]   3 conv1_b   4 positions [max_pos][dim] (row `pad` zero)
+ *   5 qkv_W [layers][3 dim][dim] (q ; k ; v)   6 qkv_b   7 so_W   8 so_b   9 fc1_W   10 fc1_b   11 fc2_W   12 fc2_b
+ *   13 ln_g [layers][2][dim] (self_attn_layer_norm ; final_layer_norm)   14 ln_b   15 fin_g   16 fin_b                      */
+typedef struct DnNarEnc DnNarEnc;
+typedef struct {
+  int32_t input_dim, conv_channels, kernel, dim, ffn, layers, heads, max_pos, pad, dtype;
+} DnNarEncConfig;
+int dn_nar_encoder_create(const DnNarEncConfig* cfg, const void* const* weights, int32_t n_weights, DnNarEnc** out);
+void dn_nar_encoder_destroy(DnNarEnc* m);
+int32_t dn_nar_encoder_out_frames(int32_t L); /* frames after the two stride-2 layers: floor((L - 1) / 2) + 1, twice */
+size_t dn_nar_encoder_workspace_bytes(const DnNarEnc* m, int32_t B, int32_t L);
+/* feats fp32 [B, L, input_dim] (zero-padded behind each utterance, as the collater leaves them; the whole padded batch is convolved,
+ * like upstream), src_lengths int32 [B] -> enc_out fp32 [B, S, dim] (BATCH-major; upstream returns [S, B, dim]), out_lengths int32 [B]
+ * (Conv1dSubsampler.get_out_seq_lens_tensor: the key-padding mask of the layers and of the decoder's encoder attention).          */
+int dn_nar_encoder_forward(DnNarEnc* m, const float* feats, const int32_t* src_lengths, int32_t B, int32_t L, float* enc_out,
+                           int32_t* out_lengths, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

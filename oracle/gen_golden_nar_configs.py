@@ -21,3 +21,7 @@ def encoder_out(B, S, lens, seed):
     x = seeded((S, B, CFG.embed_dim), seed)
     pad = torch.arange(S)[None, :] >= lens[:, None]
     return {"encoder_out": [x], "encoder_padding_mask": [pad], "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": []}
+
+
+# the speech encoder at fixture size (embed / heads match CFG so its output feeds the fixture decoder)
+ENC_CFG = N.NarEncoderConfig(input_dim=80, conv_channels=128, kernel_sizes=(5, 5), embed_dim=64, ffn_dim=128, layers=2, heads=4)

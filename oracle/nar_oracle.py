@@ -124,6 +124,88 @@ def decoder_logits(sd: SD, cfg: NarConfig, tokens: torch.Tensor, enc_out: torch.
     return F.log_softmax(out, -1) if normalize else out
 
 
+# --------------------------------------------------------------------------- the speech encoder (round 4)
+@dataclass
+class NarEncoderConfig:
+    """S2TTransformerEncoder of nar_s2ut_transformer (research/TranSpeech/nar_transformer.py:954-970): 80 fbank features, Conv1dSubsampler
+    (kernels 5,5; 1024 mid channels), 512 / 2048 / 12 pre-norm layers / 8 heads."""
+    input_dim: int = 80
+    conv_channels: int = 1024
+    kernel_sizes: tuple = (5, 5)
+    embed_dim: int = 512
+    ffn_dim: int = 2048
+    layers: int = 12
+    heads: int = 8
+    pad: int = 1  # S2TTransformerEncoder.padding_idx (s2t_transformer.py:311)
+
+
+def make_nar_encoder_state_dict(cfg: NarEncoderConfig, seed: str = "narenc") -> SD:
+    """Portable deterministic weights under the reference encoder's parameter names (S2TTransformerEncoder.state_dict())."""
+    D, Fd = cfg.embed_dim, cfg.ffn_dim
+    sd: SD = {}
+
+    def lin(name, out, inp):
+        sd[name + ".weight"] = _unit_hash_normal(seed + name + ".w", (out, inp), inp ** -0.5)
+        sd[name + ".bias"] = _unit_hash_normal(seed + name + ".b", (out,), 0.1)
+
+    n = len(cfg.kernel_sizes)
+    for i, k in enumerate(cfg.kernel_sizes):  # Conv1dSubsampler (fairseq/models/speech_to_text/modules/convolution.py:31-43)
+        cin = cfg.input_dim if i == 0 else cfg.conv_channels // 2
+        cout = cfg.conv_channels if i < n - 1 else D * 2
+        sd[f"subsample.conv_layers.{i}.weight"] = _unit_hash_normal(seed + f"conv{i}.w", (cout, cin, k), 1.7 * (cin * k) ** -0.5)
+        sd[f"subsample.conv_layers.{i}.bias"] = _unit_hash_normal(seed + f"conv{i}.b", (cout,), 0.1)
+    for l in range(cfg.layers):
+        p = f"transformer_layers.{l}."
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            lin(p + "self_attn." + proj, D, D)
+        sd[p + "self_attn_layer_norm.weight"] = 1.0 + _unit_hash_normal(seed + p + "alnw", (D,), 0.1)
+        sd[p + "self_attn_layer_norm.bias"] = _unit_hash_normal(seed + p + "alnb", (D,), 0.1)
+        lin(p + "fc1", Fd, D)
+        lin(p + "fc2", D, Fd)
+        sd[p + "final_layer_norm.weight"] = 1.0 + _unit_hash_normal(seed + p + "flnw", (D,), 0.1)
+        sd[p + "final_layer_norm.bias"] = _unit_hash_normal(seed + p + "flnb", (D,), 0.1)
+    sd["layer_norm.weight"] = 1.0 + _unit_hash_normal(seed + "lnw", (D,), 0.1)
+    sd["layer_norm.bias"] = _unit_hash_normal(seed + "lnb", (D,), 0.1)
+    return sd
+
+
+def subsampled_lengths(lengths: torch.Tensor, n_layers: int) -> torch.Tensor:
+    """Conv1dSubsampler.get_out_seq_lens_tensor (convolution.py:45-49): floor((len - 1) / 2 + 1) per stride-2 layer."""
+    out = lengths.clone()
+    for _ in range(n_layers):
+        out = ((out.float() - 1) / 2 + 1).floor().long()
+    return out
+
+
+def encoder_forward(sd: SD, cfg: NarEncoderConfig, feats: torch.Tensor, src_lengths: torch.Tensor):
+    """S2TTransformerEncoder._forward (fairseq/models/speech_to_text/s2t_transformer.py:345-373), which
+    S2STransformerEncoder.forward (research/TranSpeech/nar_transformer.py:56-76) calls with no speaker embedding:
+    feats fp32 [B, L, input_dim], src_lengths [B] -> (encoder_out [S, B, D], encoder_padding_mask bool [B, S], lengths [B]).
+    The subsampler convolves the PADDED batch (frames behind an utterance's end take part, as upstream); the transformer masks keys."""
+    D = cfg.embed_dim
+    x = feats.transpose(1, 2)  # B x C x L (convolution.py:53)
+    for i, k in enumerate(cfg.kernel_sizes):
+        x = F.conv1d(x, sd[f"subsample.conv_layers.{i}.weight"], sd[f"subsample.conv_layers.{i}.bias"], stride=2, padding=k // 2)
+        x = F.glu(x, dim=1)
+    x = x.transpose(1, 2)  # B x S x D
+    lens = subsampled_lengths(src_lengths, len(cfg.kernel_sizes))
+    S = x.size(1)
+    pad = torch.arange(S)[None, :] >= lens[:, None]  # lengths_to_padding_mask (data_utils.py); S == max(lens) when one utterance fills the batch
+    nonpad = (~pad).long()
+    positions = torch.cumsum(nonpad, dim=1) * nonpad + cfg.pad  # make_positions on the mask itself (:350; fairseq/utils.py:256-266)
+    x = math.sqrt(D) * x + sinusoidal_table(cfg.pad + 1 + S, D, cfg.pad)[positions]
+    key_pad = pad if bool(pad.any()) else None
+    ln = lambda t, p: F.layer_norm(t, (D,), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    for l in range(cfg.layers):  # TransformerEncoderLayerBase.forward, normalize_before (fairseq/modules/transformer_layer.py:163-226)
+        p = f"transformer_layers.{l}."
+        h = ln(x, p + "self_attn_layer_norm")
+        x = x + _attention(sd, p + "self_attn.", h, h, key_pad, cfg.heads)
+        h = ln(x, p + "final_layer_norm")
+        x = x + F.linear(F.relu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    x = ln(x, "layer_norm")
+    return x.transpose(0, 1), pad, lens
+
+
 def predict_lengths(sd: SD, enc_out: torch.Tensor, enc_pad) -> torch.Tensor:
     """forward_length + forward_length_prediction (:436-480) without an offset: masked mean of the encoder output -> 256-way arg-max."""
     if enc_pad is not None:

@@ -287,8 +287,26 @@ def load_reference_nar():
         sys.modules[du.__name__] = du
         fd.data_utils = du
     s2t = types.ModuleType("fairseq.models.speech_to_text")
-    s2t.S2TTransformerEncoder = type("S2TTransformerEncoder", (nn.Module,), {})
+    s2t.__path__ = []
     sys.modules[s2t.__name__] = s2t
+    # The speech encoder (round 4): S2TTransformerEncoder as it lies (fairseq/models/speech_to_text/s2t_transformer.py:295-420), compiled from
+    # its class statement alone -- the module around it imports the hub interface, checkpoint utilities and the model registry,
+    # none of which the forward pass touches -- over the real Conv1dSubsampler (modules/convolution.py, torch only), the real
+    # TransformerEncoderLayer / LayerNorm / FairseqDropout / PositionalEmbedding loaded above and FairseqEncoder.
+    import ast as _ast
+    import math as _math
+
+    _pkg("fairseq.models.speech_to_text.modules")
+    conv = _load("fairseq.models.speech_to_text.modules.convolution", "fairseq/models/speech_to_text/modules/convolution.py")
+    s2t_path = os.path.join(REF, "fairseq/models/speech_to_text/s2t_transformer.py")
+    s2t_tree = _ast.parse(open(s2t_path).read())
+    enc_cls = next(n for n in s2t_tree.body if isinstance(n, _ast.ClassDef) and n.name == "S2TTransformerEncoder")
+    enc_ns = {"FairseqEncoder": models.FairseqEncoder, "FairseqDropout": mods.FairseqDropout, "math": _math, "nn": nn, "torch": torch,
+              "Conv1dSubsampler": conv.Conv1dSubsampler, "Conv2dSubsampler": conv.Conv2dSubsampler, "PositionalEmbedding": mods.PositionalEmbedding,
+              "TransformerEncoderLayer": None, "LayerNorm": mods.LayerNorm,
+              "lengths_to_padding_mask": sys.modules["fairseq.data.data_utils"].lengths_to_padding_mask, "__name__": "fairseq.models.speech_to_text.s2t_transformer"}
+    s2t._encoder_src = (enc_cls, s2t_path, enc_ns)  # finished below, once transformer_layer is loaded
+    s2t.S2TTransformerEncoder = None
     _pkg("fairseq.models.speech_to_speech")
     _pkg("fairseq.models.speech_to_speech.modules")
     ctc = types.ModuleType("fairseq.models.speech_to_speech.modules.ctc_decoder")
@@ -321,6 +339,10 @@ def load_reference_nar():
     cm._skeptical_unmasking = compile_fn("fairseq/models/nat/cmlm_transformer.py", "_skeptical_unmasking",
                                          {"new_arange": sys.modules["fairseq.utils"].new_arange})
     sys.modules[cm.__name__] = cm
+    enc_cls, s2t_path, enc_ns = s2t._encoder_src
+    enc_ns["TransformerEncoderLayer"] = mods.transformer_layer.TransformerEncoderLayer
+    exec(compile(_ast.Module(body=[enc_cls], type_ignores=[]), s2t_path, "exec"), enc_ns)
+    s2t.S2TTransformerEncoder = enc_ns["S2TTransformerEncoder"]
     nar = _load("refnar.nar_transformer", "research/TranSpeech/nar_transformer.py")
     gen = _load("refnar.iterative_refinement_generator", "research/TranSpeech/iterative_refinement_generator.py")
     out = types.SimpleNamespace(nar=nar, gen=gen, gen_fairseq=gen_f, TransformerDecoder=dec.TransformerDecoder, cfg_from_namespace=cfg_from_namespace)

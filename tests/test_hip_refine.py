@@ -89,3 +89,52 @@ def test_hip_nar_model_in_the_research_generator_reproduces_the_reference_hypoth
     model.forward_encoder = lambda inputs: to_dev(enc)
     sample = {"net_input": {"src_tokens": torch.zeros(lens.numel(), g["enc_out"].shape[0], 80, device=DEV), "src_lengths": lens.to(DEV)}}
     check_hypotheses(g, lambda kw: IterativeRefinementGenerator(Dict1004(), speech_source=True, **kw), model, sample)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("f16", 1e-2), ("bf16", 6e-2)])
+def test_nar_speech_encoder_matches_the_real_reference(golden, dtype, tol):
+    """The speech encoder in front of the loop (round 4; dn_nar_encoder_forward: Conv1dSubsampler as two gathered-row contractions with
+    the GLUs folded into the gathers, sqrt(D) scaling + positions of the padding mask, pre-norm self-attention / ReLU FFN layers,
+    LayerNorm) against the REAL S2STransformerEncoder's output (tests/golden/nar_encoder.npz) on a ragged batch of [B, L, 80] features."""
+    import nar_oracle as N
+    from diffnorm_amd import nar_decoder
+    from gen_golden_nar_configs import ENC_CFG as E
+    from test_nar_oracle import _encoder_inputs
+
+    g = golden("nar_encoder")
+    feats, lens = _encoder_inputs(g)
+    eng = nar_decoder.NarEncoderEngine(N.make_nar_encoder_state_dict(E, "narenc"), E.input_dim, E.conv_channels, E.kernel_sizes[0], E.embed_dim, E.ffn_dim,
+                                       E.layers, E.heads, dtype=dtype, device=DEV)
+    out, ol = eng.forward(feats.to(DEV), lens.to(DEV))
+    assert ol.cpu().tolist() == g["out_lens"].tolist()
+    ref = torch.from_numpy(g["encoder_out"]).transpose(0, 1)  # [S, B, D] -> [B, S, D]
+    valid = ~torch.from_numpy(g["padding_mask"])
+    err = (out.cpu() - ref)[valid].abs().max().item()
+    print(f"NAR speech encoder {dtype}: max abs err {err:.3e} (output scale {ref.abs().max().item():.2f})")
+    assert err < tol * max(1.0, ref.abs().max().item() / 4)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_generate_from_features_reproduces_the_reference(golden, dtype):
+    """generate() of the research generator from [B, L, 80] fbank-like features, the whole model on the HIP engines -- speech encoder,
+    length predictor, encoder-attention keys / values, the refinement iterations (each one captured hipGraph launch) -- reproduces the
+    hypotheses the REAL generator produced with the REAL NARS2UTTransformerModel-style model (encoder + decoder of the fixtures)."""
+    import nar_oracle as N
+    from diffnorm_amd import nar_decoder
+    from diffnorm_amd.iterative_refinement import IterativeRefinementGenerator
+    from gen_golden_nar_configs import CFG, ENC_CFG as E, Dict1004
+    from test_nar_oracle import _encoder_inputs
+
+    g = golden("nar_encoder")
+    feats, lens = _encoder_inputs(g)
+    model = nar_decoder.NARS2UTDecoderModel(
+        N.make_nar_state_dict(CFG, "nar"), CFG.embed_dim, CFG.ffn_dim, CFG.layers, CFG.heads, CFG.vocab, dtype=dtype, device=DEV,
+        encoder_state_dict=N.make_nar_encoder_state_dict(E, "narenc"),
+        encoder_kw=dict(input_dim=E.input_dim, conv_channels=E.conv_channels, kernel=E.kernel_sizes[0], ffn=E.ffn_dim, layers=E.layers))
+    gen = IterativeRefinementGenerator(Dict1004(), speech_source=True, max_iter=4, beam_size=1, adaptive=True)
+    hyps = gen.generate([model], {"net_input": {"src_tokens": feats.to(DEV), "src_lengths": lens.to(DEV)}})
+    assert len(hyps) == int(g["gen_n"])
+    for i, h in enumerate(hyps):
+        assert h[0]["tokens"].cpu().tolist() == g[f"gen_h{i}_tokens"].tolist(), i
+        assert int(h[0]["steps"]) == int(g[f"gen_h{i}_steps"])
+        assert np.abs(h[0]["positional_scores"].cpu().numpy() - g[f"gen_h{i}_scores"]).max() < 2e-4

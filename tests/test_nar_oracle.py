@@ -53,3 +53,27 @@ def test_generator_mirror_reproduces_the_reference_hypotheses_with_the_oracle_mo
     sample = {"net_input": {"src_tokens": torch.zeros(lens.numel(), g["enc_out"].shape[0], 80), "src_lengths": lens}}
     with torch.no_grad():
         check_hypotheses(g, lambda kw: IterativeRefinementGenerator(Dict1004(), speech_source=True, **kw), model, sample)
+
+
+def _encoder_inputs(g):
+    from gen_golden_configs import seeded
+    from gen_golden_nar_configs import ENC_CFG
+
+    lens = T_(g["lens"])
+    B, L = lens.numel(), int(lens.max())
+    feats = seeded((B, L, ENC_CFG.input_dim), 901) * (torch.arange(L)[None, :, None] < lens[:, None, None])
+    return feats, lens
+
+
+def test_oracle_speech_encoder_matches_the_real_reference(golden):
+    """The speech encoder of the NAR S2UT model (round 4): oracle/nar_oracle.encoder_forward against the REAL S2STransformerEncoder over
+    fairseq's S2TTransformerEncoder (tests/golden/nar_encoder.npz, oracle/gen_golden_nar_encoder.py) on a ragged batch: encoder output,
+    padding mask, subsampled lengths."""
+    from gen_golden_nar_configs import ENC_CFG
+
+    g = golden("nar_encoder")
+    feats, lens = _encoder_inputs(g)
+    with torch.no_grad():
+        eo, pad, ol = N.encoder_forward(N.make_nar_encoder_state_dict(ENC_CFG, "narenc"), ENC_CFG, feats, lens)
+    assert (eo - T_(g["encoder_out"])).abs().max().item() < 2e-5
+    assert torch.equal(pad, T_(g["padding_mask"])) and ol.tolist() == g["out_lens"].tolist()
