@@ -393,9 +393,23 @@ def refine_leg(args, dev, stream):
         dt_host, st_host = timed(True)
         dt, st = timed(False)
     assert torch.equal(st.output_tokens, st_host.output_tokens)  # the replayed iterations are the host-stepped ones
+    # the speech encoder in front of the loop (one pass per utterance batch): [B, 512, 80] fbank frames -> [B, 128, 512]
+    enc_eng = nar_decoder.NarEncoderEngine(synthetic.random_nar_encoder_state_dict(seed=4), dtype=args.dtype, device=dev)
+    fb = torch.randn(B, 4 * S, 80, generator=g).to(dev)
+    fl = torch.full((B,), 4 * S, dtype=torch.int32, device=dev)
+    with torch.cuda.stream(stream):
+        enc_eng.forward(fb, fl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eo, _ = enc_eng.forward(fb, fl)
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - t0) / 5 * 1e3
+    assert eo.shape == (B, S, 512) and torch.isfinite(eo).all().item()
+    del enc_eng
     assert int(st.output_tokens.ne(3).sum()) == B * T  # every position decided after the last iteration
     flops = B * T * 2.0 * 6 * (4 * 512 * 512 + 2 * 512 * 512 + 2 * 512 * 2048 + 2 * 512 * (T + S)) + B * T * 2.0 * 512 * 1004
-    return {"refine": {"iterations_per_s": iters / dt, "ms_per_iteration": dt / iters * 1e3, "ms_per_iteration_host_stepped": dt_host / iters * 1e3,
+    return {"refine": {"iterations_per_s": iters / dt, "ms_per_iteration": dt / iters * 1e3, "ms_per_iteration_host_stepped": dt_host / iters * 1e3, "speech_encoder_ms_per_batch": enc_ms,
                        "hypothesis_frames_per_s": B * T * iters / dt,
                        "dtype": args.dtype, "tflops": flops * iters / dt / 1e12,
                        "what": f"NAR S2UT decoder (512 / 2048 / 6 layers / 8 heads / 1004 units) inside mask-predict refinement: B = {B}, T = {T}, "

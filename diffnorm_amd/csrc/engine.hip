@@ -208,12 +208,15 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
   // The GEGLU projection (K = dim: 16 K-tiles of 64-byte row pieces on the 256 x 256 tile) reads the feed-forward norm's output and
   // nothing else does: with the split norm its producer (the attention-out contraction) can write row * gamma K-blocked, and the
   // projection then stages whole cache lines from it and from a K-blocked copy of its weights.
+  const int mid2 = dn::dn_is16(dtype) && M >= 2048 ? option_or(OPT_MID2, 0) : 0;  // option mid2: the K = dim projections on the 256 x 128 two-workgroup tile
   bool geglu_kb = false;
   static const bool geglu_kb_off = getenv("DN_GEGLU_KB") && atoi(getenv("DN_GEGLU_KB")) == 0;  // A/B timing
   if (!geglu_kb_off && split && !fuse && kblock_mode() != 0 && dn::dn_is16(dtype) && w.ffin_Wkb && Dp % 32 == 0) {
     DnGemmParams q = gemm_base(dtype, M, ip, Dp, T);
     q.epilogue = DN_EPI_GEGLU;
-    geglu_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
+    if (mid2 & 2) q.pad_ |= 9 << 16;
+    const int gt = dn_conv_gemm_tile(&q);
+    geglu_kb = kblock_mode() == 1 || gt == 3 || gt == 9;
   }
   // The same for the q/kv projection of layers >= 1 (layer 0's norm comes from the caller, row-major): its activations are the
   // attention norm's row * gamma, written by the previous layer's feed-forward-out contraction and read by nothing else.
@@ -221,7 +224,9 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
   static const bool qkv_kb_off = getenv("DN_QKV_KB") && atoi(getenv("DN_QKV_KB")) == 0;  // A/B timing
   if (!qkv_kb_off && split && !fuse && kblock_mode() != 0 && dn::dn_is16(dtype) && w.qkv_Wkb && Dp % 32 == 0) {
     DnGemmParams q = gemm_base(dtype, M, 3 * hd, Dp, T);
-    qkv_kb = kblock_mode() == 1 || dn_conv_gemm_tile(&q) == 3;
+    if (mid2 & 1) q.pad_ |= 9 << 16;
+    const int qt = dn_conv_gemm_tile(&q);
+    qkv_kb = kblock_mode() == 1 || qt == 3 || qt == 9;
   }
   // option qkv_192: the projection's 3 x 512 columns are 8 x 192 but 6 x 256 -- at [32,512] 512 tiles of 256 x 192 are two full rounds
   // of the chip, 384 tiles of 256 x 256 one and a half
@@ -236,6 +241,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       }
       p.out = tb.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
       if (qkv_192) p.pad_ |= 8 << 16;
+      else if (mid2 & 1) p.pad_ |= 9 << 16;
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
@@ -287,6 +293,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       }
       p.bias = w.ffin_b + (size_t)l * 2 * ip;
       p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
+      if (mid2 & 2) p.pad_ |= 9 << 16;
       p.out_layout = kblocked ? DN_LAYOUT_OUT_KBLOCKED : 0;
       if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd : nullptr, gb_ld);
       DN_TRY(dn_conv_gemm(&p, s));

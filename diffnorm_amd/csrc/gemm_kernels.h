@@ -1239,6 +1239,156 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(const DnGemmParam
   half(std::integral_constant<int, 1>{});
 }
 
+// ------------------------------------------------------------------------------------------ 256 x 128 tile, two workgroups per CU
+// For the short-K contractions of a transformer layer (K = 512: the q / kv and GEGLU projections, 16 K-tiles): a workgroup there is
+// prologue (fill latency), a K loop no longer than both together, and a store-bound epilogue, and the one-workgroup-per-CU tiles
+// (256 x 256, 256 x 352) have nothing to run beside either.  Two workgroups of the 128 x 128 tile do overlap each other but stage
+// twice the bytes per flop and read 16 fragments per 32 MFMAs.  This tile keeps the two workgroups per CU at three quarters of that
+// traffic: 256 (rows) x 128 (weight rows), FOUR waves of 128 x 64 (128 accumulator registers; two waves per SIMD come from the two
+// workgroups), 64-byte K-tiles like the 256 x 256 kernel (row-major or K-blocked operands: a 16-row piece is 1 KiB) in a 3-stage
+// ring of 24 KiB (72 KiB per workgroup, 144 per CU), one barrier per K-tile: 12 fragment reads per 32 MFMAs and 24 KiB of DMA per
+// 128 MFMAs.  No stagger is scheduled: the partner workgroup is out of phase by construction after the first round of tiles.
+constexpr int BNM = 128;
+template <typename E, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_mid2_kernel(const DnGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!std::is_same<E, BF16X3>::value, "split operands pair K-tiles: not on this tile");
+  if constexpr (std::is_same<E, F16>::value) f16_saturate();
+  constexpr int ES = Elem<E>::bytes;
+  constexpr int KT = ROWB2 / ES;
+  constexpr int BMM = 256, STAGES = 3;
+  constexpr int WT = BNM * ROWB2, STAGE_BYTES = WT + BMM * ROWB2;  // 8 + 16 KiB
+  constexpr int PER = 6;                                            // DMA pieces per wave per stage: 2 weight + 4 row pieces of 16 rows
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.y;
+  const int np_total = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  const int n_tiles_n = (np_total + BNM - 1) / BNM;
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int mt_, nt_;
+  tile_coords(logical, n_tiles_n, (p.M + BMM - 1) / BMM, (p.pad_ >> 24) & 0xff, mt_, nt_);
+  const int m0 = mt_ * BMM, n0 = nt_ * BNM;
+  const int w_rows = (np_total + 127) / 128 * 128;
+
+  // ---- staging: wave w stages weight rows [32 w, +32) and activation rows [64 w, +64), 16 rows x 64 B per piece
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+  int a_row[4], a_t[4], w_row[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + wave * 64 + i * 16 + srow;
+    m = m < p.M ? m : p.M - 1;
+    a_row[i] = m;
+    a_t[i] = m % p.T;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wave * 32 + i * 16 + srow;
+    w_row[i] = n < w_rows ? n : w_rows - 1;
+  }
+  const int ktiles_per_term = p.K / KT;
+  const int nkt = p.n_terms * ktiles_per_term;
+  const char* zero_src = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+  const char* a_ptr[4];
+  const char* w_ptr[2];
+  int a_inc[4], w_inc = ROWB2;
+  int s_term = 0, s_kk = 0;
+  auto setup_term = [&](int term) {
+    const DnGemmTerm& tm = p.terms[term];
+    const int shift = tm.shift_by_group ? tm.shift * (1 << g) : tm.shift;
+    const char* A = reinterpret_cast<const char*>(tm.A) + (tm.a_gstride * g) * ES + schunk * 16;
+    const char* W = reinterpret_cast<const char*>(tm.W) + (tm.w_gstride * g) * ES + schunk * 16;
+    const bool a_kb = tm.layout & DN_LAYOUT_A_KBLOCKED, w_kb = tm.layout & DN_LAYOUT_W_KBLOCKED;
+    const int64_t a_rowb = a_kb ? ROWB2 : (int64_t)tm.lda * ES, w_rowb = w_kb ? ROWB2 : (int64_t)(tm.ldw ? tm.ldw : p.K) * ES;
+    const int a_step = a_kb ? p.M * ROWB2 : ROWB2;
+    w_inc = w_kb ? w_rows * ROWB2 : ROWB2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool valid = shift_valid(a_t[i], shift, p.T);
+      a_ptr[i] = valid ? A + (int64_t)(a_row[i] - shift) * a_rowb : zero_src;
+      a_inc[i] = valid ? a_step : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w_ptr[i] = W + (int64_t)w_row[i] * w_rowb;
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)smem);
+  auto stage = [&](int slot) {
+    const uint32_t wbase = lds_base + slot * STAGE_BYTES + wave * 2048;
+    const uint32_t abase = lds_base + slot * STAGE_BYTES + WT + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(w_ptr[i], wbase + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_ptr[i], abase + i * 1024);
+    if (++s_kk == ktiles_per_term) {
+      s_kk = 0;
+      if (++s_term < p.n_terms) setup_term(s_term);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] += a_inc[i];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w_ptr[i] += w_inc;
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int coff = (fq ^ (((frow >> 3) & 1) << 1)) << 4;
+  const int w_rd = (wn * 64 + frow) * ROWB2 + coff;
+  const int a_rd = WT + (wm * 128 + frow) * ROWB2 + coff;
+  uint4 wf[4], af[8];
+
+  setup_term(0);
+  stage(0);
+  if (nkt > 1) stage(1);
+  int slot = 0, fill = 2;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tile kt landed for every wave (tile kt + 1 may stay in flight); every wave is done reading tile kt - 1, whose slot receives tile kt + 2
+    if (kt + 1 < nkt) pipe_sync<PER>(); else pipe_sync<0>();
+    if (kt + 2 < nkt) stage(fill);
+    const char* sb = smem + slot * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const uint4*>(sb + w_rd + i * 16 * ROWB2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_rd + i * 16 * ROWB2);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) mma_kstep<E>(acc[nt][mt], wf[nt], af[mt]);
+    slot = slot == STAGES - 1 ? 0 : slot + 1;
+    fill = fill == STAGES - 1 ? 0 : fill + 1;
+  }
+  __syncthreads();  // ring reads over: the slabs overwrite it
+
+  // ---- epilogue: the wave's 128 (m) x 64 (n) sub-tile as two 64 x 64 slabs through its private LDS slab
+  float* ep = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+  auto half = [&](auto hc) {
+    constexpr int H = decltype(hc)::value;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (mt * 16 + frow) * EP_LD + nt * 16 + fq * 4) = acc[nt][H * 4 + mt];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_epilogue<EPI, false, std::is_same<E, F16>::value>(p, ep, m0 + wm * 128 + H * 64, n0 + wn * 64, g, lane, 64, -1.f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  half(std::integral_constant<int, 0>{});
+  half(std::integral_constant<int, 1>{});
+}
+
 // ------------------------------------------------------------------------------------------ whole-row tile + fused RMSNorm
 // For the two contractions per transformer layer that close a residual branch (to_out and the FFN's last Linear, N = D)
 // and the WaveNet's final 1x1 conv: a 64 (rows) x 512 (all columns) tile, so one workgroup sees complete rows of the new
@@ -2176,6 +2326,25 @@ static int launch_big(const DnGemmParams& p, hipStream_t s) {
 }
 
 template <typename E, int EPI>
+static int launch_mid2(const DnGemmParams& p, hipStream_t s) {
+  constexpr int ring = 3 * (BNM + 256) * ROWB2, slabs = 4 * 64 * EP_LD * 4;
+  constexpr int lds = ring > slabs ? ring : slabs;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_mid2_kernel<E, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const int np = p.N * (EPI == DN_EPI_GEGLU ? 2 : 1);
+  dim3 grid(((p.M + 255) / 256) * ((np + BNM - 1) / BNM), p.groups);
+  const bool timed = g_prof.cap > 0 && ((p.pad_ >> 8) & 0xff) == g_prof.tag && g_prof.n < g_prof.cap;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+  hipLaunchKernelGGL((conv_gemm_mid2_kernel<E, EPI>), grid, dim3(256), lds, s, p);
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], s);
+  DN_CHECK_LAUNCH("dn_conv_gemm (256 x 128 tile, two workgroups per CU)");
+  return DN_OK;
+}
+
+template <typename E, int EPI>
 static int launch_row(const DnGemmParams& p, hipStream_t s) {
   constexpr int ring = 2 * (512 + 64) * ROWB, slabs = 8 * 64 * EP_LD * 4 + 64 * 8 * 4;
   constexpr int lds = ring > slabs ? ring : slabs;
@@ -2323,8 +2492,10 @@ static inline int choose_tile(const DnGemmParams& p) {
   if (force == 0 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && taps_route_by_shape() && terms_are_taps(p)) return 3;
   bool kblocked = false;
   for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
-  if (kblocked) return bf && force == 8 && p.epilogue == DN_EPI_BIAS ? 8 : bf && (force == 0 || force == 3) ? 3 : -1;  // the other tile that takes them (8: its 192-column form)
+  const bool mid2_ok = bf && p.epilogue != DN_EPI_RESADD && p.epilogue != DN_EPI_POSEMB;  // tile 9: 256 x 128, two workgroups per CU (no residual prefetch / split-norm producer on it)
+  if (kblocked) return bf && force == 8 && p.epilogue == DN_EPI_BIAS ? 8 : mid2_ok && force == 9 ? 9 : bf && (force == 0 || force == 3) ? 3 : -1;  // the other tiles that take them (8: the 192-column form)
   if (bf && force == 8 && p.epilogue == DN_EPI_BIAS) return 8;
+  if (mid2_ok && force == 9) return 9;
   if (p.dtype == DN_BF16 && (force == 6 || force == 7)) return force;
   if (force >= 1 && force <= 3) return force;
 
@@ -2369,7 +2540,7 @@ static inline int choose_band(const DnGemmParams& p, int tile) {
   static const int env_band = getenv("DN_GEMM_BAND") ? atoi(getenv("DN_GEMM_BAND")) : -1;
   if (env_band >= 0) return env_band < 255 ? env_band : 255;
   const int es = dn_is16(p.dtype) ? 2 : 4;
-  const int bm = tile == 1 ? 128 : 256, bn = tile == 3 ? 256 : 128, conc = 32 * (tile == 1 ? 2 : 1);
+  const int bm = tile == 1 ? 128 : 256, bn = tile == 3 ? 256 : 128, conc = 32 * (tile == 1 || tile == 9 ? 2 : 1);
   const int np = p.N * (p.epilogue == DN_EPI_GEGLU ? 2 : 1);
   const double w_total = (double)np * p.K * p.n_terms * es;
   if (w_total < 6.0e6) return 1;
@@ -2388,7 +2559,7 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   const int tile = choose_tile(p);
   static const bool no_res_prefetch = getenv("DN_RES_PREFETCH") && atoi(getenv("DN_RES_PREFETCH")) == 0;  // A/B timing
   if (no_res_prefetch) p.pad_ |= 32;
-  if (tile >= 1 && tile <= 3 && ((p.pad_ >> 24) & 0xff) == 0)  // bits 24..31 of pad_: a band forced by the caller (tests)
+  if (((tile >= 1 && tile <= 3) || tile == 9) && ((p.pad_ >> 24) & 0xff) == 0)  // bits 24..31 of pad_: a band forced by the caller (tests)
     p.pad_ = (p.pad_ & 0x00ffffff) | (choose_band(p, tile) << 24);
   DN_CHECK_ARG(tile > 0, "dn_conv_gemm: K-blocked operands are taken by the 256 x 352 and 256 x 256 tiles only (bf16; forced tile %d)",
                forced_tile(p));
@@ -2408,6 +2579,9 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   }
   if constexpr (EPI == DN_EPI_BIAS && IsHalf<E>::value) {
     if (tile == 8) return launch_big<E, EPI, 192>(p, s);  // 256 x 192: widths that are whole multiples of 192 but ragged on 256 (forced-only)
+  }
+  if constexpr (IsHalf<E>::value && EPI != DN_EPI_RESADD && EPI != DN_EPI_POSEMB) {
+    if (tile == 9) return launch_mid2<E, EPI>(p, s);
   }
   if constexpr (std::is_same<E, BF16>::value) {  // (the forced-only hand-scheduled 256 x 256 forms: kept for bf16)
     if (tile == 6) return launch_fat<E, EPI, 8>(p, s);

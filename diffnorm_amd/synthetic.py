@@ -154,3 +154,24 @@ def random_nar_decoder_state_dict(dim=512, ffn=2048, layers=6, vocab=1004, pad=1
     sd["layer_norm.weight"], sd["layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
     sd["output_projection.weight"] = n(vocab, dim, scale=dim ** -0.5)
     return sd
+
+
+def random_nar_encoder_state_dict(input_dim=80, conv_channels=1024, kernel=5, dim=512, ffn=2048, layers=12, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the NAR S2UT model's speech encoder under the reference's parameter names (S2TTransformerEncoder.state_dict():
+    fairseq/models/speech_to_text/s2t_transformer.py:299-343): nar_s2ut_transformer's sizes by default (research/TranSpeech/nar_transformer.py:954-970)."""
+    g = torch.Generator().manual_seed(seed)
+    n = lambda *shape, scale=1.0: torch.randn(*shape, generator=g) * scale
+    sd = {"subsample.conv_layers.0.weight": n(conv_channels, input_dim, kernel, scale=(input_dim * kernel) ** -0.5),
+          "subsample.conv_layers.0.bias": n(conv_channels, scale=0.02),
+          "subsample.conv_layers.1.weight": n(2 * dim, conv_channels // 2, kernel, scale=(conv_channels // 2 * kernel) ** -0.5),
+          "subsample.conv_layers.1.bias": n(2 * dim, scale=0.02)}
+    for l in range(layers):
+        p = f"transformer_layers.{l}."
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            sd[p + f"self_attn.{proj}.weight"], sd[p + f"self_attn.{proj}.bias"] = n(dim, dim, scale=dim ** -0.5), n(dim, scale=0.02)
+        sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+        sd[p + "fc1.weight"], sd[p + "fc1.bias"] = n(ffn, dim, scale=dim ** -0.5), n(ffn, scale=0.02)
+        sd[p + "fc2.weight"], sd[p + "fc2.bias"] = n(dim, ffn, scale=ffn ** -0.5), n(dim, scale=0.02)
+        sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+    sd["layer_norm.weight"], sd["layer_norm.bias"] = torch.ones(dim), torch.zeros(dim)
+    return sd
