@@ -35,6 +35,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"wgrad_groups", "DN_WGRAD_GROUPS", nullptr},          // 0: one weight-gradient launch per WaveNet block
     {"qkv_192", "DN_QKV_192", nullptr},                    // 1: the q/kv projection (N = 1536 = 8 x 192) on the 256 x 192 tile (A/B timing)
     {"mid2", "DN_MID2", nullptr},                          // bit 0 / bit 1: the q/kv / GEGLU projection on the 256 x 128 two-workgroups-per-CU tile
+    {"wgrad_stages", "DN_WGRAD_STAGES", nullptr},          // 5: the weight-gradient kernel on a 160 KiB ring of five stages (default 4 stages = 128 KiB)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;

@@ -54,11 +54,13 @@ __device__ __forceinline__ void pipe_sync_w() {
 constexpr int TROW = 512;            // bytes of one frame's 256 columns
 constexpr int TTILE = 32 * TROW;     // one operand's K-tile: 16 KiB
 constexpr int TSTAGE = 2 * TTILE;    // X tile, then dY tile
-constexpr int TSTAGES = 4;
+// ring depth: 4 stages (128 KiB) or 5 (160 KiB: all of a CU's LDS -- the epilogue stores straight from the accumulators).  The K loop
+// moves 34 GB/s per CU on the VAE's FFN-conv gradient with 96 KiB in flight; a fifth stage was the test of whether that is latency: it is not.
 
 // byte offset of 8-byte piece `byte` of frame row `row` (0..31) in a tile: 32-byte granules swizzled with the row
 __device__ __forceinline__ int tn_off(int row, int byte) { return row * TROW + ((((byte >> 5) ^ (row & 15))) << 5) + (byte & 31); }
 
+template <int TSTAGES>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -162,7 +164,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
 #pragma unroll
   for (int st = 0; st < TSTAGES - 1; ++st)
     if (st < nkt) stage(st);
-  if (nkt > 2) pipe_sync_w<2 * PER>(); else if (nkt > 1) pipe_sync_w<PER>(); else pipe_sync_w<0>();
+  // tile 0 has landed; up to TSTAGES - 2 later ones may stay in flight
+  if (nkt >= TSTAGES) pipe_sync_w<(TSTAGES - 2) * PER>();
+  else if (nkt == 4) pipe_sync_w<3 * PER>();  // (TSTAGES == 5 only)
+  else if (nkt == 3) pipe_sync_w<2 * PER>();
+  else if (nkt == 2) pipe_sync_w<PER>();
+  else pipe_sync_w<0>();
   __builtin_amdgcn_sched_barrier(0);
   if (late) pipe_sync_w<63>();  // the stagger
   auto ktile = [&](auto late_c, auto stage_c, auto sync_c, int slot, int fill) {
@@ -183,7 +190,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
     using std::integral_constant;
     int slot = 0, fill = TSTAGES - 1, kt = 0;
     auto adv = [&]() { slot = slot == TSTAGES - 1 ? 0 : slot + 1; fill = fill == TSTAGES - 1 ? 0 : fill + 1; };
-    for (; kt + 3 < nkt; ++kt) { ktile(late_c, std::true_type{}, integral_constant<int, 2 * PER>{}, slot, fill); adv(); }
+    // the barrier that closes K-tile kt needs tile kt + 1 landed: tiles kt + 2 .. (last issued) may stay in flight
+    for (; kt + (TSTAGES - 1) < nkt; ++kt) { ktile(late_c, std::true_type{}, integral_constant<int, (TSTAGES - 2) * PER>{}, slot, fill); adv(); }
+    if constexpr (TSTAGES == 5) {
+      if (nkt >= 4) { ktile(late_c, std::false_type{}, integral_constant<int, 2 * PER>{}, slot, fill); adv(); }
+    }
     if (nkt >= 3) { ktile(late_c, std::false_type{}, integral_constant<int, PER>{}, slot, fill); adv(); }
     if (nkt >= 2) { ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill); adv(); }
     ktile(late_c, std::false_type{}, integral_constant<int, 0>{}, slot, fill);
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
   }
 }
 
+
 }  // namespace
 
 // see include/diffnorm_hip.h
@@ -253,15 +265,21 @@ int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, co
     p.shift_by_group = grp->shift_by_group;
   }
   static bool attr_done = false;
-  constexpr int lds = TSTAGES * TSTAGE;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TSTAGE);
     attr_done = true;
   }
   dim3 grid(((p.n_total + 255) / 256) * ((cout + 255) / 256), slices, groups);
   const bool timed = tag != 0 && g_prof.cap > 0 && tag == g_prof.tag && g_prof.n < g_prof.cap;
+  // option wgrad_stages = 5: the 160 KiB ring (A/B timing: measured level with the 128 KiB one, 353 vs 354 us on the VAE's FFN-conv
+  // gradient -- the loop is not waiting for its operands).  Also measured and dropped (round 4): four waves of 128 x 128 with the
+  // fragments double-buffered in registers and the accumulators pinned to AGPRs, 16 fragments per 64 MFMAs instead of 12 per 32 --
+  // 434 vs 343 us: with one wave per SIMD the compiler's schedule leaves the LDS round trips of a K-tile exposed.
+  const bool deep = option_or(OPT_WGRAD_STAGES, 4) >= 5;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
-  hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(512), lds, (hipStream_t)stream, p);
+  if (deep) hipLaunchKernelGGL(wgrad_tn_kernel<5>, grid, dim3(512), 5 * TSTAGE, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(wgrad_tn_kernel<4>, grid, dim3(512), 4 * TSTAGE, (hipStream_t)stream, p);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], (hipStream_t)stream);
   DN_CHECK_LAUNCH("dn_conv_weight_grad_tn");
   return DN_OK;
