@@ -441,10 +441,19 @@ def cond_leg(args, dev, stream, B, T):
         evals = eng.guided_ddim_chain(x, lengths, prompt, plens, n + 1, coef, cond_scale=2.0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # a chain's fixed cost (the time table of its steps, the prompt-only stage, the graph capture) amortises over its length: a
+        # second, 4x longer chain separates the per-step time from it
+        t0 = time.perf_counter()
+        evals4 = eng.guided_ddim_chain(x, lengths, prompt, plens, 4 * n + 1, coef, cond_scale=2.0)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t0
         assert torch.isfinite(x).all().item()
-    return {"cond": {"guided_steps_per_s": evals / dt, "ms_per_guided_step": dt / evals * 1e3, "dtype": args.dtype, "cond_scale": 2.0,
+    per_step = (dt4 - dt) / (evals4 - evals)
+    return {"cond": {"guided_steps_per_s": 1.0 / per_step, "ms_per_guided_step": per_step * 1e3, "chain_fixed_ms": max(0.0, dt - evals * per_step) * 1e3,
+                     "ms_per_guided_step_of_a_21_step_chain_incl_fixed": dt / evals * 1e3, "dtype": args.dtype, "cond_scale": 2.0,
                      "what": f"prompted + guided chain of the conditional eps-predictor (dim 512, prompt 768 x {Tp} frames, 64 resampler latents) on [B={B},T={T}] "
-                             f"latents: every step = one pass over 2B rows (conditioned ; null) + guidance + DDIM update, {evals} steps incl. graph capture"}}
+                             f"latents: every step = one pass over 2B rows (conditioned ; null) + guidance + DDIM update; per-step time from the difference of a "
+                             f"{evals4}- and a {evals}-step chain (the prompt-only stage, the chain's time table and the graph capture are once per chain)"}}
 
 
 # Which arithmetic mode meets which of north_star's budgets ("1e-3 fp32 / 1e-2 bf16", max-abs vs the reference's fp32 outputs),

@@ -31,6 +31,19 @@ _CFG_GROUPS = {  # which namespace attributes the reference's nested config keep
 }
 
 
+def _config_value(v):
+    """What OmegaConf.create can hold (the reference's load path runs `OmegaConf.create(state["cfg"])`, fairseq/checkpoint_utils.py:
+    convert_namespace / load_checkpoint_to_cpu): None, bool, int, float, str and lists / dicts of those.  Anything else a namespace may
+    carry (a device, a dtype, a callable, a tensor) is written as its string."""
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    if isinstance(v, (list, tuple)):
+        return [_config_value(x) for x in v]
+    if isinstance(v, dict):
+        return {str(k): _config_value(x) for k, x in v.items()}
+    return str(v)
+
+
 def nested_cfg(args) -> Optional[Dict[str, Dict[str, Any]]]:
     """The flat namespace as the nested container the reference trainer writes under "cfg" (trainer.state_dict, fairseq/trainer.py:
     392-436: {model, task, criterion, common, ...}, a plain-dict rendering of its OmegaConf object); `model` carries every attribute
@@ -38,6 +51,7 @@ def nested_cfg(args) -> Optional[Dict[str, Dict[str, Any]]]:
     if args is None:
         return None
     flat = dict(args) if isinstance(args, dict) else dict(vars(args))
+    flat = {k: _config_value(v) for k, v in flat.items()}
     cfg = {"model": dict(flat, _name=flat.get("arch"))}
     for group, keys in _CFG_GROUPS.items():
         cfg[group] = {k: flat[k] for k in keys if k in flat}
@@ -51,9 +65,9 @@ def save_checkpoint(path: str, model, args=None, criterion=None, optimizer=None,
                     num_updates: int = 0, extra_state: Optional[dict] = None) -> Dict[str, Any]:
     """The optimizer entry: the HIP-backed FlatOptimizer's moments are flat buffers in the PACKED layout -- resumable here, not by the
     reference (whose Adam keeps per-parameter exp_avg / exp_avg_sq).  They are stored under "last_optimizer_state" with
-    "optimizer_name" = "FlatOptimizer" so that a reference-side `load_checkpoint(..., reset_optimizer=True)` -- or its own check
-    that the optimizer class matches (trainer.py:520-533) -- skips them instead of mis-reading them; the MODEL entry is what is
-    interchangeable both ways."""
+    "optimizer_name" = "FlatOptimizer": the reference's trainer ASSERTS that the stored optimizer class equals its own
+    (trainer.py:520-533) and raises otherwise, so resuming such a checkpoint in the reference needs `--reset-optimizer` (which skips
+    the optimizer state); the MODEL entry is what is interchangeable both ways."""
     state = {
         "args": None,  # as the reference trainer writes it (legacy slot; load_model_ensemble_and_task takes the "cfg" branch then)
         "cfg": nested_cfg(args),

@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 #include "engine.h"
 
@@ -198,20 +201,28 @@ namespace {
 // (19.15 / 35.1 ms with them on the side stream as well: sixteen forks per stack for launches that are too short to matter).
 struct WgSide {
   hipStream_t s = nullptr;
-  hipEvent_t ready = nullptr, done[8] = {};
-  int next = 0;
+  hipEvent_t ready = nullptr, all = nullptr, done[8] = {};
+  std::atomic<int> next{0};
+  bool tried = false, ok = false;
 };
+// One side stream and event set PER DEVICE, created (under a lock) on the device that is current when an engine on it first asks:
+// an engine on another device of the same process gets its own, never another device's events.
 WgSide* wg_side() {
-  static WgSide side;
-  static bool tried = false, ok = false;
+  static WgSide sides[16];
+  static std::mutex mu;
   if (option_or(OPT_WGRAD_STREAM, 1) == 0) return nullptr;
-  if (!tried) {
-    tried = true;
-    ok = hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&side.ready, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&side.done[i], hipEventDisableTiming) == hipSuccess;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  WgSide& side = sides[dev];
+  std::lock_guard<std::mutex> lock(mu);
+  if (!side.tried) {
+    side.tried = true;
+    side.ok = hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&side.ready, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&side.all, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 8 && side.ok; ++i) side.ok = hipEventCreateWithFlags(&side.done[i], hipEventDisableTiming) == hipSuccess;
   }
-  return ok ? &side : nullptr;
+  return side.ok ? &side : nullptr;
 }
 
 struct Ctx {
@@ -301,7 +312,7 @@ int weight_grad(const Ctx& c0, const WgTap* taps, int n_taps, int cin, const voi
   }
   auto finish = [&](int rc) {
     if (rc != DN_OK || !side) return rc;
-    const int h = side->next++ & 7;
+    const int h = side->next.fetch_add(1) & 7;
     if (hipEventRecord(side->done[h], side->s) != hipSuccess) return (int)DN_ELAUNCH;
     *overlap = h;
     return rc;
@@ -702,6 +713,16 @@ int tf_backward_head(const Ctx& c, const TfP& w, const TfSave& sv, const void* d
 // one layer: tb.dx / tb.dx_act hold d x[l+1] on entry, d x[l] on exit
 int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths, const TfSave& sv, const TfTmp& tb, const float* gb = nullptr,
                       int gb_ld = 0, float* d_gb = nullptr) {
+  // An early error return must not leave the side stream running behind the caller's back (it still writes wg_scratch and
+  // gradients the caller may reuse or free): unless the layer ends normally -- where the last weight gradient is waited for --
+  // the main stream is made to wait for everything the side stream has been given.
+  struct JoinOnError {
+    const Ctx& c;
+    bool armed = true;
+    ~JoinOnError() {
+      if (armed && c.side && hipEventRecord(c.side->all, c.side->s) == hipSuccess) (void)hipStreamWaitEvent(c.s, c.side->all, 0);
+    }
+  } join{c};
   const int dtype = c.dtype, es = c.es, B = c.B, T = c.T, M = c.M;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
   const size_t MD = (size_t)M * Dp;
@@ -780,7 +801,9 @@ int tf_backward_layer(const Ctx& c, const TfP& w, int l, const int32_t* lengths,
   DN_TRY(dn_rmsnorm_backward(x, Dp, tb.d_xn, Dp, dtype, B, T, D, ada ? nullptr : c.P(w.g1(l)), ada ? gb + col1 : nullptr, gb_ld, Dp, tb.dx, tb.dx,
                              tb.dx_act, dtype, Dp, (ada || c.frozen) ? nullptr : c.G(w.g1(l)), ada ? d_gb + col1 : nullptr, gb_ld, c.red_scratch,
                              c.s));
-  return wg_wait(c, h_last);
+  const int rc = wg_wait(c, h_last);
+  join.armed = rc != DN_OK;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------ workspace plan

@@ -70,3 +70,28 @@ def test_plugin_loads_the_vae_checkpoint_for_the_diffusion_model(tmp_path):
     checkpoint.load_checkpoint(ck, fresh)
     for k, v in sd.items():
         assert torch.equal(fresh.state_dict()[k], v), k
+
+
+def test_cfg_holds_only_what_omegaconf_can_hold():
+    """The reference's load path runs OmegaConf.create(state["cfg"]) (fairseq/checkpoint_utils.py): every value of the nested cfg must
+    be a primitive, a list or a dict of those -- a namespace that carries a device, a dtype or a callable is written as strings
+    (ADVICE round 3)."""
+    from diffnorm_amd import checkpoint
+
+    args = types.SimpleNamespace(arch="diff_discrete", lr=[1e-4], adam_betas="(0.9, 0.98)", device=torch.device("cpu"), dtype=torch.float16,
+                                 hook=len, nested={"a": torch.device("cpu"), 3: (1, 2.5, None)}, max_tokens=15000, task="speech_diffusion_discrete",
+                                 tensor=torch.zeros(2))
+    cfg = checkpoint.nested_cfg(args)
+
+    def ok(v):
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return True
+        if isinstance(v, list):
+            return all(ok(x) for x in v)
+        if isinstance(v, dict):
+            return all(isinstance(k, str) and ok(x) for k, x in v.items())
+        return False
+
+    assert ok(cfg), cfg
+    assert cfg["model"]["device"] == "cpu" and cfg["model"]["dtype"] == "torch.float16" and cfg["model"]["lr"] == [1e-4]
+    assert cfg["model"]["nested"] == {"a": "cpu", "3": [1, 2.5, None]} and cfg["dataset"]["max_tokens"] == 15000 and cfg["task"]["_name"] == "speech_diffusion_discrete"

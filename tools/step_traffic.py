@@ -20,7 +20,7 @@ def total(counter, steps):
 fetch = (total("FETCH_SIZE", sb) - total("FETCH_SIZE", sa)) / (sb - sa)
 write = (total("WRITE_SIZE", sb) - total("WRITE_SIZE", sa)) / (sb - sa)
 print(json.dumps({
-    "what": "fabric-side traffic of ONE denoising step of bench.py's workload ([B=32,T=512] bf16, single stream), from the "
+    "what": "fabric-side traffic of ONE denoising step of bench.py's workload ([B=32,T=512], the dtype of the runs, single stream), from the "
             f"difference of two PMC runs with --steps {sa} and --steps {sb}",
     "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --no-split "
                "--no-cpu-baseline --steps <n>   (4 passes); tools/step_traffic.py",
