@@ -70,7 +70,7 @@ class DiffDiscreteModel(FairseqEncoderModel):
         parser.add_argument("--multitask", type=bool, default=False)
         parser.add_argument("--diffusion-timesteps", type=int, default=200,
                             help="schedule length (upstream hard-codes 200 at diff_discrete.py:84)")
-        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "bf16x3", "f32"], help="MFMA arithmetic of the HIP engine (bf16x3: split-operand bf16, fp32-class results)")
+        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"], help="MFMA arithmetic of the HIP engine (f16: IEEE-half operands, the 2-byte mode inside the 1e-2 budget, inference only; bf16: fastest, also the fast training mode; bf16x3: split-operand bf16, fp32-class results, inference only; f32: exact)")
 
     def max_positions(self):
         return self.encoder.max_positions()

@@ -33,7 +33,7 @@ class SpeechVAEDecoder(FairseqEncoderModel):
     def add_args(parser):
         add_inherited_args(parser)
         parser.add_argument("--latent_dim", type=int, default=16)
-        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "bf16x3", "f32"], help="MFMA arithmetic of the HIP engine (bf16x3: split-operand bf16, fp32-class results)")
+        parser.add_argument("--hip-dtype", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"], help="MFMA arithmetic of the HIP engine (f16: IEEE-half operands, the 2-byte mode inside the 1e-2 budget, inference only; bf16: fastest, also the fast training mode; bf16x3: split-operand bf16, fp32-class results, inference only; f32: exact)")
 
     def max_positions(self):
         return self.encoder.max_positions()

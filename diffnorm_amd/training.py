@@ -20,6 +20,16 @@ from .profiling import profile_range
 from .engine import _dtype_code, _require_cuda
 
 
+def _training_dtype(dtype) -> int:
+    """The training engines run exact fp32 (the reference's own training arithmetic: parity at 1e-3) or bf16 (the fast mode);
+    f16 and bf16x3 are arithmetic modes of the inference / sampling engines."""
+    code = _dtype_code(dtype)
+    if code not in (_lib.DN_F32, _lib.DN_BF16):
+        raise ValueError(f"training engines run dtype 'f32' or 'bf16'; {dtype!r} is an inference-only arithmetic mode "
+                         "(build the model with --hip-dtype bf16 / f32 for a training run)")
+    return code
+
+
 def _aligned_empty(nbytes: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """(owner, 256-byte aligned uint8 view of nbytes)."""
     raw = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
@@ -55,7 +65,7 @@ class VaeTrainEngine:
         for m in self.mults:
             z //= m
         self.z = z // 2
-        self.dtype = _dtype_code(dtype)
+        self.dtype = _training_dtype(dtype)
         mults = (C.c_int32 * 4)(*(self.mults + [0] * (4 - len(self.mults))))
         cfg = _lib.VaeConfig(dim, self.z, depth, heads, dim_head, stacks, layers, vocab, len(self.mults), mults, self.dtype)
         self.handle = C.c_void_p()
@@ -259,7 +269,7 @@ class EpsTrainEngine(_FlatEngine):
         self.device = _require_cuda(device)
         self.lib = _lib.load()
         self.cfg, self.vae, self.timesteps, self.multitask = cfg, vae, timesteps, multitask
-        self.dtype = _dtype_code(dtype)
+        self.dtype = _training_dtype(dtype)
         self.depth = cfg.depth
         c = _lib.EpsConfig(cfg.dim, cfg.latent_dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.wavenet_layers, cfg.wavenet_stacks,
                            cfg.dim_cond_mult, self.dtype, max_pos)
