@@ -702,6 +702,7 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
             logged, norm = step(i)
         if os.environ.get("DN_SYNC_DEBUG"):
             torch.cuda.set_sync_debug_mode("default")
+        dt_enqueue = time.perf_counter() - t0  # the host's share: all K updates are enqueued (nothing in an update waits for the GPU)
         barrier()
         dt = time.perf_counter() - t0
         used = [batches[i % len(batches)] for i in range(K)]
@@ -734,7 +735,7 @@ def measure_training(kind, dtype, max_tokens, K, W, ctx, stream):
             ar_ms = tr.reducer.all_reduce_ms()
             tr.reducer.measure = False
     ip = (inner + 63) // 64 * 64
-    return {"dt": dt, "sent": float(sent), "toks": float(toks), "frames": float(frames), "flops": flops, "ar_ms": ar_ms,
+    return {"dt": dt, "dt_enqueue": dt_enqueue, "sent": float(sent), "toks": float(toks), "frames": float(frames), "flops": flops, "ar_ms": ar_ms,
             "k_flops": 2.0 * ip * (3 * ip) * batches[0]["frames"], "k_ms": timed["alone"], "k_ms_overlapped": timed["overlapped"], "k_n": k_n.value, "k_frames": batches[0]["frames"], "inner": ip,
             "loss": float(logged[0]), "grad_norm": float(norm), "buckets": len(tr.reducer.buckets), "gradient_bytes": eng.n_params * 4}
 
@@ -747,7 +748,7 @@ def train_summary(kind, dtype, max_tokens, K, m, world):
             "ddpm_discrete_loss update of the eps-predictor Model(512, z=128) through the frozen VAE (260.6 M trained parameters)")
     return {"loss": kind, "workload": f"{what}, synthetic (feat, unit) pairs, lengths U[64,512], --max-tokens {max_tokens} per GPU, Adam(0.9,0.98) "
                                       f"clip 2.0, attention dropout 0.1, random-init weights", "dtype": dtype, "updates": K,
-            "samples_per_s": m["sent"] / m["dt"], "tokens_per_s": m["toks"] / m["dt"], "ms_per_update": m["dt"] / K * 1e3,
+            "samples_per_s": m["sent"] / m["dt"], "tokens_per_s": m["toks"] / m["dt"], "ms_per_update": m["dt"] / K * 1e3, "host_enqueue_ms_per_update": m.get("dt_enqueue", 0.0) / K * 1e3,
             "step_tflops_per_gpu": m["flops"] / m["dt"] / 1e12 / world, "step_mfma_frac": m["flops"] / m["dt"] / 1e12 / world / peak,
             "all_reduce_ms_per_update": m["ar_ms"], "gradient_bytes": m["gradient_bytes"], "buckets": m["buckets"],
             "final_loss": m["loss"], "grad_norm": m["grad_norm"],
@@ -811,6 +812,7 @@ def run_training(args, ctx):
                        "parallelism": f"dp{world} ({'RCCL' if ctx['backend'] == 'rccl' else ctx['backend']} gradient all-reduce, {t['buckets']} buckets)"},
             "tokens_per_s": t["tokens_per_s"], "padded_frames_per_s": m["frames"] / m["dt"], "all_reduce_ms_per_update": t["all_reduce_ms_per_update"],
             "gradient_bytes": t["gradient_bytes"], "step_tflops_per_gpu": t["step_tflops_per_gpu"], "step_mfma_frac": t["step_mfma_frac"],
+            "host_enqueue_ms_per_update": t["host_enqueue_ms_per_update"],
             "loss": t["final_loss"], "grad_norm": t["grad_norm"], "roofline": t["roofline"],
         }
         print(json.dumps(result), flush=True)

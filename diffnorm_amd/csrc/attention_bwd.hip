@@ -39,22 +39,28 @@ __device__ __forceinline__ int bwd_lds_off<F32>(int row, int byte) {
 constexpr int BT = 64;  // rows of a staged tile (keys in the dq kernel, queries in the dkv kernel)
 constexpr float LSE_BIG = 3.0e38f;
 
-// delta[b, h, q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one wave per (row, head)
+// delta[b, h, q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d].  G lanes (a power of two, 8 elements each) per (row, head), 64 / G
+// consecutive heads per wave: a wave reads whole contiguous pieces of a row of both tensors.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const void* __restrict__ o, int ldo, const void* __restrict__ dout, int lddo, int dtype,
-                                                         int B, int T, int heads, int dh, float* __restrict__ delta) {
-  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (idx >= (int64_t)B * T * heads) return;
-  const int h = (int)(idx % heads);
-  const int64_t m = idx / heads;
+                                                         int B, int T, int heads, int dh, int G, float* __restrict__ delta) {
+  const int lane = threadIdx.x & 63, per = 64 / G;
+  const int sub = lane & (G - 1);
+  const int64_t idx = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * per + lane / G;
+  const bool live = idx < (int64_t)B * T * heads;
+  const int h = live ? (int)(idx % heads) : 0;
+  const int64_t m = live ? idx / heads : 0;
   float s = 0.f;
-  for (int d = lane * 4; d < dh; d += 256) {
-    const float4 a = load4(o, m * ldo + h * dh + d, dtype), g = load4(dout, m * lddo + h * dh + d, dtype);
-    s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) {
+  if (live)
+    for (int d = sub * 8; d < dh; d += G * 8) {
+      const float4 a = load4(o, m * ldo + h * dh + d, dtype), g = load4(dout, m * lddo + h * dh + d, dtype);
+      s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+      if (d + 4 < dh) {
+        const float4 a2 = load4(o, m * ldo + h * dh + d + 4, dtype), g2 = load4(dout, m * lddo + h * dh + d + 4, dtype);
+        s += a2.x * g2.x + a2.y * g2.y + a2.z * g2.z + a2.w * g2.w;
+      }
+    }
+  for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (live && sub == 0) {
     const int b = (int)(m / T), q = (int)(m - (int64_t)b * T);
     delta[((int64_t)b * heads + h) * T + q] = s;
   }
@@ -536,8 +542,11 @@ extern "C" int dn_attention_backward(const DnAttnBwdParams* pp, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     const int64_t rows = (int64_t)p.B * p.T * p.heads;
-    hipLaunchKernelGGL(dn::attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p.out, p.ldo, p.dout, p.lddo, p.dtype, p.B,
-                       p.T, p.heads, p.dim_head, p.delta);
+    int G = 1;
+    while (G < 64 && G * 8 < p.dim_head) G *= 2;  // lanes per (row, head)
+    const int64_t per_block = 4 * (64 / G);
+    hipLaunchKernelGGL(dn::attn_delta_kernel, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, s, p.out, p.ldo, p.dout, p.lddo,
+                       p.dtype, p.B, p.T, p.heads, p.dim_head, G, p.delta);
   }
   dn::AttnBwdArgs a;
   a.q = p.q; a.k = p.k; a.v = p.v; a.dout = p.dout; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;

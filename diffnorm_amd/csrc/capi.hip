@@ -36,6 +36,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"qkv_192", "DN_QKV_192", nullptr},                    // 1: the q/kv projection (N = 1536 = 8 x 192) on the 256 x 192 tile (A/B timing)
     {"mid2", "DN_MID2", nullptr},                          // bit 0 / bit 1: the q/kv / GEGLU projection on the 256 x 128 two-workgroups-per-CU tile
     {"wgrad_stages", "DN_WGRAD_STAGES", nullptr},          // 5: the weight-gradient kernel on a 160 KiB ring of five stages (default 4 stages = 128 KiB)
+    {"tile_192", "DN_TILE_192", nullptr},                  // 0: never choose the 256 x 192 tile by score (default: where a lone launch fills the chip better on it)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;

@@ -177,31 +177,37 @@ void set_norm(DnGemmParams& p, void* xn, int Dp, int D, int dtype, const float* 
   p.norm_gamma = gamma; p.norm_gb = gb; p.norm_gb_ld = gb_ld; p.norm_gb_half = Dp;
 }
 
-// gamma / conditioning row of the norm in front of (layer l, sub-block j): j = 0 attention, 1 feed-forward;
-// l == depth selects to_pred's norm.
+// gamma / conditioning row of the norm in front of (layer l, sub-block j of nj): j = 0 attention, nj - 1 feed-forward (nj = 3: 1 is the
+// cross-attention block of the prompt-conditioned model); l == depth selects to_pred's norm.
 struct NormSrc { const float* gamma; const float* gb; };
-NormSrc norm_src(const TransformerW& w, const float* gb, int l, int j) {
+NormSrc norm_src(const TransformerW& w, const float* gb, int l, int j, int nj = 2) {
   const int D = w.dim, Dp = padk(D);
   if (l == w.depth) return {w.pred_gamma, nullptr};
   const float* g = j == 0 ? w.g1 : w.g2;
-  return {g ? g + (size_t)l * D : nullptr, gb ? gb + (size_t)(2 * l + j) * 2 * Dp : nullptr};
+  return {g ? g + (size_t)l * D : nullptr, gb ? gb + (size_t)(nj * l + j) * 2 * Dp : nullptr};
 }
+
+// The prompt-conditioned model's extra block per layer (latent_module.py:694-700): cross-attention from the frames to the resampled
+// prompt latents, no mask.  kv: [depth][B * n_kv][2 hd] keys | values of every layer (they depend on the prompt only); q: [M, hd].
+struct CrossAttn { const void* q_W; const void* out_W; const void* kv; int n_kv; void* q; };
 
 // xres fp32 [M, padk(dim)] is updated in place; `pred` receives to_pred's output.  When the model width fits the
 // whole-row tile (padk(dim) <= 512) every RMSNorm is fused into the contraction that produces its input: the caller
 // supplies the first one (`xn_ready`: tb.xn already holds layer 0's attention norm) or it runs standalone once.
-// `rb` (split RMSNorm with adaptive norms only): fp32 rows [Bc, gb_ld] of beta . W^T, layer l at columns
-// l * (3 hd + 2 padk(inner)): first the q/kv projection's, then the GEGLU projection's (packed column order).
+// `rb` (split RMSNorm with adaptive norms only): fp32 rows [Bc, rb_ld] of beta . W^T, layer l at columns
+// l * (3 hd [+ hd] + 2 padk(inner)): first the q/kv projection's, [then the cross-attention query projection's,] then the GEGLU
+// projection's (packed column order).  `cx`: the cross-attention block between the two (NULL: the unconditional model).
 int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T, const int32_t* lengths, const float* gb, int gb_ld,
-                    const float* rb, const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s) {
+                    const float* rb, int rb_ld, const TfBufs& tb, void* pred, int pred_ld, int pred_dtype, bool xn_ready, hipStream_t s,
+                    const CrossAttn* cx = nullptr) {
   const int es = esize(dtype), M = B * T;
   const int D = w.dim, Dp = padk(D), Dn = padn(D), hd = w.heads * w.dim_head, ip = padk(w.inner), in_n = padn(w.inner);
   const bool fuse = fuse_norm_enabled(Dp, dtype);
   const bool split = split_norm_enabled(Dp, dtype);
-  const int rb_layer = 3 * hd + 2 * ip;
+  const int nj = cx ? 3 : 2, rb_layer = 3 * hd + (cx ? hd : 0) + 2 * ip;
   bool scaled = split && xn_ready;  // tb.xn holds row*gamma + tb.ssq its sums of squares (else: the finished norm)
   auto standalone_norm = [&](int l, int j) -> int {
-    const NormSrc ns = norm_src(w, gb, l, j);
+    const NormSrc ns = norm_src(w, gb, l, j, nj);
     return dn_rmsnorm(xres, Dp, tb.xn, Dp, dtype, M, D, T, ns.gamma, ns.gb, gb_ld, Dp, s);
   };
   if (!((fuse || split) && xn_ready)) DN_TRY(standalone_norm(0, 0));
@@ -242,7 +248,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       p.out = tb.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
       if (qkv_192) p.pad_ |= 8 << 16;
       else if (mid2 & 1) p.pad_ |= 9 << 16;
-      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, gb_ld);
+      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer : nullptr, rb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     {
@@ -258,14 +264,44 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
       p.terms[0].A = tb.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      const NormSrc ns = norm_src(w, gb, l, 1);
+      const NormSrc ns = norm_src(w, gb, l, 1, nj);
       if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
-      if (geglu_kb) p.norm_split = 2;  // row * gamma goes out K-blocked: its only reader is the GEGLU projection below
+      if (geglu_kb && !cx) p.norm_split = 2;  // row * gamma goes out K-blocked: its only reader is the GEGLU projection below
       DN_TRY(dn_conv_gemm(&p, s));
     }
     if (!fuse && !split) DN_TRY(standalone_norm(l, 1));
     scaled = split;
+    if (cx) {  // cross-attention to the resampled prompt latents, no mask (:694-700)
+      {
+        DnGemmParams p = gemm_base(dtype, M, hd, Dp, T);
+        p.terms[0].A = tb.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(cx->q_W, (size_t)l * padn(hd) * Dp, es);
+        p.out = cx->q; p.ldo = hd; p.out_dtype = side_dtype(dtype);
+        if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd : nullptr, rb_ld);
+        DN_TRY(dn_conv_gemm(&p, s));
+      }
+      {
+        const void* kv = eoff(cx->kv, (size_t)l * B * cx->n_kv * 2 * hd, esize(side_dtype(dtype)));
+        DnAttnParams a;
+        memset(&a, 0, sizeof(a));
+        a.q = cx->q; a.k = kv; a.v = eoff(kv, hd, esize(side_dtype(dtype))); a.out = tb.ao;
+        a.ldq = hd; a.ldk = a.ldv = 2 * hd; a.ldo = hd;
+        a.B = B; a.T = T; a.Tk = cx->n_kv; a.heads = w.heads; a.dim_head = w.dim_head; a.dtype = dtype; a.lengths = nullptr;
+        a.scale = 1.0f / sqrtf((float)w.dim_head);
+        DN_TRY(dn_attention(&a, s));
+      }
+      {
+        DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
+        p.terms[0].A = tb.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(cx->out_W, (size_t)l * Dn * hd, es);
+        p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
+        const NormSrc ns = norm_src(w, gb, l, 2, nj);
+        if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+        else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
+        if (geglu_kb) p.norm_split = 2;
+        DN_TRY(dn_conv_gemm(&p, s));
+      }
+      if (!fuse && !split) DN_TRY(standalone_norm(l, 2));
+    }
     // CausalConv1d(inner, inner, 3) (:894), set up first: when it runs on one of the two 256-row tiles its operands go K-blocked --
     // the GEGLU projection writes its output that way and the weights come from their K-blocked copy (the tile then stages
     // 1 KiB pieces of whole cache lines instead of sixteen half-lines: -5 % on this contraction; DN_KBLOCK=0 disables)
@@ -295,7 +331,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       p.epilogue = DN_EPI_GEGLU; p.out = tb.gg; p.ldo = ip;
       if (mid2 & 2) p.pad_ |= 9 << 16;
       p.out_layout = kblocked ? DN_LAYOUT_OUT_KBLOCKED : 0;
-      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd : nullptr, gb_ld);
+      if (scaled) set_row_scale(p, tb, Dp, D, rb ? rb + (size_t)l * rb_layer + 3 * hd + (cx ? hd : 0) : nullptr, rb_ld);
       DN_TRY(dn_conv_gemm(&p, s));
     }
     DN_TRY(dn_conv_gemm(&pc, s));
@@ -304,7 +340,7 @@ int run_transformer(const TransformerW& w, int dtype, float* xres, int B, int T,
       p.terms[0].A = tb.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
       p.bias = w.ffout_b + (size_t)l * Dp;
       p.epilogue = DN_EPI_RESADD; p.res = xres; p.ldr = Dp; p.out = xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      const NormSrc ns = norm_src(w, gb, l + 1, 0);
+      const NormSrc ns = norm_src(w, gb, l + 1, 0, nj);
       if (fuse) set_norm(p, tb.xn, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       else if (split) set_split_norm(p, tb, Dp, D, dtype, ns.gamma, ns.gb, gb_ld);
       if (qkv_kb && l + 1 < w.depth) p.norm_split = 2;  // the next layer's q/kv projection reads it K-blocked (to_pred: row-major)
@@ -441,6 +477,38 @@ extern "C" size_t dn_eps_workspace_bytes(const DnEps* m, int32_t B, int32_t T) {
 
 namespace {
 
+// Split RMSNorm: the beta of an adaptive norm reaches its consumer as beta . W^T, which depends on the conditioning row only -- one
+// grouped contraction per consumer (one group per layer) writes it to rb [n, rb_ld]: per layer [q/kv columns | cross-attention query
+// columns (prompt-conditioned model) | GEGLU columns (packed order)].  gb: the n conditioning rows (fp32, row stride gb_ld); gbh:
+// room for them in the arithmetic dtype (unused in fp32).
+int eps_beta_rows(const DnEps* m, const float* gb, int gb_ld, int n, void* gbh, float* rb, int rb_ld, hipStream_t s) {
+  const int Dp = padk(m->cfg.dim), dtype = m->cfg.dtype, es = esize(dtype);
+  const TransformerW& w = m->tf;
+  const bool cx = m->cfg.dim_prompt > 0;
+  const int hd = w.heads * w.dim_head, ip = padk(w.inner), nj = cx ? 3 : 2, rb_layer = 3 * hd + (cx ? hd : 0) + 2 * ip;
+  const size_t tf_off = (size_t)m->cfg.wn_stacks * m->cfg.wn_layers * 2 * Dp;  // first transformer norm's [gamma ; beta]
+  const void* A = gb;
+  int lda = gb_ld;
+  if (dtype != DN_F32) {  // operands in the arithmetic dtype
+    DN_TRY(dn_convert_rows(gb, DN_F32, gb_ld, gbh, dtype, m->n_cond, n, m->n_cond, s));
+    A = gbh; lda = m->n_cond;
+  }
+  int col = 0;
+  for (int j = 0; j < nj; ++j) {  // j = 0: attention norm -> q/kv projection; nj - 1: feed-forward norm -> GEGLU projection
+    const bool last = j == nj - 1;
+    const int N = j == 0 ? 3 * hd : (last ? 2 * ip : hd);
+    DnGemmParams q = gemm_base(dtype, n, N, Dp, 1);
+    q.groups = w.depth;
+    q.terms[0].A = eoff(A, tf_off + (size_t)j * 2 * Dp + Dp, es); q.terms[0].lda = lda; q.terms[0].a_gstride = (int64_t)nj * 2 * Dp;
+    q.terms[0].W = j == 0 ? w.qkv_W : (last ? w.ffin_W : m->cq_W);
+    q.terms[0].w_gstride = j == 0 ? (int64_t)padn(3 * hd) * Dp : (last ? (int64_t)2 * ip * Dp : (int64_t)padn(hd) * Dp);
+    q.out = rb + col; q.ldo = rb_ld; q.out_dtype = DN_F32; q.out_gstride = rb_layer;
+    DN_TRY(dn_conv_gemm(&q, s));
+    col += N;
+  }
+  return DN_OK;
+}
+
 // Conditioning table: rows of [gamma ; beta] for the S*L FiLM blocks and the 2*depth adaptive norms,
 // one row per entry of `times`.  Always fp32 (exact-f32 MFMA, fp32 weights): the raw integer timestep
 // drives activations of O(100), so this tiny contraction is kept out of the bf16 budget.
@@ -452,28 +520,7 @@ int eps_cond_rows(const DnEps* m, const int32_t* times, int n, float* cond, floa
   p.bias = m->cond_b; p.out = gb; p.ldo = m->n_row; p.out_dtype = DN_F32;
   DN_TRY(dn_conv_gemm(&p, s));
   if (!split_norm_enabled(Dp, dtype)) return DN_OK;
-  // Split RMSNorm: the beta of an adaptive norm reaches its consumer as beta . W^T, which depends on t only -- two grouped
-  // contractions (one group per layer) append it to the row: [q/kv columns | GEGLU columns (packed order)] per layer.
-  const TransformerW& w = m->tf;
-  const int hd = w.heads * w.dim_head, ip = padk(w.inner), rb_layer = 3 * hd + 2 * ip;
-  const size_t tf_off = (size_t)m->cfg.wn_stacks * m->cfg.wn_layers * 2 * Dp;  // first transformer norm's [gamma ; beta]
-  const void* A = gb;
-  int lda = m->n_row;
-  if (dtype != DN_F32) {  // operands in the arithmetic dtype
-    DN_TRY(dn_convert_rows(gb, DN_F32, m->n_row, gbh, dtype, m->n_cond, n, m->n_cond, s));
-    A = gbh; lda = m->n_cond;
-  }
-  for (int j = 0; j < 2; ++j) {  // j = 0: attention norm -> q/kv projection; j = 1: feed-forward norm -> GEGLU projection
-    const int N = j == 0 ? 3 * hd : 2 * ip;
-    DnGemmParams q = gemm_base(dtype, n, N, Dp, 1);
-    q.groups = w.depth;
-    q.terms[0].A = eoff(A, tf_off + (size_t)j * 2 * Dp + Dp, es); q.terms[0].lda = lda; q.terms[0].a_gstride = 4 * Dp;
-    q.terms[0].W = j == 0 ? w.qkv_W : w.ffin_W;
-    q.terms[0].w_gstride = j == 0 ? (int64_t)padn(3 * hd) * Dp : (int64_t)2 * ip * Dp;
-    q.out = gb + m->n_cond + (j == 0 ? 0 : 3 * hd); q.ldo = m->n_row; q.out_dtype = DN_F32; q.out_gstride = rb_layer;
-    DN_TRY(dn_conv_gemm(&q, s));
-  }
-  return DN_OK;
+  return eps_beta_rows(m, gb, m->n_row, n, gbh, gb + m->n_cond, m->n_row, s);
 }
 
 // Model.forward after the conditioning (latent_module.py:861-876); gb_ld == 0 -> one row for the batch.
@@ -501,7 +548,7 @@ int eps_core(const DnEps* m, const float* x, const float* gb, int gb_ld, const i
   }
   const float* gb_tf = gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
   const bool xn_ready = fuse_norm_enabled(Dp, dtype) || split_norm_enabled(Dp, dtype);
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, gb + m->n_cond, b.tf, b.tp, Dp, dtype, xn_ready, s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, gb_ld, gb + m->n_cond, gb_ld, b.tf, b.tp, Dp, dtype, xn_ready, s));
   // final_proj: dim -> latent (:807,875), dense fp32 out
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
@@ -624,8 +671,8 @@ static int sampler_loop(DnEps* m, float* x, const int32_t* lengths, int32_t B, i
     m->table_ws = workspace; m->table_B = B; m->table_T = T; m->table_split = (int)split; m->table_rows = start_step;
   }
   const int noise_top = start_step - 1;  // injected noise: row (noise_top - t) belongs to step t
-  g_twin_launches = split;  // tile choice of the half-batch launches (host side, also at graph capture)
-  struct TwinReset { ~TwinReset() { g_twin_launches = false; } } twin_reset;
+  g_twin_launches = dn::g_gemm_twin = split;  // tile choice of the half-batch launches (host side, also at graph capture)
+  struct TwinReset { ~TwinReset() { g_twin_launches = dn::g_gemm_twin = false; } } twin_reset;
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, counter);
     hipLaunchKernelGGL(copy_cond_row_kernel, dim3(32), dim3(256), 0, s, table, m->n_row, counter, bufs.gb);
@@ -797,10 +844,11 @@ __global__ void add_const_i32_kernel(const int32_t* __restrict__ a, int32_t c, i
 namespace {
 
 struct CondBufs {
-  float *cond, *pooled, *pc, *cond2, *gb, *gbp, *lat, *xres;
-  void *prompt_act, *ctx, *kvsrc, *lat_act, *rq, *rkv, *rao, *rgg, *c_act, *ckv, *xin, *h0, *xn, *qkv, *ao, *cq, *gg, *fc, *tp;
+  float *cond, *pooled, *pc, *cond2, *gb, *gbp, *lat, *xres, *rb;
+  void *prompt_act, *ctx, *kvsrc, *lat_act, *rq, *rkv, *rao, *rgg, *c_act, *ckv, *xin, *h0, *cq, *tp, *gbh;
   int32_t* klen;
   WaveBufs wv;
+  TfBufs tf;
 };
 
 CondBufs plan_eps_cond(const DnEps* m, int B, int T, int Tp, Arena& ar) {
@@ -820,8 +868,11 @@ CondBufs plan_eps_cond(const DnEps* m, int B, int T, int Tp, Arena& ar) {
   b.klen = (int32_t*)ar.take((size_t)B * 4);
   b.xin = ar.take(M * zp * es); b.h0 = ar.take(M * Dp * es);
   b.wv = plan_wave(m->wn, (int)M, es, ar);
-  b.xres = (float*)ar.take(M * Dp * 4); b.xn = ar.take(M * Dp * es); b.qkv = ar.take(M * 3 * hd * es); b.ao = ar.take(M * hd * es);
-  b.cq = ar.take(M * hd * es); b.gg = ar.take(M * ip * es); b.fc = ar.take(M * ip * es); b.tp = ar.take(M * Dp * es);
+  b.xres = (float*)ar.take(M * Dp * 4);
+  b.tf = plan_tf(m->tf, (int)M, es, ar);
+  b.cq = ar.take(M * hd * es); b.tp = ar.take(M * Dp * es);
+  b.rb = (float*)ar.take((size_t)B * c.depth * (4 * hd + 2 * ip) * 4);  // split RMSNorm: beta . W^T of every adaptive norm's consumer, per sample
+  b.gbh = es == 4 && c.dtype == DN_F32 ? nullptr : ar.take((size_t)B * m->n_cond * es);
   return b;
 }
 
@@ -994,6 +1045,9 @@ extern "C" int dn_eps_forward_cond_ex(DnEps* m, const float* x, const int32_t* t
     p.epilogue = DN_EPI_RESADD; p.res = b.gbp; p.ldr = m->n_cond; p.out = b.gb; p.ldo = m->n_cond; p.out_dtype = DN_F32;
     DN_TRY(dn_conv_gemm(&p, s));
   }
+  const bool split = split_norm_enabled(Dp, dtype), xn_ready = split || fuse_norm_enabled(Dp, dtype);
+  const int rb_ld = c.depth * (4 * hd + 2 * ip);
+  if (split) DN_TRY(eps_beta_rows(m, b.gb, m->n_cond, B, b.gbh, b.rb, rb_ld, s));
   // ---- the eps-predictor proper (:861-876)
   DN_TRY(dn_convert_rows(x, DN_F32, z, b.xin, dtype, zp, M, z, s));
   {
@@ -1006,78 +1060,16 @@ extern "C" int dn_eps_forward_cond_ex(DnEps* m, const float* x, const int32_t* t
     DnGemmParams fin = gemm_base(dtype, M, Dp, Dp, T);
     fin.epilogue = DN_EPI_POSEMB; fin.pos_table = m->pos_table; fin.pos_ld = Dp; fin.lengths = lengths;
     fin.out = b.xres; fin.ldo = Dp; fin.out_dtype = DN_F32;
+    const float* gb0 = b.gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;  // layer 0's attention norm rides on it
+    if (fuse_norm_enabled(Dp, dtype)) set_norm(fin, b.tf.xn, Dp, D, dtype, nullptr, gb0, m->n_cond);
+    else if (split) set_split_norm(fin, b.tf, Dp, D, dtype, nullptr, gb0, m->n_cond);
     DN_TRY(run_wavenet(m->wn, dtype, b.h0, M, T, b.gb, m->n_cond, b.wv, fin, s));
   }
-  const TransformerW& w = m->tf;
+  // the transformer of the unconditional model with the cross-attention block between attention and feed-forward: every RMSNorm
+  // split between the contraction that produces its input and the one that consumes it, K-blocked operands where a tile gains
   const float* gb_tf = b.gb + (size_t)c.wn_stacks * c.wn_layers * 2 * Dp;
-  auto norm = [&](int l, int j) -> int {  // j = 0 attention, 1 cross-attention, 2 feed-forward
-    return dn_rmsnorm(b.xres, Dp, b.xn, Dp, dtype, M, D, T, nullptr, gb_tf + (size_t)(3 * l + j) * 2 * Dp, m->n_cond, Dp, s);
-  };
-  for (int l = 0; l < w.depth; ++l) {
-    DN_TRY(norm(l, 0));
-    {
-      DnGemmParams p = gemm_base(dtype, M, 3 * hd, Dp, T);
-      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.qkv_W, (size_t)l * padn(3 * hd) * Dp, es);
-      p.out = b.qkv; p.ldo = 3 * hd; p.out_dtype = side_dtype(dtype);
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    DN_TRY(attn_call(dtype, b.qkv, 3 * hd, eoff(b.qkv, hd, es), eoff(b.qkv, 2 * hd, es), 3 * hd, b.ao, hd, B, T, 0, c.heads, c.dim_head, lengths, s));
-    {
-      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
-      p.terms[0].A = b.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(w.out_W, (size_t)l * Dn * hd, es);
-      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    // cross-attention to the resampled prompt latents, no mask (:694-700)
-    DN_TRY(norm(l, 1));
-    {
-      DnGemmParams p = gemm_base(dtype, M, hd, Dp, T);
-      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(m->cq_W, (size_t)l * padn(hd) * Dp, es);
-      p.out = b.cq; p.ldo = hd; p.out_dtype = side_dtype(dtype);
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    {
-      const void* kv = eoff(b.ckv, (size_t)l * B * ml * 2 * hd, es);
-      DN_TRY(attn_call(dtype, b.cq, hd, kv, eoff(kv, hd, es), 2 * hd, b.ao, hd, B, T, ml, c.heads, c.dim_head, nullptr, s));
-    }
-    {
-      DnGemmParams p = gemm_base(dtype, M, Dp, hd, T);
-      p.terms[0].A = b.ao; p.terms[0].lda = hd; p.terms[0].W = eoff(m->cout_W, (size_t)l * Dn * hd, es);
-      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    DN_TRY(norm(l, 2));
-    {
-      DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);
-      p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = eoff(w.ffin_W, (size_t)l * 2 * ip * Dp, es);
-      p.bias = w.ffin_b + (size_t)l * 2 * ip; p.epilogue = DN_EPI_GEGLU; p.out = b.gg; p.ldo = ip;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    {
-      DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
-      p.n_terms = 3;
-      for (int j = 0; j < 3; ++j) {
-        p.terms[j].A = b.gg; p.terms[j].lda = ip; p.terms[j].shift = 2 - j;
-        p.terms[j].W = eoff(w.ffconv_W, ((size_t)l * 3 + j) * in_n * ip, es);
-      }
-      p.bias = w.ffconv_b + (size_t)l * ip; p.out = b.fc; p.ldo = ip;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-    {
-      DnGemmParams p = gemm_base(dtype, M, Dp, ip, T);
-      p.terms[0].A = b.fc; p.terms[0].lda = ip; p.terms[0].W = eoff(w.ffout_W, (size_t)l * Dn * ip, es);
-      p.bias = w.ffout_b + (size_t)l * Dp;
-      p.epilogue = DN_EPI_RESADD; p.res = b.xres; p.ldr = Dp; p.out = b.xres; p.ldo = Dp; p.out_dtype = DN_F32;
-      DN_TRY(dn_conv_gemm(&p, s));
-    }
-  }
-  DN_TRY(dn_rmsnorm(b.xres, Dp, b.xn, Dp, dtype, M, D, T, w.pred_gamma, nullptr, 0, 0, s));
-  {
-    DnGemmParams p = gemm_base(dtype, M, Dp, Dp, T);
-    p.terms[0].A = b.xn; p.terms[0].lda = Dp; p.terms[0].W = w.pred_W;
-    p.out = b.tp; p.ldo = Dp;
-    DN_TRY(dn_conv_gemm(&p, s));
-  }
+  const CrossAttn cx = {m->cq_W, m->cout_W, b.ckv, ml, b.cq};
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, gb_tf, m->n_cond, split ? b.rb : nullptr, rb_ld, b.tf, b.tp, Dp, dtype, xn_ready, s, &cx));
   DnGemmParams p = gemm_base(dtype, M, z, Dp, T);
   p.terms[0].A = b.tp; p.terms[0].lda = Dp; p.terms[0].W = m->final_W;
   p.bias = m->final_b; p.out = eps_out; p.ldo = z; p.out_dtype = DN_F32;
@@ -1233,7 +1225,7 @@ extern "C" int dn_vae_decode(DnVae* m, const float* latent, const int32_t* lengt
   }
   float* rec = dense_recon ? recon : b.recon;
   const int rec_ld = dense_recon ? D : Dp;
-  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, nullptr, b.tf, rec, rec_ld, DN_F32, false, s));
+  DN_TRY(run_transformer(m->tf, dtype, b.xres, B, T, lengths, nullptr, 0, nullptr, 0, b.tf, rec, rec_ld, DN_F32, false, s));
   if (recon && !dense_recon) DN_TRY(dn_convert_rows(rec, DN_F32, Dp, recon, DN_F32, D, M, D, s));
   if (!want_lm) return DN_OK;
   DN_TRY(dn_convert_rows(rec, DN_F32, rec_ld, b.pred_act, dtype, Dp, M, D, s));

@@ -4,6 +4,7 @@
 
 namespace dn {
 LaunchProfile g_prof;
+thread_local bool g_gemm_twin = false;
 }
 
 extern "C" int dn_conv_gemm_kblocked_ok(const DnGemmParams* pp) {

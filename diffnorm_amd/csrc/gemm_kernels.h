@@ -2494,7 +2494,7 @@ static inline int choose_tile(const DnGemmParams& p) {
   for (int i = 0; i < p.n_terms; ++i) kblocked = kblocked || p.terms[i].layout != 0;
   const bool mid2_ok = bf && p.epilogue != DN_EPI_RESADD && p.epilogue != DN_EPI_POSEMB;  // tile 9: 256 x 128, two workgroups per CU (no residual prefetch / split-norm producer on it)
   if (kblocked) return bf && force == 8 && p.epilogue == DN_EPI_BIAS ? 8 : mid2_ok && force == 9 ? 9 : bf && (force == 0 || force == 3) ? 3 : -1;  // the other tiles that take them (8: the 192-column form)
-  if (bf && force == 8 && p.epilogue == DN_EPI_BIAS) return 8;
+  if (bf && force == 8 && (p.epilogue == DN_EPI_BIAS || (p.epilogue == DN_EPI_RESADD && !(p.norm_out && p.norm_split)))) return 8;
   if (mid2_ok && force == 9) return 9;
   if (p.dtype == DN_BF16 && (force == 6 || force == 7)) return force;
   if (force >= 1 && force <= 3) return force;
@@ -2527,6 +2527,19 @@ static inline int choose_tile(const DnGemmParams& p) {
   const bool long_taps = heur != 4 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && (long)p.K * p.n_terms >= 1024 && terms_are_taps(p);
   const double s_big = 1.00 * fill(tiles_big, 1), s_mid = (long_taps ? 0.78 : 0.90) * fill(tiles_mid, 1),
                s_small = (long_taps ? 0.72 : 0.92) * fill(tiles_small, 2);
+  // The 256 x 192 form of the 256 x 256 kernel (tile 8; BIAS and RESADD epilogues, 2-byte operands, not the taps of a long conv: those
+  // share staged rows on the 256-wide form only): widths that are whole multiples of 192 but leave 256-wide tiles a ragged round --
+  // the VAE's N = 768 contractions at M = 12288 are 144 tiles of 256 x 256 (0.56 of one round) but 192 of 256 x 192 (0.75 of one,
+  // each 3/4 of the work).  Scored only for a launch that has the chip to itself (see g_gemm_twin; option tile_192 = 0: never) and
+  // only from K = 768 up: the narrower tile saves MFMAs and weight-panel reads, not the activation panel's LDS traffic nor the
+  // prologue and epilogue a short K loop is made of (measured in the training updates: N = 768, K = 768-4096: 75.5 -> 66.2 us;
+  // N = 1408, K = 512 at M = 8192, 192 -> 256 workgroups: 77.2 -> 78.8 us).
+  if (bf && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_RESADD) && !long_taps && !g_gemm_twin && !(p.norm_out && p.norm_split) &&
+      (long)p.K * p.n_terms >= 768 && option_or(OPT_TILE_192, 1) != 0) {
+    const int c192 = (np + 191) / 192, c256 = (np + 255) / 256;
+    const double s_192 = 0.90 * fill(mt256 * c192 * p.groups, 1) * (256.0 * c256) / (192.0 * c192);
+    if (s_big >= s_mid && s_big >= s_small && s_192 > s_big) return 8;  // (against the same kernel's 256-wide form only: a pure fill gain)
+  }
   if (s_big >= s_mid && s_big >= s_small) return 3;
   return s_mid > s_small ? 2 : 1;
 }
@@ -2577,8 +2590,8 @@ static int launch(const DnGemmParams& p0, hipStream_t s) {
   if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_GEGLU) && IsHalf<E>::value) {
     if (tile == 4) return launch_fat<E, EPI, 11>(p, s);
   }
-  if constexpr (EPI == DN_EPI_BIAS && IsHalf<E>::value) {
-    if (tile == 8) return launch_big<E, EPI, 192>(p, s);  // 256 x 192: widths that are whole multiples of 192 but ragged on 256 (forced-only)
+  if constexpr ((EPI == DN_EPI_BIAS || EPI == DN_EPI_RESADD) && IsHalf<E>::value) {
+    if (tile == 8) return launch_big<E, EPI, 192>(p, s);  // 256 x 192: widths that are whole multiples of 192 but ragged on 256
   }
   if constexpr (IsHalf<E>::value && EPI != DN_EPI_RESADD && EPI != DN_EPI_POSEMB) {
     if (tile == 9) return launch_mid2<E, EPI>(p, s);

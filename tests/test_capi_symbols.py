@@ -160,6 +160,13 @@ def test_tile_choice_is_host_logic(lib, monkeypatch):
     assert tile(params(M, 1408, 512, epi=_lib.EPI_GEGLU)) == 3                                 # GEGLU projection (2816 packed columns)
     assert tile(params(M, 1536, 512)) == 1                                                     # q/kv: two 128 x 128 workgroups per CU
     assert tile(params(M, 2048, 2048, n_terms=3)) == 3                                         # the VAE's FFN conv (not a multiple of 352)
+    # a lone launch whose 256 x 256 tiles leave most of a round idle goes to the 256 x 192 form when the width divides (training)
+    assert tile(params(24 * 512, 768, 768)) == 8 and tile(params(24 * 512, 768, 2048, epi=_lib.EPI_RESADD)) == 8
+    _lib.set_option("tile_192", 0)
+    try:
+        assert tile(params(24 * 512, 768, 768)) == 3
+    finally:
+        _lib.set_option("tile_192", None)
     # K-blocked operands: taken by the two 256-row tiles; a forced tile that cannot take them is an error (-1)
     assert tile(params(M, 1536, 512, layout=3)) == 3
     assert tile(params(M, 1408, 1408, n_terms=3, layout=3)) == 4

@@ -5,6 +5,8 @@ the engine-level golden tests (tests/test_hip_engine.py, test_hip_fullsize.py, t
 the operators are held (a) TIGHT to the oracle fed the same half-rounded operands (only fp32 summation order differs) and (b) to
 the fp32 oracle at the half rounding level, on every tile variant that takes 2-byte operands.
 """
+import ctypes as C
+
 import pytest
 import torch
 
@@ -79,6 +81,30 @@ def test_causal_conv_gemm_f16_every_tile(ops, tile, cin, cout, k, dil, B, T):
     outh = torch.full((B * T, N), float("nan"), device=DEV, dtype=torch.float16)
     ops_.conv_gemm(terms, outh, T, N, bias=bias, tile=4 if tile == 5 else tile, taps_inner=(tile == 5) if tile else None)
     assert torch.equal(outh.cpu(), out.cpu().to(torch.float16))  # the half store is the RNE rounding of the fp32 result
+
+
+@pytest.mark.parametrize("half", ["f16", "bf16"])
+@pytest.mark.parametrize("B,T,K,N", [(3, 200, 256, 384), (2, 515, 128, 768)])
+def test_residual_epilogue_on_the_256x192_tile(ops, half, B, T, K, N):
+    """RESADD (fp32 residual stream, in place) on the 256 x 192 form of the 256 x 256 kernel -- the tile a lone launch of an N = 768
+    contraction is scored onto (training: 144 -> 192 workgroups): bit-identical to the 128 x 128 tile, ragged M."""
+    ops_, packing, _lib = ops
+    code, tdt = (_lib.DN_F16, torch.float16) if half == "f16" else (_lib.DN_BF16, torch.bfloat16)
+    M = B * T
+    x, w, b = seeded((M, K), 21), seeded((N, K), 22, K ** -0.5), seeded((N,), 23, 0.1)
+    res = seeded((M, N), 24)
+    xa, W = x.to(DEV, tdt).contiguous(), packing._mat(w, code).to(DEV)
+    outs = []
+    for tile in (8, 1):
+        stream = res.to(DEV).clone()
+        ops_.conv_gemm([(xa, W, 0)], stream, T, N, bias=packing._vec(b, W.shape[0]).to(DEV), epilogue=_lib.EPI_RESADD, res=stream, tile=tile)
+        outs.append(stream.cpu())
+        p = _lib.GemmParams()
+        p.M, p.N, p.K, p.T, p.groups, p.n_terms, p.epilogue, p.dtype, p.pad_ = M, N, K, T, 1, 1, _lib.EPI_RESADD, code, tile << 16
+        assert _lib.load().dn_conv_gemm_tile(C.byref(p)) == tile
+    assert torch.equal(outs[0], outs[1])
+    want = res + x.to(tdt).float() @ w.to(tdt).float().t() + b
+    assert maxerr(outs[0], want) < 2e-4
 
 
 def test_f16_wavenet_block_geglu_and_split_norm_chain(ops):
