@@ -44,7 +44,8 @@ class GemmParams(C.Structure):
                 ("norm_gb_half", C.c_int32), ("out_layout", C.c_int32),
                 ("norm_split", C.c_int32), ("norm_ssq_ld", C.c_int32), ("norm_ssq", C.c_void_p),
                 ("row_ssq", C.c_void_p), ("row_ssq_ld", C.c_int32), ("row_ssq_parts", C.c_int32),
-                ("row_D", C.c_float), ("row_bias_ld", C.c_int32), ("row_bias", C.c_void_p)]
+                ("row_D", C.c_float), ("row_bias_ld", C.c_int32), ("row_bias", C.c_void_p),
+                ("pre_out", C.c_void_p), ("pre_ld", C.c_int32), ("pre_pad_", C.c_int32)]
 
 
 class AdamParams(C.Structure):

@@ -89,6 +89,10 @@ extern "C" int dn_conv_gemm(const DnGemmParams* pp, void* stream) {
     DN_CHECK_ARG(p.row_ssq_parts >= 1 && p.row_ssq_ld >= p.row_ssq_parts && p.row_D > 0.f, "dn_conv_gemm: bad row_ssq_parts / row_ssq_ld / row_D");
     DN_CHECK_ARG(p.row_bias_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p.row_bias) & 15) == 0, "dn_conv_gemm: row_bias must be 16-byte aligned, stride a multiple of 4");
   }
+  if (p.pre_out)
+    DN_CHECK_ARG(p.epilogue == DN_EPI_GEGLU && p.groups == 1 && p.dtype != DN_BF16X3 && p.out_dtype == p.dtype && p.pre_ld >= 2 * p.N && p.pre_ld % 8 == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.pre_out) & 15) == 0,
+                 "dn_conv_gemm: pre_out (the kept pre-activation) needs the GEGLU epilogue, one group, out_dtype == dtype, pre_ld >= 2 N and a multiple of 8");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.dtype == DN_BF16X3) return dn::gemm_dispatch_x3(p, s);
   if (p.dtype == DN_F16) return dn::gemm_dispatch_f16(p, s);

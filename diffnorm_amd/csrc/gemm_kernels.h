@@ -305,9 +305,13 @@ __device__ __forceinline__ void wave_epilogue_wide(const DnGemmParams& p, const 
         for (int i = 0; i < 8; ++i) { v[i] = __fadd_rn(__fmul_rn(v[i], sm), rv[i]); gt[i] = __fadd_rn(__fmul_rn(gt[i], sm), rg[i]); }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = gelu_erf(gt[i] + bg[i]) * (v[i] + bv[i]);
+      for (int i = 0; i < 8; ++i) { v[i] += bv[i]; gt[i] += bg[i]; o[i] = gelu_erf(gt[i]) * v[i]; }
       // K-blocked output ([N/32][M][32]): the 8 columns stay inside one 32-column block
       store8_h16<H16>(out, out_off(p, m, n), o);
+      if (p.pre_out) {  // training: the pre-activation, packed columns, for the backward pass
+        store8_h16<H16>(p.pre_out, (int64_t)m * p.pre_ld + np, v);
+        store8_h16<H16>(p.pre_out, (int64_t)m * p.pre_ld + np + 8, gt);
+      }
     }
   } else {
     const int c8 = (lane & 7) * 8;
@@ -400,9 +404,14 @@ __device__ __forceinline__ void wave_epilogue_impl(const DnGemmParams& p, const 
         gt = make_float4(__fadd_rn(__fmul_rn(gt.x, sm), rg.x), __fadd_rn(__fmul_rn(gt.y, sm), rg.y), __fadd_rn(__fmul_rn(gt.z, sm), rg.z),
                          __fadd_rn(__fmul_rn(gt.w, sm), rg.w));
       }
-      store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(out, out_off(p, m, n),
-                      gelu_erf(gt.x + bg.x) * (v.x + bv.x), gelu_erf(gt.y + bg.y) * (v.y + bv.y),
-                      gelu_erf(gt.z + bg.z) * (v.z + bv.z), gelu_erf(gt.w + bg.w) * (v.w + bv.w));
+      v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+      gt = make_float4(gt.x + bg.x, gt.y + bg.y, gt.z + bg.z, gt.w + bg.w);
+      store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(out, out_off(p, m, n), gelu_erf(gt.x) * v.x, gelu_erf(gt.y) * v.y, gelu_erf(gt.z) * v.z,
+                                                 gelu_erf(gt.w) * v.w);
+      if (p.pre_out) {  // training: the pre-activation, packed columns, for the backward pass
+        store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(p.pre_out, (int64_t)m * p.pre_ld + np, v.x, v.y, v.z, v.w);
+        store4t<(OUT_BF == 1 && H16) ? 3 : OUT_BF>(p.pre_out, (int64_t)m * p.pre_ld + np + 8, gt.x, gt.y, gt.z, gt.w);
+      }
     }
   } else {
     const int c4 = (lane & 15) * 4;

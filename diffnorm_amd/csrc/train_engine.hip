@@ -658,13 +658,19 @@ int tf_forward(const Ctx& c, const TfP& w, const int32_t* lengths, const TfSave&
       DN_TRY(dn_conv_gemm(&p, c.s));
     }
     DN_TRY(dn_rmsnorm(xmid, Dp, xn2, Dp, dtype, M, D, T, ada ? nullptr : c.P(w.g2(l)), gb2, gb_ld, Dp, c.s));
-    {  // Linear(D -> 2*inner), packed [8 value ; 8 gate] columns, pre-activation kept (:899)
+    if (option_or(OPT_FUSED_GEGLU, 1) != 0) {  // Linear(D -> 2*inner) + GEGLU in the contraction's epilogue as inference runs it (:899,881-884),
+      DnGemmParams p = gemm_base(dtype, M, ip, Dp, T);  // which also keeps the pre-activation (packed [8 value ; 8 gate] columns) for the backward
+      p.terms[0].A = xn2; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.ffin_W(l));
+      p.bias = c.P(w.ffin_b(l)); p.epilogue = DN_EPI_GEGLU; p.out = gg; p.ldo = ip;
+      p.pre_out = pre; p.pre_ld = 2 * ip;
+      DN_TRY(dn_conv_gemm(&p, c.s));
+    } else {  // option fused_geglu = 0: the projection, then a pass over its output (A/B timing)
       DnGemmParams p = gemm_base(dtype, M, 2 * ip, Dp, T);
       p.terms[0].A = xn2; p.terms[0].lda = Dp; p.terms[0].W = c.W(w.ffin_W(l));
       p.bias = c.P(w.ffin_b(l)); p.out = pre; p.ldo = 2 * ip;
       DN_TRY(dn_conv_gemm(&p, c.s));
+      DN_TRY(dn_geglu_forward(pre, gg, dtype, M, ip, c.s));
     }
-    DN_TRY(dn_geglu_forward(pre, gg, dtype, M, ip, c.s));
     {  // CausalConv1d(inner, inner, 3) (:894)
       DnGemmParams p = gemm_base(dtype, M, ip, ip, T);
       p.n_terms = 3;

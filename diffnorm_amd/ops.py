@@ -37,7 +37,7 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
               norm_ssq: Optional[torch.Tensor] = None, row_ssq: Optional[torch.Tensor] = None, row_D: int = 0,
               row_bias: Optional[torch.Tensor] = None, row_bias_shared: bool = False, a_kblocked: bool = False,
               w_kblocked: bool = False, out_kblocked: bool = False, band: int = 0, x3: bool = False,
-              shared_rows: Optional[bool] = None):
+              shared_rows: Optional[bool] = None, pre_out: Optional[torch.Tensor] = None):
     """out = epilogue(sum_terms shift(A) @ W^T).
 
     terms: (A [G?,M,lda], W [G?,Np,K], shift).  With groups > 1 the leading dim of A (unless
@@ -102,6 +102,9 @@ def conv_gemm(terms: Sequence[Tuple[torch.Tensor, torch.Tensor, int]], out: torc
             assert row_bias.dtype == torch.float32
             p.row_bias = row_bias.data_ptr()
             p.row_bias_ld = 0 if row_bias_shared else row_bias.stride(0)
+    if pre_out is not None:  # GEGLU: the pre-activation (packed columns) kept for the backward pass
+        assert pre_out.is_contiguous() and pre_out.dtype == out.dtype
+        p.pre_out, p.pre_ld = pre_out.data_ptr(), pre_out.shape[-1]
     p.pad_ = int(os.environ.get("DN_DEBUG_FLAGS", "0")) | (tile << 16) | (0 if taps_inner is None else (1 << 22) if taps_inner else (1 << 23)) | ((band & 0x7f) << 24) | ((1 << 21) if shared_rows is False else 0)  # ablation switches (tools/gemm_bench.py) | forced tile / K order / no shared staging of the taps' rows (tests; None = the library's default)
     _lib.check(lib.dn_conv_gemm(C.byref(p), _stream()), "dn_conv_gemm")
     return out

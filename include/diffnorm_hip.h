@@ -154,6 +154,10 @@ typedef struct {
   float row_D;             /* the norm's D (not padded)                                              */
   int32_t row_bias_ld;     /* elements between batch rows of row_bias (0 = one row for the batch)    */
   const float* row_bias;   /* [Bc, >= N (packed columns for GEGLU)] fp32 or NULL                     */
+  /* GEGLU only (training forward, groups == 1): when pre_out != NULL the epilogue also stores the pre-activation it gates --
+   * [M, pre_ld] in out_dtype, packed columns (what the BIAS epilogue would have written) -- for the backward pass.          */
+  void* pre_out;
+  int32_t pre_ld, pre_pad_;
 } DnGemmParams;
 
 int dn_conv_gemm(const DnGemmParams* p, void* stream);

@@ -107,6 +107,38 @@ def test_residual_epilogue_on_the_256x192_tile(ops, half, B, T, K, N):
     assert maxerr(outs[0], want) < 2e-4
 
 
+@pytest.mark.parametrize("half", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_geglu_epilogue_keeps_the_pre_activation(ops, half, tile):
+    """Training forward: the GEGLU epilogue with pre_out also stores the projection it gates (packed [8 value ; 8 gate] columns, what
+    the BIAS epilogue writes) -- bit-identical to the two-pass form's pre-activation, and the gated output unchanged by the extra store."""
+    ops_, packing, _lib = ops
+    code, tdt = {"f16": (_lib.DN_F16, torch.float16), "bf16": (_lib.DN_BF16, torch.bfloat16), "f32": (_lib.DN_F32, torch.float32)}[half]
+    B, T, D, inner = 3, 171, 128, 85
+    M, ip = B * T, padk(inner)
+    x = seeded((M, D), 31).to(DEV, tdt).contiguous()
+    w_in, b_in = seeded((2 * inner, D), 32, D ** -0.5), seeded((2 * inner,), 33, 0.1)
+    rows = packing._geglu_rows(inner)
+    keep = rows >= 0
+    wp, bp = torch.zeros(2 * ip, D), torch.zeros(2 * ip)
+    wp[keep] = w_in[rows[keep]]
+    bp[keep] = b_in[rows[keep]]
+    W, bias = wp.to(DEV, tdt).contiguous(), bp.to(DEV)
+    pre_two = torch.empty(M, 2 * ip, device=DEV, dtype=tdt)
+    ops_.conv_gemm([(x, W, 0)], pre_two, T, 2 * ip, bias=bias, tile=tile)
+    gg_plain = torch.empty(M, ip, device=DEV, dtype=tdt)
+    ops_.conv_gemm([(x, W, 0)], gg_plain, T, ip, bias=bias, epilogue=_lib.EPI_GEGLU, tile=tile)
+    gg, pre = torch.empty_like(gg_plain), torch.full_like(pre_two, float("nan"))
+    ops_.conv_gemm([(x, W, 0)], gg, T, ip, bias=bias, epilogue=_lib.EPI_GEGLU, tile=tile, pre_out=pre)
+    assert torch.equal(gg, gg_plain)
+    if tile:  # (chosen by shape, the two-pass projection may land on another tile: another summation order)
+        assert torch.equal(pre, pre_two)
+    assert maxerr(pre.float().cpu(), pre_two.float().cpu()) < (1e-5 if half == "f32" else 3e-2 if half == "bf16" else 4e-3)
+    h = x.float().cpu() @ w_in.to(tdt).float().t() + b_in
+    want = torch.nn.functional.gelu(h[:, inner:]) * h[:, :inner]
+    assert maxerr(gg.float().cpu()[:, :inner], want) < (1e-4 if half == "f32" else 4e-2 if half == "bf16" else 6e-3)
+
+
 def test_f16_wavenet_block_geglu_and_split_norm_chain(ops):
     """The epilogues that read or write half tensors: FiLM . tanh . sigmoid + half residual, GEGLU (8-column wide stores), the
     split RMSNorm's producer (row * gamma as half + sums of squares) and consumer (row factor + beta . W^T)."""
