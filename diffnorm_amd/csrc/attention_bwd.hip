@@ -335,7 +335,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 
 // ------------------------------------------------------------------------------------------------------ dQ
 template <typename E, int DHP, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
+// (two workgroups per CU asked for where the kernel fits 256 registers without spilling: left alone the compiler spent 260 on the
+// 96-dim head -- the VAE's -- which made that variant a one-wave-per-SIMD kernel; 236 when told)
+__global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 2 : 1) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using TP = TilePair<E, DHP>;
   constexpr int ES = Elem<E>::bytes;
