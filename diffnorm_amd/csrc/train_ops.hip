@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const void* __restrict__
 // One wave per row, D <= 1024 (the row lives in registers).  A workgroup walks `rows_per_block` consecutive rows of ONE
 // sample and keeps the gamma / (gamma, beta) partial sums of its columns in registers; partial[blk][...] is reduced by
 // colsum_final_kernel in a fixed order.
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(256, 3) void rmsnorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dy, int lddy,
                                                           int dy_dtype, int B, int T, int D, const float* __restrict__ gamma,
                                                           const float* __restrict__ gb, int gb_ld, int gb_half,
                                                           const float* __restrict__ dres, float* __restrict__ dx, void* __restrict__ dx_act,
@@ -159,32 +159,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     }
     accg[i] = accb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // A wave's next row (x, dy and the residual gradient) is requested before the current one is reduced: with one row in flight per
-  // wave the kernel waited out two memory round trips per row (the row, then dres) at 3 waves per SIMD -- 3.1 TB/s.
-  float4 xn[4], dn[4], rn[4];
-  auto fetch = [&](int t) {
-    const int64_t row = (int64_t)b * T + t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      xn[i] = dn[i] = rn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < D && t < t1) {
-        xn[i] = *reinterpret_cast<const float4*>(x + row * ldx + c);
-        dn[i] = load4(dy, row * lddy + c, dy_dtype);
-        if (dres) rn[i] = *reinterpret_cast<const float4*>(dres + row * ldx + c);
-      }
-    }
-  };
-  if (t0 + wave < t1) fetch(t0 + wave);
+  // (the residual gradient of a row is requested with the row itself, not after the row's reductions: one memory round trip per row
+  // instead of two.  Keeping a second row in flight per wave cost 100 registers and a workgroup per CU: 47 -> 58 us.)
   for (int t = t0 + wave; t < t1; t += 4) {
     const int64_t row = (int64_t)b * T + t;
     float4 xv[4], dv[4], rv[4];
     float ss = 0.f, dot = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i];
+      const int c = (i * 64 + lane) * 4;
+      xv[i] = dv[i] = rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < D) {
+        xv[i] = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        dv[i] = load4(dy, row * lddy + c, dy_dtype);
+        if (dres) rv[i] = *reinterpret_cast<const float4*>(dres + row * ldx + c);
+      }
     }
-    fetch(t + 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
