@@ -400,11 +400,14 @@ def refine_leg(args, dev, stream):
     with torch.cuda.stream(stream):
         enc_eng.forward(fb, fl)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            eo, _ = enc_eng.forward(fb, fl)
-        torch.cuda.synchronize()
-        enc_ms = (time.perf_counter() - t0) / 5 * 1e3
+        passes = []
+        for _ in range(3):  # the median of three groups of five passes (a single stall of the box once put 15 ms on a 1.2 ms pass)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eo, _ = enc_eng.forward(fb, fl)
+            torch.cuda.synchronize()
+            passes.append((time.perf_counter() - t0) / 5 * 1e3)
+        enc_ms = sorted(passes)[1]
     assert eo.shape == (B, S, 512) and torch.isfinite(eo).all().item()
     del enc_eng
     assert int(st.output_tokens.ne(3).sum()) == B * T  # every position decided after the last iteration

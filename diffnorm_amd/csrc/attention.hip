@@ -43,8 +43,16 @@ __device__ __forceinline__ int lds_off<F32>(int row, int byte) {
 constexpr int KV_TILE = 64;
 constexpr float NEG_BIG = -3.0e38f;
 
-template <typename E, int DHP, bool DROP>
-__global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
+// QT: 16-query tiles per wave.  2 = four waves of 32 queries: a workgroup's waves sit on different SIMDs and two workgroups share a CU
+// by their 64 KiB of LDS, i.e. two waves per SIMD at ~240 registers (one at 96 / 128-dim heads: 320-380 registers).  1 = eight waves
+// of 16 queries: the same 128 queries and the same LDS per workgroup, half the accumulators and Q fragments per wave (106-122
+// registers up to 64 dims, 150-161 above), so a CU holds FOUR waves per SIMD (two above 64 dims) -- more waves to cover the
+// QK^T -> softmax -> PV dependency chain of each, at twice the K / V fragment reads per MFMA.  Bit-identical results (every query
+// sees the same key tiles in the same order through the same MFMA shapes).  The 2-byte modes run QT = 1 (option attn_waves8 = 0:
+// QT = 2; measured in the two-stream chain at [32,512], f16: 181.7 -> 183.5 steps/s, three alternating runs).
+template <typename E, int DHP, bool DROP, int QT = 2>
+__global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? (DHP <= 64 ? 4 : 2) : 1) void attn_kernel(const DnAttnParams p) {
+  constexpr int NT = 128 / (16 * QT) * 64;  // threads
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (std::is_same<E, F16>::value) f16_saturate();
   constexpr int ES = Elem<E>::bytes;
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   else dn_xcd_block_map(qblk, h, b);
   const int T = p.T, dh = p.dim_head;
   const int Tk = p.Tk > 0 ? p.Tk : T;  // cross-attention: the keys are another sequence of Tk rows per batch element
-  const int q0 = qblk * 128 + wave * 32;
+  const int q0 = qblk * 128 + wave * (16 * QT);
   const int dhb = dh * ES;  // valid bytes per head row
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
@@ -71,9 +79,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   const char* vp = reinterpret_cast<const char*>(p.v) + ((int64_t)b * Tk * p.ldv + h * dh) * ES;
 
   // Q fragments (B operand): row = query, chunk = ks*4 + fg
-  uint4 qf[2][KS_D];
+  uint4 qf[QT][KS_D];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     int q = q0 + qt * 16 + fr;
     q = q < T ? q : T - 1;
 #pragma unroll
@@ -83,14 +91,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     }
   }
 
-  f32x4 acc_o[DT][2];
+  f32x4 acc_o[DT][QT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc_o[i][0] = acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) acc_o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m_run[qt] = NEG_BIG; l_run[qt] = 0.f; }
   // bf16: the softmax denominators ride on the matrix pipe -- one extra output tile whose V^T fragment is all ones makes
   // acc_l[qt][r] = sum_k P[k][query] (the same bf16-rounded P the numerator uses), replacing 32 v_add + 2 cross-lane
   // reductions per key tile by 4 MFMAs on a pipe that has slack here (the loop is VALU-bound on the exponentials).
-  f32x4 acc_l[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc_l[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) acc_l[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr bool H16 = std::is_same<E, F16>::value;  // IEEE-half operands: same tiles and swizzles as bf16, P in [0, 1] rounds to 11 bits
   constexpr uint32_t ONE2 = H16 ? 0x3c003c00u : 0x3f803f80u;  // (1.0, 1.0) in the operand type
   const uint4 ones_frag = make_uint4(ONE2, ONE2, ONE2, ONE2);
@@ -104,13 +118,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   }
 
   // attention dropout (training): thr = p * 2^32, kept probabilities scaled by 1 / (1 - p); the per-lane query rows' hashes are hoisted
-  uint32_t drop_thr = 0, drop_row[2] = {0, 0};
+  uint32_t drop_thr = 0, drop_row[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) drop_row[qt] = 0;
   float drop_inv = 1.f;
   if constexpr (DROP) {
     drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
     drop_inv = 1.0f / (1.0f - p.dropout_p);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
       drop_row[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fr)), p.seed_lo);
   }
   auto dropped = [&](float pv, int qt, int key) -> float {
@@ -123,13 +139,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   // waiting for its successor's loads.  Tile t travels in register set t % 2: requested at the top of iteration t-2,
   // written to LDS buffer t % 2 at the end of iteration t-1 (that buffer was last read in iteration t-2; one barrier
   // per tile).  The loop is unrolled over two tiles so the set index is a compile-time constant.
-  constexpr int NPT = (KV_TILE * NCH + 255) / 256;  // 16-byte chunks per thread per tensor per tile
+  constexpr int NPT = (KV_TILE * NCH + NT - 1) / NT;  // 16-byte chunks per thread per tensor per tile
   uint4 kreg[2][NPT], vreg[2][NPT];
   auto issue_loads = [&](auto set_c, int kv0) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / NCH, ch = idx - row * NCH;
       const int key = kv0 + row;
       kreg[S][i] = vreg[S][i] = make_uint4(0, 0, 0, 0);
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / NCH, ch = idx - row * NCH;
       if (idx < KV_TILE * NCH) {
         const int off = buf * TILE_LDS + lds_off<E>(row, ch * 16);
@@ -178,16 +194,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     const char* vt_lds = v_lds + buf * TILE_LDS;
 
     // ---- S^T = K . Q^T : acc_s[kt][qt][r] = S[query qt*16+fr][key kt*16 + 4*fg + r]
-    f32x4 acc_s[4][2];
+    f32x4 acc_s[4][QT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc_s[kt][0] = acc_s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const uint4 kf = *reinterpret_cast<const uint4*>(kt_lds + k_base[ks] + kt * 16 * ROWB);
-        mma_kstep<E>(acc_s[kt][0], kf, qf[0][ks]);
-        mma_kstep<E>(acc_s[kt][1], kf, qf[1][ks]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<E>(acc_s[kt][qt], kf, qf[qt][ks]);
       }
     }
 
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     auto softmax_tile = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         float mx = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -248,9 +266,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
     if constexpr (ES == 2) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {  // 32-key k-steps = accumulator tiles (2kk, 2kk+1)
-        uint4 pf[2], pfd[2];  // pf: the probabilities (denominator); pfd: after dropout (numerator)
+        uint4 pf[QT], pfd[QT];  // pf: the probabilities (denominator); pfd: after dropout (numerator)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
           pf[qt].x = pack_h2<H16>(acc_s[2 * kk][qt][0], acc_s[2 * kk][qt][1]);
           pf[qt].y = pack_h2<H16>(acc_s[2 * kk][qt][2], acc_s[2 * kk][qt][3]);
           pf[qt].z = pack_h2<H16>(acc_s[2 * kk + 1][qt][0], acc_s[2 * kk + 1][qt][1]);
@@ -277,11 +295,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
           uint4 vf;
           const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
           vf.x = lo2.x; vf.y = lo2.y; vf.z = hi2.x; vf.w = hi2.y;
-          mma_kstep<E>(acc_o[dt][0], vf, pfd[0]);
-          mma_kstep<E>(acc_o[dt][1], vf, pfd[1]);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) mma_kstep<E>(acc_o[dt][qt], vf, pfd[qt]);
         }
-        mma_kstep<E>(acc_l[0], ones_frag, pf[0]);
-        mma_kstep<E>(acc_l[1], ones_frag, pf[1]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<E>(acc_l[qt], ones_frag, pf[qt]);
       }
     } else {
 #pragma unroll
@@ -289,12 +307,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;  // k-slot fg of MFMA (kt, r)
-          const float p0 = dropped(acc_s[kt][0][r], 0, kv0 + key), p1 = dropped(acc_s[kt][1][r], 1, kv0 + key);
+          float pq[QT];
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) pq[qt] = dropped(acc_s[kt][qt][r], qt, kv0 + key);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const float vv = *reinterpret_cast<const float*>(vt_lds + lds_off<E>(key, (dt * 16 + fr) * 4));
-            acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p0, acc_o[dt][0], 0, 0, 0);
-            acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p1, acc_o[dt][1], 0, 0, 0);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pq[qt], acc_o[dt][qt], 0, 0, 0);
           }
         }
     }
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const DnAttnParams p) {
   // ---- O = acc / l ; lane holds dims dt*16 + 4*fg + 0..3 of query qt*16 + fr
   char* op = reinterpret_cast<char*>(p.out);
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + fr;
     if (q >= T) continue;
     const float inv = 1.0f / (ES == 2 ? acc_l[qt][0] : l_run[qt]);
@@ -609,23 +629,31 @@ static int launch_attn_x3(const DnAttnParams& p, hipStream_t s) {
   return p.dropout_p > 0.f ? launch_attn_x3_v<DHP, true>(p, s) : launch_attn_x3_v<DHP, false>(p, s);
 }
 
-template <typename E, int DHP, bool DROP>
+template <typename E, int DHP, bool DROP, int QT = 2>
 static int launch_attn_v(const DnAttnParams& p, hipStream_t s) {
   constexpr int lds = 4 * KV_TILE * AttnGeom<E>::ROWB;  // K and V, double-buffered
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<E, DHP, DROP, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   dim3 grid((p.T + 127) / 128, p.heads, p.B);
-  hipLaunchKernelGGL((attn_kernel<E, DHP, DROP>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((attn_kernel<E, DHP, DROP, QT>), grid, dim3(128 / (16 * QT) * 64), lds, s, p);
   DN_CHECK_LAUNCH("dn_attention");
   return DN_OK;
 }
 
 template <typename E, int DHP>
 static int launch_attn(const DnAttnParams& p, hipStream_t s) {
+  if constexpr (Elem<E>::bytes == 2) {
+    if (option_or(OPT_ATTN_WAVES8, 1) != 0)
+      return p.dropout_p > 0.f ? launch_attn_v<E, DHP, true, 1>(p, s) : launch_attn_v<E, DHP, false, 1>(p, s);
+  }
   return p.dropout_p > 0.f ? launch_attn_v<E, DHP, true>(p, s) : launch_attn_v<E, DHP, false>(p, s);
+}
+template <int DHP>
+static int launch_attn_f16(const DnAttnParams& p, hipStream_t s) {  // inference mode: no dropout
+  return option_or(OPT_ATTN_WAVES8, 1) != 0 ? launch_attn_v<F16, DHP, false, 1>(p, s) : launch_attn_v<F16, DHP, false>(p, s);
 }
 
 }  // namespace dn
@@ -664,10 +692,10 @@ extern "C" int dn_attention(const DnAttnParams* pp, void* stream) {
     if (dh <= 128) return dn::launch_attn<dn::BF16, 128>(p, s);
   } else if (p.dtype == DN_F16) {
     DN_CHECK_ARG(p.dropout_p == 0.f && !p.lse, "dn_attention: DN_F16 is an inference mode (no dropout, no saved log-sum-exp)");
-    if (dh <= 32) return dn::launch_attn_v<dn::F16, 32, false>(p, s);
-    if (dh <= 64) return dn::launch_attn_v<dn::F16, 64, false>(p, s);
-    if (dh <= 96) return dn::launch_attn_v<dn::F16, 96, false>(p, s);
-    if (dh <= 128) return dn::launch_attn_v<dn::F16, 128, false>(p, s);
+    if (dh <= 32) return dn::launch_attn_f16<32>(p, s);
+    if (dh <= 64) return dn::launch_attn_f16<64>(p, s);
+    if (dh <= 96) return dn::launch_attn_f16<96>(p, s);
+    if (dh <= 128) return dn::launch_attn_f16<128>(p, s);
   } else {
     if (dh <= 16) return dn::launch_attn<dn::F32, 16>(p, s);
     if (dh <= 32) return dn::launch_attn<dn::F32, 32>(p, s);

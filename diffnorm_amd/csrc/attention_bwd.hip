@@ -68,18 +68,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const void* __restrict_
 
 // The tile machinery shared by both kernels: two row-major [BT][DHP] tiles (X, Y) of one (batch, head), double-buffered in
 // LDS, one register set of lead (tile t+1 is requested at the top of tile t and written to the other buffer at its end).
-template <typename E, int DHP>
+template <typename E, int DHP, int NT = 256>
 struct TilePair {
   static constexpr int ES = Elem<E>::bytes;
   static constexpr int ROWB = BwdGeom<E>::ROWB;
   static constexpr int NCH = DHP * ES / 16;
   static constexpr int TILE_LDS = BT * ROWB;
-  static constexpr int NPT = (BT * NCH + 255) / 256;
+  static constexpr int NPT = (BT * NCH + NT - 1) / NT;
   uint4 xr[NPT], yr[NPT];
   __device__ __forceinline__ void issue(const char* xp, int64_t ldxb, const char* yp, int64_t ldyb, int row0, int T, int dhb, int tid) {
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / NCH, ch = idx - row * NCH;
       const int r = row0 + row;
       xr[i] = yr[i] = make_uint4(0, 0, 0, 0);
@@ -92,7 +92,7 @@ struct TilePair {
   __device__ __forceinline__ void write(char* x_lds, char* y_lds, int buf, int tid) {
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / NCH, ch = idx - row * NCH;
       if (idx < BT * NCH) {
         const int off = buf * TILE_LDS + bwd_lds_off<E>(row, ch * 16);
@@ -129,10 +129,13 @@ struct AttnBwdArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------ dK, dV
-template <typename E, int DHP, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) {
+// WT: 16-key tiles per wave.  2 = four waves of 32 keys; 1 = eight waves of 16 keys (the same 128 keys and LDS per workgroup, half the
+// K / V fragments and accumulators per wave: twice the waves per SIMD -- see attn_kernel's QT; option attn_waves8).
+template <typename E, int DHP, bool DROP, int WT = 2>
+__global__ __launch_bounds__(128 / (16 * WT) * 64, WT == 1 ? (DHP <= 64 ? 4 : 2) : 1) void attn_bwd_dkv_kernel(const AttnBwdArgs p) {
+  constexpr int NT = 128 / (16 * WT) * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using TP = TilePair<E, DHP>;
+  using TP = TilePair<E, DHP, NT>;
   constexpr int ES = Elem<E>::bytes;
   constexpr int ROWB = BwdGeom<E>::ROWB;
   constexpr int KS_D = DHP * ES / 64;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
   int rblk, h, b;  // this workgroup's row block of (batch b, head h), XCD-aware order
   dn_xcd_block_map(rblk, h, b);
   const int T = p.T, dh = p.dim_head;
-  const int k0 = rblk * 128 + wave * 32;  // this wave's 32 keys
+  const int k0 = rblk * 128 + wave * (16 * WT);  // this wave's keys
   const int dhb = dh * ES;
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
@@ -174,9 +177,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
     drop_inv = 1.0f / (1.0f - p.dropout_p);
   }
   // K, V fragments (B operands): row = key
-  uint4 kf[2][KS_D], vf[2][KS_D];
+  uint4 kf[WT][KS_D], vf[WT][KS_D];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < WT; ++kt) {
     int key = k0 + kt * 16 + fr;
     key = key < T ? key : T - 1;
 #pragma unroll
@@ -187,9 +190,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
       vf[kt][ks] = ok ? *reinterpret_cast<const uint4*>(vp + (int64_t)key * p.ldv * ES + byte) : make_uint4(0, 0, 0, 0);
     }
   }
-  f32x4 acc_dk[DT][2], acc_dv[DT][2];  // [d tile][key tile]: lane holds d = dt*16 + 4 fg + r, key = kt*16 + fr
+  f32x4 acc_dk[DT][WT], acc_dv[DT][WT];  // [d tile][key tile]: lane holds d = dt*16 + 4 fg + r, key = kt*16 + fr
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc_dk[i][0] = acc_dk[i][1] = acc_dv[i][0] = acc_dv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int kt = 0; kt < WT; ++kt) acc_dk[i][kt] = acc_dv[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int a_base[KS_D];  // A rows of the first products: row fr of a 16-query tile, chunk ks*4 + fg
 #pragma unroll
@@ -223,19 +228,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
     const float* del_t = st_lds + (buf * 2 + 1) * BT;
 
     // ---- S = Q K^T, dP = dO V^T : acc[qt][kt][r] <-> query qt*16 + 4 fg + r, key kt*16 + fr
-    f32x4 acc_s[4][2], acc_dp[4][2];
+    f32x4 acc_s[4][WT], acc_dp[4][WT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) acc_s[qt][0] = acc_s[qt][1] = acc_dp[qt][0] = acc_dp[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < WT; ++kt) acc_s[qt][kt] = acc_dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
         const uint4 qa = *reinterpret_cast<const uint4*>(qt_lds + a_base[ks] + qt * 16 * ROWB);
         const uint4 da = *reinterpret_cast<const uint4*>(dot_lds + a_base[ks] + qt * 16 * ROWB);
-        mma_kstep<E>(acc_s[qt][0], qa, kf[0][ks]);
-        mma_kstep<E>(acc_s[qt][1], qa, kf[1][ks]);
-        mma_kstep<E>(acc_dp[qt][0], da, vf[0][ks]);
-        mma_kstep<E>(acc_dp[qt][1], da, vf[1][ks]);
+#pragma unroll
+        for (int kt = 0; kt < WT; ++kt) {
+          mma_kstep<E>(acc_s[qt][kt], qa, kf[kt][ks]);
+          mma_kstep<E>(acc_dp[qt][kt], da, vf[kt][ks]);
+        }
       }
     }
     // ---- P = 2^(S sc - lse[q]) (0 for masked keys), dS = P (dP - delta[q]); acc_s <- P, acc_dp <- dS
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
           rowh[r] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fg * 4 + r)), p.seed_lo);
       }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < WT; ++kt) {
         const int key = k0 + kt * 16 + fr;
         const bool key_ok = key < len;
 #pragma unroll
@@ -269,9 +277,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
     if constexpr (ES == 2) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {  // 32-query k-steps = accumulator tiles (2kk, 2kk+1)
-        uint4 pf[2], sf[2];
+        uint4 pf[WT], sf[WT];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < WT; ++kt) {
           pf[kt].x = pack_bf16x2(acc_s[2 * kk][kt][0], acc_s[2 * kk][kt][1]);
           pf[kt].y = pack_bf16x2(acc_s[2 * kk][kt][2], acc_s[2 * kk][kt][3]);
           pf[kt].z = pack_bf16x2(acc_s[2 * kk + 1][kt][0], acc_s[2 * kk + 1][kt][1]);
@@ -285,10 +293,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
         for (int dt = 0; dt < DT; ++dt) {
           const uint4 dof = tr_frag<BF16>(dot_lds, t_base[dt], kk, ROWB);
           const uint4 qtf = tr_frag<BF16>(qt_lds, t_base[dt], kk, ROWB);
-          mma_kstep<E>(acc_dv[dt][0], dof, pf[0]);
-          mma_kstep<E>(acc_dv[dt][1], dof, pf[1]);
-          mma_kstep<E>(acc_dk[dt][0], qtf, sf[0]);
-          mma_kstep<E>(acc_dk[dt][1], qtf, sf[1]);
+#pragma unroll
+          for (int kt = 0; kt < WT; ++kt) {
+            mma_kstep<E>(acc_dv[dt][kt], dof, pf[kt]);
+            mma_kstep<E>(acc_dk[dt][kt], qtf, sf[kt]);
+          }
         }
       }
     } else {
@@ -301,10 +310,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
           for (int dt = 0; dt < DT; ++dt) {
             const float dov = *reinterpret_cast<const float*>(dot_lds + bwd_lds_off<E>(qrow, (dt * 16 + fr) * 4));
             const float qv = *reinterpret_cast<const float*>(qt_lds + bwd_lds_off<E>(qrow, (dt * 16 + fr) * 4));
-            acc_dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov, acc_s[qt][0][r], acc_dv[dt][0], 0, 0, 0);
-            acc_dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov, acc_s[qt][1][r], acc_dv[dt][1], 0, 0, 0);
-            acc_dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, acc_dp[qt][0][r], acc_dk[dt][0], 0, 0, 0);
-            acc_dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, acc_dp[qt][1][r], acc_dk[dt][1], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < WT; ++kt) {
+              acc_dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov, acc_s[qt][kt][r], acc_dv[dt][kt], 0, 0, 0);
+              acc_dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, acc_dp[qt][kt][r], acc_dk[dt][kt], 0, 0, 0);
+            }
           }
         }
     }
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
   char* dkp = reinterpret_cast<char*>(p.dk);
   char* dvp = reinterpret_cast<char*>(p.dv);
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < WT; ++kt) {
     const int key = k0 + kt * 16 + fr;
     if (key >= T) continue;
 #pragma unroll
@@ -334,12 +344,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------------------ dQ
-template <typename E, int DHP, bool DROP>
-// (two workgroups per CU asked for where the kernel fits 256 registers without spilling: left alone the compiler spent 260 on the
+// WT: 16-query tiles per wave (2 = four waves of 32 queries, 1 = eight waves of 16: see the dK/dV kernel).
+// (WT = 2: two waves per SIMD asked for where the kernel fits 256 registers without spilling: left alone the compiler spent 260 on the
 // 96-dim head -- the VAE's -- which made that variant a one-wave-per-SIMD kernel; 236 when told)
-__global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 2 : 1) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
+template <typename E, int DHP, bool DROP, int WT = 2>
+__global__ __launch_bounds__(128 / (16 * WT) * 64, WT == 1 ? (DHP <= 64 ? 4 : 2) : (std::is_same<E, BF16>::value && DHP <= 96) ? 2 : 1) void attn_bwd_dq_kernel(const AttnBwdArgs p) {
+  constexpr int NT = 128 / (16 * WT) * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using TP = TilePair<E, DHP>;
+  using TP = TilePair<E, DHP, NT>;
   constexpr int ES = Elem<E>::bytes;
   constexpr int ROWB = BwdGeom<E>::ROWB;
   constexpr int KS_D = DHP * ES / 64;
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
   int rblk, h, b;  // this workgroup's row block of (batch b, head h), XCD-aware order
   dn_xcd_block_map(rblk, h, b);
   const int T = p.T, dh = p.dim_head;
-  const int q0 = rblk * 128 + wave * 32;
+  const int q0 = rblk * 128 + wave * (16 * WT);
   const int dhb = dh * ES;
 
   const char* qp = reinterpret_cast<const char*>(p.q) + ((int64_t)b * T * p.ldq + h * dh) * ES;
@@ -373,16 +385,18 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
     out_scale = 0.f;
   }
 
-  uint4 qf[2][KS_D], dof[2][KS_D];  // B operands: row = query
-  float lse_q[2], del_q[2];
-  uint32_t drop_thr = 0, rowh[2] = {0, 0};
+  uint4 qf[WT][KS_D], dof[WT][KS_D];  // B operands: row = query
+  float lse_q[WT], del_q[WT];
+  uint32_t drop_thr = 0, rowh[WT];
+#pragma unroll
+  for (int qt = 0; qt < WT; ++qt) rowh[qt] = 0;
   float drop_inv = 1.f;
   if constexpr (DROP) {
     drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
     drop_inv = 1.0f / (1.0f - p.dropout_p);
   }
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < WT; ++qt) {
     int q = q0 + qt * 16 + fr;
     if constexpr (DROP) rowh[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + q), p.seed_lo);
     q = q < T ? q : T - 1;
@@ -396,9 +410,11 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
       dof[qt][ks] = ok ? *reinterpret_cast<const uint4*>(dop + (int64_t)q * p.lddo * ES + byte) : make_uint4(0, 0, 0, 0);
     }
   }
-  f32x4 acc_dq[DT][2];  // lane holds d = dt*16 + 4 fg + r, query qt*16 + fr
+  f32x4 acc_dq[DT][WT];  // lane holds d = dt*16 + 4 fg + r, query qt*16 + fr
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc_dq[i][0] = acc_dq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int qt = 0; qt < WT; ++qt) acc_dq[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int a_base[KS_D];
 #pragma unroll
@@ -420,19 +436,22 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
     const char* vt_lds = v_lds + buf * TILE_LDS;
 
     // ---- S^T = K Q^T, dP^T = V dO^T : acc[kt][qt][r] <-> key kt*16 + 4 fg + r, query qt*16 + fr
-    f32x4 acc_s[4][2], acc_dp[4][2];
+    f32x4 acc_s[4][WT], acc_dp[4][WT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc_s[kt][0] = acc_s[kt][1] = acc_dp[kt][0] = acc_dp[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < WT; ++qt) acc_s[kt][qt] = acc_dp[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const uint4 ka = *reinterpret_cast<const uint4*>(kt_lds + a_base[ks] + kt * 16 * ROWB);
         const uint4 va = *reinterpret_cast<const uint4*>(vt_lds + a_base[ks] + kt * 16 * ROWB);
-        mma_kstep<E>(acc_s[kt][0], ka, qf[0][ks]);
-        mma_kstep<E>(acc_s[kt][1], ka, qf[1][ks]);
-        mma_kstep<E>(acc_dp[kt][0], va, dof[0][ks]);
-        mma_kstep<E>(acc_dp[kt][1], va, dof[1][ks]);
+#pragma unroll
+        for (int qt = 0; qt < WT; ++qt) {
+          mma_kstep<E>(acc_s[kt][qt], ka, qf[qt][ks]);
+          mma_kstep<E>(acc_dp[kt][qt], va, dof[qt][ks]);
+        }
       }
     }
     // ---- dS^T = P^T (dP^T - delta[q]) -> acc_dp
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < WT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kv0 + kt * 16 + fg * 4 + r;
@@ -454,9 +473,9 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
     if constexpr (ES == 2) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        uint4 sf[2];
+        uint4 sf[WT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < WT; ++qt) {
           sf[qt].x = pack_bf16x2(acc_dp[2 * kk][qt][0], acc_dp[2 * kk][qt][1]);
           sf[qt].y = pack_bf16x2(acc_dp[2 * kk][qt][2], acc_dp[2 * kk][qt][3]);
           sf[qt].z = pack_bf16x2(acc_dp[2 * kk + 1][qt][0], acc_dp[2 * kk + 1][qt][1]);
@@ -465,8 +484,8 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const uint4 ktf = tr_frag<BF16>(kt_lds, t_base[dt], kk, ROWB);
-          mma_kstep<E>(acc_dq[dt][0], ktf, sf[0]);
-          mma_kstep<E>(acc_dq[dt][1], ktf, sf[1]);
+#pragma unroll
+          for (int qt = 0; qt < WT; ++qt) mma_kstep<E>(acc_dq[dt][qt], ktf, sf[qt]);
         }
       }
     } else {
@@ -478,8 +497,8 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const float kv = *reinterpret_cast<const float*>(kt_lds + bwd_lds_off<E>(krow, (dt * 16 + fr) * 4));
-            acc_dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, acc_dp[kt][0][r], acc_dq[dt][0], 0, 0, 0);
-            acc_dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, acc_dp[kt][1][r], acc_dq[dt][1], 0, 0, 0);
+#pragma unroll
+            for (int qt = 0; qt < WT; ++qt) acc_dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, acc_dp[kt][qt][r], acc_dq[dt][qt], 0, 0, 0);
           }
         }
     }
@@ -489,7 +508,7 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
 
   char* dqp = reinterpret_cast<char*>(p.dq);
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < WT; ++qt) {
     const int q = q0 + qt * 16 + fr;
     if (q >= T) continue;
 #pragma unroll
@@ -503,26 +522,36 @@ __global__ __launch_bounds__(256, (std::is_same<E, BF16>::value && DHP <= 96) ? 
   }
 }
 
-template <typename E, int DHP, bool DROP>
+// WK / WQ: tiles per wave of the dK/dV and of the dQ kernel
+template <typename E, int DHP, bool DROP, int WK = 2, int WQ = 2>
 static int launch_attn_bwd_v(const AttnBwdArgs& a, hipStream_t s) {
   constexpr int tile = BT * BwdGeom<E>::ROWB;
   constexpr int lds_dkv = 4 * tile + 4 * BT * (int)sizeof(float);
   constexpr int lds_dq = 4 * tile;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<E, DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<E, DHP, DROP, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<E, DHP, DROP, WQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     attr_done = true;
   }
   dim3 grid((a.T + 127) / 128, a.heads, a.B);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<E, DHP, DROP>), grid, dim3(256), lds_dkv, s, a);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<E, DHP, DROP>), grid, dim3(256), lds_dq, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<E, DHP, DROP, WK>), grid, dim3(128 / (16 * WK) * 64), lds_dkv, s, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<E, DHP, DROP, WQ>), grid, dim3(128 / (16 * WQ) * 64), lds_dq, s, a);
   DN_CHECK_LAUNCH("dn_attention_backward");
   return DN_OK;
 }
 
 template <typename E, int DHP>
 static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
+  // option attn_waves8 (default on), 2-byte mode: eight waves of one tile per workgroup where that raises the waves per SIMD -- the
+  // dK/dV kernel at every head size (96 dims: 310 -> 214 registers, one -> two waves per SIMD), the dQ kernel up to 64 dims (above,
+  // its 32-query form already holds two waves per SIMD and reads half the K / V fragments per MFMA)
+  if constexpr (Elem<E>::bytes == 2) {
+    if (option_or(OPT_ATTN_WAVES8, 1) != 0) {
+      constexpr int WQ = DHP <= 64 ? 1 : 2;
+      return a.dropout_p > 0.f ? launch_attn_bwd_v<E, DHP, true, 1, WQ>(a, s) : launch_attn_bwd_v<E, DHP, false, 1, WQ>(a, s);
+    }
+  }
   return a.dropout_p > 0.f ? launch_attn_bwd_v<E, DHP, true>(a, s) : launch_attn_bwd_v<E, DHP, false>(a, s);
 }
 

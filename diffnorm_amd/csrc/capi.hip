@@ -38,6 +38,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"wgrad_stages", "DN_WGRAD_STAGES", nullptr},          // 5: the weight-gradient kernel on a 160 KiB ring of five stages (default 4 stages = 128 KiB)
     {"tile_192", "DN_TILE_192", nullptr},                  // 0: never choose the 256 x 192 tile by score (default: where a lone launch fills the chip better on it)
     {"fused_geglu", "DN_FUSED_GEGLU", nullptr},            // 0: training forward runs the GEGLU as a pass over the projection's output (default: in its epilogue)
+    {"attn_waves8", "DN_ATTN_WAVES8", nullptr},            // 0: attention (2-byte modes) on four waves of 32 queries per workgroup (default: eight waves of 16)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;
