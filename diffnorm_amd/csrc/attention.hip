@@ -354,8 +354,10 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? (DHP <= 64 ? 4 : 2)
 // fp32 softmax output.  S^T = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi, O^T += V_lo P_hi + V_hi P_lo + V_hi P_hi; softmax, masks
 // and the denominators are fp32 as in the exact-fp32 kernel.  96 bf16 MFMAs per 64-key tile instead of 256 fp32 ones.
 // dim_head <= 64 (larger heads run the exact-fp32 kernel).
-template <int DHP, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
+// QT: 16-query tiles per wave (2 = four waves of 32 queries, 1 = eight waves of 16: attn_kernel's note)
+template <int DHP, bool DROP, int QT = 2>
+__global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_x3_kernel(const DnAttnParams p) {
+  constexpr int NT = 128 / (16 * QT) * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(DHP == 32 || DHP == 64, "padded head dim");
   using L = BF16;                     // LDS geometry and swizzle of the bf16 kernel
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
   else dn_xcd_block_map(qblk, h, b);
   const int T = p.T, dh = p.dim_head;
   const int Tk = p.Tk > 0 ? p.Tk : T;
-  const int q0 = qblk * 128 + wave * 32;
+  const int q0 = qblk * 128 + wave * (16 * QT);
   const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)b * T * p.ldq + h * dh;
   const float* kp = reinterpret_cast<const float*>(p.k) + (int64_t)b * Tk * p.ldk + h * dh;
   const float* vp = reinterpret_cast<const float*>(p.v) + (int64_t)b * Tk * p.ldv + h * dh;
@@ -384,9 +386,9 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     split_pair(v.z, v.w, hi.y, lo.y);
   };
   // Q fragments (B operand): lane (fr, fg) holds dims ks*32 + fg*8 .. +7 of query fr, as hi and lo halves
-  uint4 qh[2][KS_D], ql[2][KS_D];
+  uint4 qh[QT][KS_D], ql[QT][KS_D];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     int q = q0 + qt * 16 + fr;
     q = q < T ? q : T - 1;
 #pragma unroll
@@ -403,10 +405,14 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     }
   }
 
-  f32x4 acc_o[DT][2];
+  f32x4 acc_o[DT][QT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc_o[i][0] = acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) acc_o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m_run[qt] = NEG_BIG; l_run[qt] = 0.f; }
 
   int len = p.lengths ? p.lengths[b] : Tk;
   len = len < Tk ? len : Tk;
@@ -415,13 +421,15 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     len = Tk;
     sc = 0.f;
   }
-  uint32_t drop_thr = 0, drop_row[2] = {0, 0};
+  uint32_t drop_thr = 0, drop_row[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) drop_row[qt] = 0;
   float drop_inv = 1.f;
   if constexpr (DROP) {
     drop_thr = (uint32_t)fminf(p.dropout_p * 4294967296.0f, 4294967040.0f);
     drop_inv = 1.0f / (1.0f - p.dropout_p);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
       drop_row[qt] = dn_drop_row((uint32_t)(((int64_t)b * p.heads + h) * T + (q0 + qt * 16 + fr)), p.seed_lo);
   }
   auto dropped = [&](float pv, int qt, int key) -> float {
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
 
   // fp32 K / V tiles travel global -> registers ONE tile ahead (a tile's three-product work, ~2.5k cycles, covers a loaded L2
   // round trip; a second register set would cost the second workgroup per CU) and are split into bf16 halves on the way to LDS
-  constexpr int NPT = KV_TILE * NCH / 256;  // 16-byte chunks per thread per tensor per tile
-  constexpr int RSTEP = 256 / NCH;          // tile rows between a thread's chunks: its chunk column is the same in all of them
+  constexpr int NPT = KV_TILE * NCH / NT;  // 16-byte chunks per thread per tensor per tile
+  constexpr int RSTEP = NT / NCH;          // tile rows between a thread's chunks: its chunk column is the same in all of them
   static_assert(RSTEP % 8 == 0, "a thread's rows share one swizzle key");
   const int ld_r0 = tid / NCH, ld_ch = tid - ld_r0 * NCH;
   const bool ld_col = ld_ch * 4 < dh;
@@ -491,21 +499,23 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     const char* vt_lds = v_lds + buf * TILE_LDS;
 
     // ---- S^T = K . Q^T, three bf16 products, small terms first
-    f32x4 acc_s[4][2];
+    f32x4 acc_s[4][QT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc_s[kt][0] = acc_s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS_D; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const uint4 kh = *reinterpret_cast<const uint4*>(kt_lds + k_base_h[ks] + kt * 16 * ROWB);
         const uint4 kl = *reinterpret_cast<const uint4*>(kt_lds + k_base_l[ks] + kt * 16 * ROWB);
-        mma_kstep<BF16>(acc_s[kt][0], kl, qh[0][ks]);
-        mma_kstep<BF16>(acc_s[kt][1], kl, qh[1][ks]);
-        mma_kstep<BF16>(acc_s[kt][0], kh, ql[0][ks]);
-        mma_kstep<BF16>(acc_s[kt][1], kh, ql[1][ks]);
-        mma_kstep<BF16>(acc_s[kt][0], kh, qh[0][ks]);
-        mma_kstep<BF16>(acc_s[kt][1], kh, qh[1][ks]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_s[kt][qt], kl, qh[qt][ks]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_s[kt][qt], kh, ql[qt][ks]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_s[kt][qt], kh, qh[qt][ks]);
       }
     }
     if (more) {  // K rows to the other buffer (last read one barrier ago); the same registers then fetch the V rows
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     auto softmax_tile = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         float mx = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -558,9 +568,9 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
     // ---- O^T += V^T . P^T with P split into its bf16 halves
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 ph[2], pl[2];
+      uint4 ph[QT], pl[QT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         const int ka = kv0 + (2 * kk) * 16 + fg * 4, kb = ka + 16;
         float v8[8];
 #pragma unroll
@@ -578,12 +588,12 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
         const uint2 h0 = tr_read(vt_lds + v_base_h[dt] + (2 * kk) * 16 * ROWB), h1 = tr_read(vt_lds + v_base_h[dt] + (2 * kk + 1) * 16 * ROWB);
         const uint2 l0 = tr_read(vt_lds + v_base_l[dt] + (2 * kk) * 16 * ROWB), l1 = tr_read(vt_lds + v_base_l[dt] + (2 * kk + 1) * 16 * ROWB);
         const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        mma_kstep<BF16>(acc_o[dt][0], vl, ph[0]);
-        mma_kstep<BF16>(acc_o[dt][1], vl, ph[1]);
-        mma_kstep<BF16>(acc_o[dt][0], vh, pl[0]);
-        mma_kstep<BF16>(acc_o[dt][1], vh, pl[1]);
-        mma_kstep<BF16>(acc_o[dt][0], vh, ph[0]);
-        mma_kstep<BF16>(acc_o[dt][1], vh, ph[1]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_o[dt][qt], vl, ph[qt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_o[dt][qt], vh, pl[qt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mma_kstep<BF16>(acc_o[dt][qt], vh, ph[qt]);
       }
     }
     if (more) write_tile(v_lds, 1 - buf);
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
 
   char* op = reinterpret_cast<char*>(p.out);
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + fr;
     if (q >= T) continue;
     const float inv = 1.0f / l_run[qt];
@@ -611,21 +621,23 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const DnAttnParams p) {
   }
 }
 
-template <int DHP, bool DROP>
+template <int DHP, bool DROP, int QT = 2>
 static int launch_attn_x3_v(const DnAttnParams& p, hipStream_t s) {
   constexpr int lds = 4 * KV_TILE * AttnGeom<BF16>::ROWB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<DHP, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x3_kernel<DHP, DROP, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   dim3 grid((p.T + 127) / 128, p.heads, p.B);
-  hipLaunchKernelGGL((attn_x3_kernel<DHP, DROP>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((attn_x3_kernel<DHP, DROP, QT>), grid, dim3(128 / (16 * QT) * 64), lds, s, p);
   DN_CHECK_LAUNCH("dn_attention (split operands)");
   return DN_OK;
 }
 template <int DHP>
 static int launch_attn_x3(const DnAttnParams& p, hipStream_t s) {
+  if (option_or(OPT_ATTN_WAVES8, 1) != 0)
+    return p.dropout_p > 0.f ? launch_attn_x3_v<DHP, true, 1>(p, s) : launch_attn_x3_v<DHP, false, 1>(p, s);
   return p.dropout_p > 0.f ? launch_attn_x3_v<DHP, true>(p, s) : launch_attn_x3_v<DHP, false>(p, s);
 }
 

@@ -210,7 +210,7 @@ def test_attention_f16(ops, dh, heads, B, T):
     assert maxerr(out.float().cpu().view(B, T, hd), want) < 3e-3  # P and the output rounded to half (bf16 kernel: 2e-2)
 
 
-@pytest.mark.parametrize("half", ["f16", "bf16"])
+@pytest.mark.parametrize("half", ["f16", "bf16", "x3"])
 @pytest.mark.parametrize("dh,heads,B,T,Tk", [(64, 8, 3, 200, 0), (48, 4, 2, 515, 0), (64, 8, 2, 130, 64), (64, 2, 4, 64, 0), (16, 4, 2, 70, 0), (96, 8, 2, 300, 0),
                                              (128, 2, 1, 257, 0)])
 def test_attention_on_eight_waves_is_bit_identical(ops, hip_option, half, dh, heads, B, T, Tk):
@@ -218,7 +218,9 @@ def test_attention_on_eight_waves_is_bit_identical(ops, hip_option, half, dh, he
     two up to 64-dim heads, two instead of one above).  Every query sees the same key tiles in the same order through the same MFMA shapes: bit-identical outputs, with
     key masks, ragged and fully masked sequences, and cross-attention (Tk != T, no mask)."""
     ops_, _, _lib = ops
-    tdt = torch.float16 if half == "f16" else torch.bfloat16
+    if half == "x3" and dh > 64:
+        pytest.skip("split operands: heads over 64 dims run the exact-fp32 kernel")
+    tdt = torch.float16 if half == "f16" else torch.bfloat16 if half == "bf16" else torch.float32  # (x3: q / k / v stay plain fp32)
     hd = heads * dh
     Tkv = Tk or T
     q, k, v = seeded((B, T, hd), 1), seeded((B, Tkv, hd), 2), seeded((B, Tkv, hd), 3)
@@ -226,13 +228,13 @@ def test_attention_on_eight_waves_is_bit_identical(ops, hip_option, half, dh, he
     outs = []
     for on in (0, 1):
         hip_option("attn_waves8", on)
-        out = torch.full((B * T, hd), float("nan"), device=DEV, dtype=tdt)
+        out = torch.full((B * T, 2 * hd if half == "x3" else hd), float("nan"), device=DEV, dtype=torch.bfloat16 if half == "x3" else tdt)  # (x3: split rows)
         p = _lib.AttnParams()
         qa, ka, va = (z.view(-1, hd).to(DEV, tdt).contiguous() for z in (q, k, v))
         p.q, p.k, p.v, p.out = qa.data_ptr(), ka.data_ptr(), va.data_ptr(), out.data_ptr()
         p.ldq = p.ldk = p.ldv = p.ldo = hd
         p.B, p.T, p.Tk, p.heads, p.dim_head = B, T, Tk, heads, dh
-        p.dtype = _lib.DN_F16 if half == "f16" else _lib.DN_BF16
+        p.dtype = {"f16": _lib.DN_F16, "bf16": _lib.DN_BF16, "x3": _lib.DN_BF16X3}[half]
         p.lengths = lens.data_ptr() if lens is not None else None
         p.scale = dh ** -0.5
         _lib.check(_lib.load().dn_attention(C.byref(p), ops_._stream()), "dn_attention")
