@@ -749,6 +749,34 @@ def _unit_hash_normal(name: str, shape, scale: float) -> Tensor:
     return torch.randn(*shape, generator=g) * scale
 
 
+# The recipe-sized state dicts take 4-12 s to draw and the GPU test tier asks for the same ones once per arithmetic mode: the last few
+# are kept (callers get a fresh dict over the SAME tensors -- they are read-only by convention: tests upload or load_state_dict them).
+_SD_KEEP = 3
+_sd_recent: "OrderedDict[str, SD]" = None  # type: ignore[assignment]
+
+
+def _recent_state_dict(maker):
+    import functools
+    from collections import OrderedDict
+
+    @functools.wraps(maker)
+    def cached(cfg, seed: str = maker.__defaults__[0]):
+        global _sd_recent
+        if _sd_recent is None:
+            _sd_recent = OrderedDict()
+        key = f"{maker.__name__}|{cfg!r}|{seed}"
+        if key in _sd_recent:
+            _sd_recent.move_to_end(key)
+        else:
+            _sd_recent[key] = maker(cfg, seed)
+            while len(_sd_recent) > _SD_KEEP:
+                _sd_recent.popitem(last=False)
+        return dict(_sd_recent[key])
+
+    return cached
+
+
+@_recent_state_dict
 def make_eps_state_dict(cfg: EpsConfig, seed: str = "eps") -> SD:
     """Portable deterministic weights keyed by parameter name, in the reference's
     state-dict layout of ``Model``.  Scales follow PyTorch's default
@@ -816,6 +844,7 @@ def make_eps_state_dict(cfg: EpsConfig, seed: str = "eps") -> SD:
     return sd
 
 
+@_recent_state_dict
 def make_vae_state_dict(cfg: VaeConfig, seed: str = "vae") -> SD:
     """Deterministic weights in the state-dict layout of ``SpeechVAEEncoderDecoder``."""
     sd: SD = {}
