@@ -173,6 +173,8 @@ SYMBOLS = {
     "dn_eps_train_forward": (C.c_int, [_vp, _vp, C.POINTER(EpsTrainBatch), _vp, _sz, _vp]),
     "dn_eps_train_backward": (C.c_int, [_vp, _vp, C.POINTER(EpsTrainBatch), _i32, _i32, _vp, _sz, _vp]),
     "dn_sum_groups": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i64, _vp]),
+    "dn_rows_times_weight_scratch_bytes": (_sz, [_i32, _i32, _i32]),
+    "dn_rows_times_weight": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_transpose_weights": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "dn_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "dn_conv_weight_grad_tn": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

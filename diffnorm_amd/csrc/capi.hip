@@ -39,6 +39,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"tile_192", "DN_TILE_192", nullptr},                  // 0: never choose the 256 x 192 tile by score (default: where a lone launch fills the chip better on it)
     {"fused_geglu", "DN_FUSED_GEGLU", nullptr},            // 0: training forward runs the GEGLU as a pass over the projection's output (default: in its epilogue)
     {"attn_waves8", "DN_ATTN_WAVES8", nullptr},            // 0: attention (2-byte modes) on four waves of 32 queries per workgroup (default: eight waves of 16)
+    {"cond_stream", "DN_COND_STREAM", nullptr},            // 0: training: the data gradient of the conditioning projection from a transposed copy (default: the master matrix streamed as it lies)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;

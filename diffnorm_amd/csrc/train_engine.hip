@@ -282,6 +282,11 @@ WgPlan plan_wgrad(int cin, int cout, int n_taps, int max_shift, int B, int T, in
 
 struct WgTap { const void* x; int ldx; int shift; };
 
+// the data gradient of the conditioning projection from the row-major master matrix (dn_rows_times_weight); option
+// cond_stream = 0: from the transposed copy with a split-K contraction.  The option is read when the working copies are refreshed
+// too: switch it between updates only after a refresh.
+inline bool cond_streamed() { return option_or(OPT_COND_STREAM, 1) != 0; }
+
 
 template <typename T>
 void launch_transpose_slices(const void* src, int ld, int B, int Tn, int C, int front, const WgPlan& pl, void* dst, int rows, int rows_total,
@@ -1378,6 +1383,7 @@ EpsPlan plan_eps_train(const DnEpsTrain* m, const DnVaeTrain* vae, int B, int T,
   p.d_gb = (float*)ar.take((size_t)B * m->n_cond * 4);
   p.d_cond = (float*)ar.take((size_t)B * m->C * 4);
   p.d_cond_parts_bytes = (size_t)32 * B * m->C * 4;
+  p.d_cond_parts_bytes = std::max(p.d_cond_parts_bytes, dn_rows_times_weight_scratch_bytes(B, m->n_cond, m->C));
   p.d_cond_parts = (float*)ar.take(p.d_cond_parts_bytes);
   p.ds = (float*)ar.take((size_t)B * m->C * 4);
   p.xt = (float*)ar.take(M * zl * 4);
@@ -1554,7 +1560,9 @@ extern "C" int dn_eps_train_refresh(DnEpsTrain* m, void* stream) {
   DN_TRY(tr_strided(t.ffout_W(0), t.layer_stride, t.t_ffout, t.depth, D, ip));
   DN_TRY(tr(t.pred_W, t.t_pred, 1, D, Dp));
   DN_TRY(tr(m->final_W, m->t_final, 1, zl, Dp));
-  // the fp32 conditioning projection [n_cond][C] -> [padn(C)][n_cond], from the master buffer
+  // the fp32 conditioning projection [n_cond][C] -> [padn(C)][n_cond], from the master buffer (option cond_stream = 0 only: by default
+  // its data gradient streams the master matrix as it lies)
+  if (cond_streamed()) return DN_OK;
   return dn_transpose_weights(m->master + m->cond_W, DN_F32, 1, (int64_t)padn(m->n_cond) * m->C, m->n_cond, m->C, fder + m->f_condT,
                               (int64_t)padn(m->C) * m->n_cond, m->n_cond, padn(m->C), s);
 }
@@ -1677,7 +1685,11 @@ extern "C" int dn_eps_train_backward(DnEpsTrain* m, DnVaeTrain* vae, const DnEps
       DN_TRY(dn_colsum(pl.d_gb, m->n_cond, DN_F32, 1, B, m->n_cond, c.G(m->cond_b), 0, 1.0f, 1, pl.red_scratch, s));
       WgTap tap{pl.cond, m->C, 0};
       DN_TRY(weight_grad(cf, &tap, 1, m->C, pl.d_gb, m->n_cond, m->n_cond, c.G(m->cond_W)));
-      {
+      if (cond_streamed()) {
+        // d cond = d gb [B, n_cond] . W_c: the fp32 master matrix [n_cond][C] streamed once as it lies (dn_rows_times_weight: no
+        // transposed copy per update -- 236 us -- and no split-K contraction over it -- 235 us)
+        DN_TRY(dn_rows_times_weight(pl.d_gb, m->n_cond, B, m->master + m->cond_W, m->C, m->n_cond, m->C, pl.d_cond, pl.d_cond_parts, s));
+      } else {
         // d cond = d gb [B, n_cond] . W_c: B rows against a 57 k-deep contraction -- 16 output tiles on 256 CUs (measured 7.0 ms = 16 %
         // of a diffusion update when it ran un-split).  Split K over `ks` groups (a K-slice of the packed transpose: ldw = n_cond),
         // partial sums per group, then a fixed-order sum of the groups: every CU gets a slice and the 470 MB of weights stream once.

@@ -467,6 +467,66 @@ __global__ __launch_bounds__(256) void sum_groups_kernel(const void* __restrict_
   }
 }
 
+// part[s][b][c] = sum over the slice's rows n of X[b][n] * W[n][c]: a handful of rows (B <= RB) against a huge ROW-MAJOR fp32 matrix
+// W [N][C] -- the data gradient of the conditioning projection (d cond = d gb [B, 57 k] . W_c [57 k, 2048], 470 MB of weights).  The
+// matrix is streamed exactly once, as it lies (whole rows, float4 per thread, eight rows in flight per thread): no transposed copy
+// to make per update and no MFMA tile that is 1/8 full.  A workgroup owns 1024 columns x one slice of rows; the slice's X values go
+// through LDS in chunks of 64 rows ([n][b] order: a thread reads its RB multipliers of a row as broadcast float4s).
+template <int RB>
+__global__ __launch_bounds__(256) void rows_times_weight_kernel(const float* __restrict__ X, int ldx, int B, const float* __restrict__ W, int ldw,
+                                                                int N, int C, int per, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float xs[64][RB];
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int n_begin = blockIdx.y * per;
+  int n_end = n_begin + per;
+  n_end = n_end < N ? n_end : N;
+  float4 acc[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * RB; i += 256) {  // xs[j][b] = X[b][n0 + j]: consecutive threads read consecutive n of one row b
+      const int b = i >> 6, j = i & 63;
+      xs[j][b] = (b < B && n0 + j < n_end) ? X[(int64_t)b * ldx + n0 + j] : 0.f;
+    }
+    __syncthreads();
+    if (c < C) {
+      const int rows = n_end - n0 < 64 ? n_end - n0 : 64;
+      const float* wp = W + (int64_t)n0 * ldw + c;
+      int j = 0;
+      for (; j + 8 <= rows; j += 8) {
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (int64_t)(j + u) * ldw);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int b4 = 0; b4 < RB / 4; ++b4) {
+            const float4 x = *reinterpret_cast<const float4*>(&xs[j + u][b4 * 4]);
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4& a = acc[b4 * 4 + q];
+              a.x = fmaf(xv[q], w[u].x, a.x); a.y = fmaf(xv[q], w[u].y, a.y); a.z = fmaf(xv[q], w[u].z, a.z); a.w = fmaf(xv[q], w[u].w, a.w);
+            }
+          }
+      }
+      for (; j < rows; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(wp + (int64_t)j * ldw);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const float xv = xs[j][b];
+          acc[b].x = fmaf(xv, w.x, acc[b].x); acc[b].y = fmaf(xv, w.y, acc[b].y); acc[b].z = fmaf(xv, w.z, acc[b].z); acc[b].w = fmaf(xv, w.w, acc[b].w);
+        }
+      }
+    }
+  }
+  if (c < C)
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+      if (b < B) *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * B + b) * C + c) = acc[b];
+}
+
 // Batched padded transpose of packed weight matrices (the operand of the data-gradient contraction):
 // dst[n][c][r] = src[n][r][c] for r < R, c < Cc; dst matrices are [Cp][Rp] with zeros elsewhere; consecutive matrices lie
 // src_stride / dst_stride elements apart (src rows beyond R -- the zero pad rows of a packed weight -- are not read).
@@ -776,6 +836,32 @@ extern "C" int dn_sum_groups(const void* src, int64_t stride, int32_t count, voi
   DN_CHECK_ARG(src && dst && count >= 1 && n > 0 && n % 4 == 0 && stride % 4 == 0, "dn_sum_groups: bad args");
   hipLaunchKernelGGL(sum_groups_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, S_(stream), src, stride, count, dst, dtype, n);
   DN_CHECK_LAUNCH("dn_sum_groups");
+  return DN_OK;
+}
+
+extern "C" size_t dn_rows_times_weight_scratch_bytes(int32_t B, int32_t N, int32_t C) {
+  const int slices = N >= 128 * 64 ? 128 : (N + 63) / 64;
+  return (size_t)slices * (B < 32 ? B : 32) * C * sizeof(float);
+}
+
+// see include/diffnorm_hip.h
+extern "C" int dn_rows_times_weight(const float* X, int32_t ldx, int32_t B, const float* W, int32_t ldw, int32_t N, int32_t C, float* out,
+                                    float* scratch, void* stream) {
+  DN_CHECK_ARG(X && W && out && scratch && B >= 1 && N >= 1 && C >= 4 && C % 4 == 0 && ldw % 4 == 0 && ldw >= C && ldx >= N,
+               "dn_rows_times_weight: bad args (C and ldw multiples of 4; B=%d N=%d C=%d)", B, N, C);
+  DN_CHECK_ARG(((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)scratch & 15) == 0, "dn_rows_times_weight: 16-byte alignment");
+  const int slices = N >= 128 * 64 ? 128 : (N + 63) / 64;      // about a slice per CU-half: 256 workgroups at C = 2048
+  const int per = ((N + slices - 1) / slices + 63) / 64 * 64;  // whole 64-row chunks
+  dim3 grid((C / 4 + 255) / 256, (N + per - 1) / per);
+  for (int b0 = 0; b0 < B; b0 += 32) {  // more than 32 rows: one stream of the matrix per 32
+    const int nb = B - b0 < 32 ? B - b0 : 32;
+    const float* Xb = X + (int64_t)b0 * ldx;
+    if (nb <= 16) hipLaunchKernelGGL(rows_times_weight_kernel<16>, grid, dim3(256), 0, S_(stream), Xb, ldx, nb, W, ldw, N, C, per, scratch);
+    else hipLaunchKernelGGL(rows_times_weight_kernel<32>, grid, dim3(256), 0, S_(stream), Xb, ldx, nb, W, ldw, N, C, per, scratch);
+    DN_CHECK_LAUNCH("dn_rows_times_weight");
+    const int rc = dn_sum_groups(scratch, (int64_t)nb * C, (int)grid.y, out + (int64_t)b0 * C, DN_F32, (int64_t)nb * C, stream);
+    if (rc != DN_OK) return rc;
+  }
   return DN_OK;
 }
 

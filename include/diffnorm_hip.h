@@ -418,6 +418,13 @@ int dn_vec_sum(const float* v, int64_t n, float* out, int32_t accumulate, float*
 
 /* dst[i] = sum_{k < count} src[k * stride + i], i < n (the gradients a tensor receives from several consumers). */
 int dn_sum_groups(const void* src, int64_t stride, int32_t count, void* dst, int32_t dtype, int64_t n, void* stream);
+/* out[b][c] = sum_n X[b][n] * W[n][c], fp32: a handful of rows (one stream of W per 32) against a huge ROW-MAJOR matrix W [N, ldw] (C valid columns), streamed once
+ * as it lies -- the data gradient of the eps-predictor's conditioning projection (autograd of nn.Linear, latent_module.py:841-852),
+ * without a transposed copy of its 470 MB.  Partial sums per row slice in `scratch` (dn_rows_times_weight_scratch_bytes), added in a
+ * fixed order.                                                                                                                     */
+size_t dn_rows_times_weight_scratch_bytes(int32_t B, int32_t N, int32_t C);
+int dn_rows_times_weight(const float* X, int32_t ldx, int32_t B, const float* W, int32_t ldw, int32_t N, int32_t C, float* out,
+                         float* scratch, void* stream);
 
 /* Batched padded transpose of packed weights, the W operand of the data-gradient contraction: dst[n] [Cp][Rp] = (the first
  * R rows of src[n], [R][Cc])^T, zeros beyond; matrices src_stride / dst_stride elements apart.                           */

@@ -334,3 +334,24 @@ def test_weight_gradient_f32(ops, cin, cout, k, dil, B, T):
     dya = pad(dy, packing.padk(cout)).view(B * T, -1).to(DEV)
     got = ops_.conv_weight_grad(xa, dya, T, cin, cout, [(k - 1 - j) * dil for j in range(k)])
     assert relerr(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,C", [(16, 57344, 2048), (3, 1000, 256), (20, 9000, 516), (40, 700, 1028)])
+def test_rows_times_weight(ops, B, N, C):
+    """dn_rows_times_weight: out = X [B, N] . W [N, C] with W row-major and streamed once (the data gradient of the eps-predictor's
+    conditioning projection, autograd of nn.Linear latent_module.py:841-852): the recipe's shape, ragged row slices, column counts off the
+    1024-column workgroup, and more than 32 rows (one stream per 32)."""
+    import ctypes as C_
+
+    ops_, _, _lib = ops
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(B, N, generator=g)
+    W = torch.randn(N, C, generator=g) * N ** -0.5
+    Xd, Wd = X.to(DEV), W.to(DEV)
+    out = torch.full((B, C), float("nan"), device=DEV)
+    lib = _lib.load()
+    scratch = torch.empty(int(lib.dn_rows_times_weight_scratch_bytes(B, N, C)) // 4 + 4, device=DEV)
+    _lib.check(lib.dn_rows_times_weight(Xd.data_ptr(), N, B, Wd.data_ptr(), C, N, C, out.data_ptr(), scratch.data_ptr(), ops_._stream()),
+               "dn_rows_times_weight")
+    want = X.double() @ W.double()
+    assert (out.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
