@@ -2529,13 +2529,18 @@ static inline int choose_tile(const DnGemmParams& p) {
     const double rounds = (double)tiles / (256.0 * per_cu);
     return rounds / ceil(rounds);
   };
-  // The taps of a causal conv share one staged copy of their rows on the 256 x 256 tile only, and a long-K contraction has no
-  // prologue / epilogue for a neighbour workgroup to cover: there the smaller tiles are worth 0.72-0.78 of it per output, not 0.9
-  // (conv k = 3, 2048 wide, M = 12288: 265 us on 384 tiles of 256 x 256 = 1.5 rounds against 285 us on 1536 of 128 x 128 = 3 full
-  // rounds; M = 15360: 293 against 411).  DN_GEMM_HEUR=4: the short-K factors for every shape (A/B timing).
-  const bool long_taps = heur != 4 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && (long)p.K * p.n_terms >= 1024 && terms_are_taps(p);
-  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = (long_taps ? 0.78 : 0.90) * fill(tiles_mid, 1),
-               s_small = (long_taps ? 0.72 : 0.92) * fill(tiles_small, 2);
+  // A long-K contraction of several terms (a conv's taps, forward or backward-data) has no prologue / epilogue for a neighbour
+  // workgroup to cover: there the smaller tiles are worth 0.72-0.78 of the 256 x 256 tile per output, not 0.9 -- and 0.60-0.68 where the
+  // taps share one staged copy of their rows, which only the 256 x 256 tile does.  Measured, bf16, conv k = 3, 2048 wide, M = 12288
+  // (tools/bwd_tiles.py): forward 244 us on 384 tiles of 256 x 256 (1.5 rounds, shared rows) against 269 on 768 of 256 x 128 and 309
+  // on 1536 of 128 x 128 (3 full rounds each); backward-data (negative shifts: no shared rows) 268 / 259 / 281.  M = 15360: 293
+  // against 411.  DN_GEMM_HEUR=4: the short-K factors for every shape (A/B timing).
+  const bool multi_long = heur != 4 && (p.epilogue == DN_EPI_BIAS || p.epilogue == DN_EPI_FILM_GATE) && p.n_terms >= 2 && (long)p.K * p.n_terms >= 1024;
+  const bool long_taps = multi_long && terms_are_taps(p);
+  const bool shares = long_taps && big_taps_share_rows(p, 32) && heur != 5;
+  const bool long_k = heur == 5 ? long_taps : multi_long;  // DN_GEMM_HEUR=5: the rule before round 4's recalibration (taps only, no shared-row factor; A/B timing)
+  const double s_big = 1.00 * fill(tiles_big, 1), s_mid = (shares ? 0.68 : long_k ? 0.78 : 0.90) * fill(tiles_mid, 1),
+               s_small = (shares ? 0.60 : long_k ? 0.72 : 0.92) * fill(tiles_small, 2);
   // The 256 x 192 form of the 256 x 256 kernel (tile 8; BIAS and RESADD epilogues, 2-byte operands, not the taps of a long conv: those
   // share staged rows on the 256-wide form only): widths that are whole multiples of 192 but leave 256-wide tiles a ragged round --
   // the VAE's N = 768 contractions at M = 12288 are 144 tiles of 256 x 256 (0.56 of one round) but 192 of 256 x 192 (0.75 of one,
