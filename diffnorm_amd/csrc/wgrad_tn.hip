@@ -13,6 +13,7 @@
 // [n][k]), B operand = dY^T.  Tile 256 (k) x 256 (n), 8 waves of 64 x 128, the 256 x 256 forward kernel's pipeline: 4-stage ring
 // of 32 KiB K-tiles, two wave groups staggered by one segment (L = DMA issue + fragment reads, C = 32 MFMAs), counted vmcnt waits.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include "common.h"
 #include "engine.h"
@@ -60,14 +61,20 @@ constexpr int TSTAGE = 2 * TTILE;    // X tile, then dY tile
 // byte offset of 8-byte piece `byte` of frame row `row` (0..31) in a tile: 32-byte granules swizzled with the row
 __device__ __forceinline__ int tn_off(int row, int byte) { return row * TROW + ((((byte >> 5) ^ (row & 15))) << 5) + (byte & 31); }
 
-template <int TSTAGES>
+// KW: k columns of a tile.  256 = 8 waves of 64 x 128; 192 = 8 waves of 48 x 128 (three A fragments instead of four: 22 transposing
+// reads per 24 MFMAs instead of 24 per 32) for the shapes whose 256-wide tiles leave a quarter of the chip idle -- the VAE's FFN conv:
+// 6144 x 2048 is 24 x 8 = 192 tiles of 256 x 256 but 32 x 8 = 256 of 192 x 256.  The LDS layout keeps its 512-byte row pitch; the
+// X tile's columns beyond 192 are not fetched (zero page).
+template <int TSTAGES, int KW = 256>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
+  constexpr int WKC = KW / 4;   // k columns of a wave: 64 or 48
+  constexpr int NA = WKC / 16;  // its A fragments
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave >> 1, wn = wave & 1;  // wave tile: k columns [64 wk, +64) x n columns [128 wn, +128)
-  const int k_tiles = (p.n_total + 255) / 256;
-  const int kq0 = (blockIdx.x % k_tiles) * 256, n0 = (blockIdx.x / k_tiles) * 256;
+  const int wk = wave >> 1, wn = wave & 1;  // wave tile: k columns [WKC wk, +WKC) x n columns [128 wn, +128)
+  const int k_tiles = (p.n_total + KW - 1) / KW;
+  const int kq0 = (blockIdx.x % k_tiles) * KW, n0 = (blockIdx.x / k_tiles) * 256;
   const int slice = blockIdx.y;
   const int g = blockIdx.z;
   const int f_begin = slice * p.frames_per_slice;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
     const int kq = kq0 + cs * 8;
     int tap = kq / p.rows_w;
     const int k = kq - tap * p.rows_w;
-    const bool ok = kq < p.n_total && k < p.cin;  // (a chunk that straddles cin relies on the buffer's zero pad columns)
+    const bool ok = kq < p.n_total && k < p.cin && cs * 8 < KW;  // (a chunk that straddles cin relies on the buffer's zero pad columns)
     tap = tap < p.n_taps ? tap : 0;
     x_shift[i] = p.shift_by_group ? p.shift[tap] << g : p.shift[tap];
     x_col_ok[i] = ok;
@@ -119,9 +126,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
     }
   };
 
-  f32x4 acc[4][8];
+  f32x4 acc[NA][8];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -129,12 +136,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
   // 32-byte block of its 16 columns; + 16 rows for the upper half of the k-values
   const int fr = lane & 15, fg = lane >> 4;
   const int rrow = fg * 4 + (fr >> 2);
-  int a_rd[4], b_rd[8];
+  int a_rd[NA], b_rd[8];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) a_rd[a] = tn_off(rrow, (wk * 64 + a * 16) * 2 + (fr & 3) * 8);
+  for (int a = 0; a < NA; ++a) a_rd[a] = tn_off(rrow, (wk * WKC + a * 16) * 2 + (fr & 3) * 8);
 #pragma unroll
   for (int b = 0; b < 8; ++b) b_rd[b] = TTILE + tn_off(rrow, (wn * 128 + b * 16) * 2 + (fr & 3) * 8);
-  uint4 af[4], bf[8];
+  uint4 af[NA], bf[8];
   auto tr = [&](const char* base, int off) -> uint2 {
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
     return __builtin_bit_cast(uint2, v);
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
   auto load_frags = [&](int slot) {
     const char* sb = smem + slot * TSTAGE;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
       const uint2 lo = tr(sb, a_rd[a]), hi = tr(sb, a_rd[a] + 16 * TROW);  // (row + 16 keeps row & 15: same swizzle)
       af[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
 #pragma unroll
     for (int b = 0; b < 8; ++b)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) mma_kstep<BF16>(acc[a][b], af[a], bf[b]);
+      for (int a = 0; a < NA; ++a) mma_kstep<BF16>(acc[a][b], af[a], bf[b]);
   };
 
   constexpr int PER = 4;  // DMA pieces per wave per stage
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgTnParams p) {
     const int n = n0 + wn * 128 + b * 16 + fr;
     if (n >= p.cout) continue;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int kq = kq0 + wk * 64 + a * 16 + fg * 4;
+    for (int a = 0; a < NA; ++a) {
+      const int kq = kq0 + wk * WKC + a * 16 + fg * 4;
       if (kq >= p.n_total) continue;
       const int tap = kq / p.rows_w, k = kq - tap * p.rows_w;
       f32x4 v = acc[a][b];
@@ -268,9 +275,20 @@ int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, co
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TSTAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tn_kernel<4, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
     attr_done = true;
   }
-  dim3 grid(((p.n_total + 255) / 256) * ((cout + 255) / 256), slices, groups);
+  // k columns of a tile: option wgrad_k192 = 1 -> 192 where that fills the chip better than 256.  Off: measured on the VAE's FFN conv
+  // (192 -> 256 workgroups) the kernel alone gains 7 % (352 -> 328 us, 0.35 -> 0.37 of peak), but the update LOSES 1.7 % (16.11 ->
+  // 16.39 ms, three alternating pairs): the kernel runs on the second stream beside the data-gradient chain, and a launch that takes
+  // every CU for 330 us starves the chain that 192 workgroups left 64 CUs to.
+  const long n_tiles = (cout + 255) / 256, per = (long)slices * groups;
+  auto fill = [](long tiles) { const double r = (double)tiles / 256.0; return r / ceil(r); };
+  const long t256 = ((p.n_total + 255) / 256) * n_tiles * per, t192 = ((p.n_total + 191) / 192) * n_tiles * per;
+  // per output a 192-wide tile costs 22 / 24 transposing reads per MFMA against 24 / 32: worth 0.82 of the 256-wide one on a full chip
+  const bool k192 = option_or(OPT_WGRAD_K192, 0) != 0 && per == 1 /* (the sliced launches' slice counts were chosen for 256-wide tiles) */ && 0.82 * fill(t192) * p.n_total / (192.0 * ((p.n_total + 191) / 192)) >
+                                                             fill(t256) * p.n_total / (256.0 * ((p.n_total + 255) / 256));
+  dim3 grid((k192 ? (p.n_total + 191) / 192 : (p.n_total + 255) / 256) * (unsigned)n_tiles, slices, groups);
   const bool timed = tag != 0 && g_prof.cap > 0 && tag == g_prof.tag && g_prof.n < g_prof.cap;
   // option wgrad_stages = 5: the 160 KiB ring (A/B timing: measured level with the 128 KiB one, 353 vs 354 us on the VAE's FFN-conv
   // gradient -- the loop is not waiting for its operands).  Also measured and dropped (round 4): four waves of 128 x 128 with the
@@ -278,7 +296,8 @@ int wgrad_tn_launch(const void* dy, int lddy, int cout, const void* const* x, co
   // 434 vs 343 us: with one wave per SIMD the compiler's schedule leaves the LDS round trips of a K-tile exposed.
   const bool deep = option_or(OPT_WGRAD_STAGES, 4) >= 5;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
-  if (deep) hipLaunchKernelGGL(wgrad_tn_kernel<5>, grid, dim3(512), 5 * TSTAGE, (hipStream_t)stream, p);
+  if (k192) hipLaunchKernelGGL((wgrad_tn_kernel<4, 192>), grid, dim3(512), 4 * TSTAGE, (hipStream_t)stream, p);
+  else if (deep) hipLaunchKernelGGL(wgrad_tn_kernel<5>, grid, dim3(512), 5 * TSTAGE, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(wgrad_tn_kernel<4>, grid, dim3(512), 4 * TSTAGE, (hipStream_t)stream, p);
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n++ + 1], (hipStream_t)stream);
   DN_CHECK_LAUNCH("dn_conv_weight_grad_tn");
