@@ -41,6 +41,7 @@ const OptDef kOpts[dn::OPT_COUNT] = {
     {"attn_waves8", "DN_ATTN_WAVES8", nullptr},            // 0: attention (2-byte modes) on four waves of 32 queries per workgroup (default: eight waves of 16)
     {"cond_stream", "DN_COND_STREAM", nullptr},            // 0: training: the data gradient of the conditioning projection from a transposed copy (default: the master matrix streamed as it lies)
     {"wgrad_k192", "DN_WGRAD_K192", nullptr},              // 1: the weight-gradient kernel on 192 k-columns per tile where that fills the chip better (default off: faster alone, slower beside the data-gradient chain)
+    {"wgrad_prio", "DN_WGRAD_PRIO", nullptr},              // 1: the weight-gradient stream at the lowest priority (read when the stream is created; measured level, default off)
 };
 std::atomic<int> g_opt[dn::OPT_COUNT];
 std::once_flag g_opt_once;

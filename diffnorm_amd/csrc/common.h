@@ -240,7 +240,7 @@ void dn_set_error(const char* fmt, ...);
 // variable of the same meaning, read ONCE when the library first looks (a process-wide default), and is switched afterwards through
 // the C ABI only -- no per-launch getenv, no environment mutation by callers.  DN_OPT_UNSET: neither set nor in the environment.
 namespace dn {
-enum Opt { OPT_TAPS_INNER = 0, OPT_FUSE_NORM, OPT_NO_SPLIT_NORM, OPT_KBLOCK, OPT_WGRAD_STREAM, OPT_WGRAD_TN, OPT_WGRAD_GROUPS, OPT_QKV_192, OPT_MID2, OPT_WGRAD_STAGES, OPT_TILE_192, OPT_FUSED_GEGLU, OPT_ATTN_WAVES8, OPT_COND_STREAM, OPT_WGRAD_K192, OPT_COUNT };
+enum Opt { OPT_TAPS_INNER = 0, OPT_FUSE_NORM, OPT_NO_SPLIT_NORM, OPT_KBLOCK, OPT_WGRAD_STREAM, OPT_WGRAD_TN, OPT_WGRAD_GROUPS, OPT_QKV_192, OPT_MID2, OPT_WGRAD_STAGES, OPT_TILE_192, OPT_FUSED_GEGLU, OPT_ATTN_WAVES8, OPT_COND_STREAM, OPT_WGRAD_K192, OPT_WGRAD_PRIO, OPT_COUNT };
 constexpr int DN_OPT_UNSET = -2147483647 - 1;
 int option(Opt o);                       // current value or DN_OPT_UNSET
 inline int option_or(Opt o, int dflt) { const int v = option(o); return v == DN_OPT_UNSET ? dflt : v; }
