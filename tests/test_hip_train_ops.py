@@ -355,3 +355,32 @@ def test_rows_times_weight(ops, B, N, C):
                "dn_rows_times_weight")
     want = X.double() @ W.double()
     assert (out.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,k,B,T", [(2048, 2048, 3, 2, 320), (1365, 1365, 3, 3, 100), (704, 2048, 1, 1, 515)])
+def test_weight_gradient_on_192_column_tiles_is_bit_identical(ops, hip_option, cin, cout, k, B, T):
+    """Option wgrad_k192: the row-major weight-gradient kernel on tiles of 192 k-columns (eight waves of 48 x 128) where that fills the
+    chip better than 256 -- the VAE's FFN conv shape 6144 x 2048 (192 -> 256 workgroups), a width off both grids, and a shape where the
+    score keeps 256.  Every output sums its frames in the same order: bit-identical to the 256-column tiles, and right."""
+    ops_, _, _lib = ops
+    M = B * T
+    cinp, coutp = (cin + 63) // 64 * 64, (cout + 63) // 64 * 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.zeros(M, cinp)
+    dy = torch.zeros(M, coutp)
+    x[:, :cin] = torch.randn(M, cin, generator=g)
+    dy[:, :cout] = torch.randn(M, cout, generator=g) * 0.1
+    xb, dyb = x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16)
+    shifts = [k - 1 - j for j in range(k)]
+    outs = []
+    for on in (0, 1):
+        hip_option("wgrad_k192", on)
+        outs.append(ops_.conv_weight_grad_tn(xb, dyb, T, cin, cout, shifts).cpu())
+    assert torch.equal(outs[0], outs[1])
+    xr, dr = xb.float().cpu().view(B, T, cinp)[..., :cin], dyb.float().cpu().view(B, T, coutp)[..., :cout]
+    for j, sft in enumerate(shifts):
+        xs = torch.zeros_like(xr)
+        xs[:, sft:] = xr[:, :T - sft]
+        want = torch.einsum("btn,btc->nc", dr, xs)
+        assert (outs[1][j] - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+
